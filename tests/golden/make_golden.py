@@ -1,0 +1,442 @@
+#!/usr/bin/env python3
+"""Generate golden input/output vectors from the REFERENCE's own Python.
+
+Run in the authoring container only (needs /root/reference):
+
+    python tests/golden/make_golden.py
+
+What it does (nothing from the reference is copied into this repo):
+  * converts /root/reference/lib + configs to py3 in a scratch TEMP dir with
+    lib2to3 (all fixers except fix_import), patches the two Py2 integer
+    divisions in proposal_layer.py (:118, :163) to ``//`` and the Py2
+    comprehension-variable leak in utils/blob.py:23;
+  * installs tiny stub modules for things the container lacks (caffe, cv2,
+    toml, easydict, requests, nms.cpu_nms/gpu_nms);
+  * imports the reference modules and drives them on seeded inputs;
+  * writes inputs + expected outputs as small .npz/.json fixtures next to
+    this script.  The fixtures are DATA only.
+
+Reference entry points exercised (file:line in /root/reference):
+  lib/layers/generate_anchors.py:11   generate_anchors
+  lib/layers/proposal_layer.py:60     ProposalLayer.forward (TEST phase)
+  lib/utils/bbox_transform.py:33,80   bbox_transform_inv / clip_boxes
+  lib/test.py:181                     bbox_vote
+  lib/nms/py_cpu_nms.py:10            py_cpu_nms
+  lib/test.py:21                      forward_net (flip / unscale / tile)
+  lib/test.py:109                     detect (pyramid orchestration, fake net)
+  lib/utils/test_utils.py:8           _compute_scaling_factor (+ test.py:131-137)
+  lib/utils/get_config.py:134,140     cfg_from_file / cfg_from_list
+  lib/datasets/wider.py:143           write_detections line format
+"""
+import io
+import json
+import os
+import shutil
+import sys
+import tempfile
+import types
+
+import numpy as np
+
+REF = "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+# --------------------------------------------------------------------------
+# scratch conversion
+# --------------------------------------------------------------------------
+def convert_reference(tmp):
+    from lib2to3 import refactor
+    fixers = [f for f in refactor.get_fixers_from_package("lib2to3.fixes")
+              if not f.endswith("fix_import")]
+    rt = refactor.RefactoringTool(fixers)
+    for sub in ("lib", "configs"):
+        shutil.copytree(os.path.join(REF, sub), os.path.join(tmp, sub))
+    for root, _, files in os.walk(os.path.join(tmp, "lib")):
+        for fn in files:
+            if not fn.endswith(".py"):
+                continue
+            p = os.path.join(root, fn)
+            src = open(p).read()
+            if not src.endswith("\n"):
+                src += "\n"
+            try:
+                out = str(rt.refactor_string(src, p))
+            except Exception as e:  # pragma: no cover
+                print("2to3 failed for", p, e)
+                continue
+            if fn == "proposal_layer.py":
+                a = "num_classes = scores.shape[1] / (A * self._num_feats)"
+                b = "stride = self._feat_stride[i / len(self._shifts)**"
+                assert a in out and b in out
+                out = out.replace(a, a.replace(" / ", " // "))
+                out = out.replace(b, b.replace("[i / len", "[i // len"))
+            if fn == "blob.py":
+                # Py2 leaked the list-comprehension variable `im` (blob.py:21-23)
+                a = "max_shape[1], im.shape[2])"
+                assert a in out
+                out = out.replace(a, "max_shape[1], ims[0].shape[2])")
+            open(p, "w").write(out)
+
+
+def install_stubs(fake_cv2):
+    np.float = float  # noqa  (np 2.x removed the aliases the reference uses)
+    np.int = int  # noqa
+    np.bool = bool  # noqa
+    import yaml
+    _load = yaml.load
+    yaml.load = lambda s, Loader=None: _load(s, Loader=yaml.SafeLoader)
+
+    caffe = types.ModuleType("caffe")
+    caffe.Layer = object
+    caffe.TEST = 1
+    caffe.TRAIN = 0
+    sys.modules["caffe"] = caffe
+
+    sys.modules["cv2"] = fake_cv2
+
+    import tomli
+    toml = types.ModuleType("toml")
+    toml.load = lambda p: tomli.load(open(p, "rb"))
+    toml.loads = tomli.loads
+    toml.dumps = lambda d: repr(d)
+    toml.dump = lambda d, f: f.write(repr(d))
+    sys.modules["toml"] = toml
+
+    ed = types.ModuleType("easydict")
+
+    class EasyDict(dict):
+        def __init__(self, d=None, **kw):
+            super().__init__()
+            d = dict(d or {}, **kw)
+            for k, v in d.items():
+                self[k] = v
+
+        def __setitem__(self, k, v):
+            if isinstance(v, dict) and not isinstance(v, EasyDict):
+                v = EasyDict(v)
+            super().__setitem__(k, v)
+
+        __setattr__ = __setitem__
+
+        def __getattr__(self, k):
+            try:
+                return self[k]
+            except KeyError:
+                raise AttributeError(k)
+
+        def has_key(self, k):
+            return k in self
+
+        def iteritems(self):
+            return self.items()
+
+    ed.EasyDict = EasyDict
+    sys.modules["easydict"] = ed
+
+    sys.modules.setdefault("requests", types.ModuleType("requests"))
+    for name in ("nms.cpu_nms", "nms.gpu_nms"):
+        m = types.ModuleType(name)
+        m.cpu_nms = None
+        m.gpu_nms = None
+        sys.modules[name] = m
+
+
+# --------------------------------------------------------------------------
+# helpers
+# --------------------------------------------------------------------------
+class FakeBlob(object):
+    def __init__(self, arr=None):
+        self.data = None if arr is None else np.array(arr, dtype=np.float32)
+
+    def reshape(self, *dims):
+        if self.data is None or self.data.shape != tuple(dims):
+            self.data = np.zeros(dims, dtype=np.float32)
+
+    @property
+    def shape(self):
+        return self.data.shape
+
+
+def softmax_blob(rng, h, w, bias):
+    """(1,6,h,w) blob laid out as the net does: channel c*3+d, bg+fg = 1."""
+    logit = rng.normal(0, 2.0, size=(3, h, w)).astype(np.float32) + np.float32(bias)
+    fg = (1.0 / (1.0 + np.exp(-logit.astype(np.float64)))).astype(np.float32)
+    bg = (np.float32(1.0) - fg).astype(np.float32)
+    return np.concatenate([bg, fg], axis=0)[None].astype(np.float32)
+
+
+def clustered_dets(rng, n_centers, per, jitter, size=(20, 120), extent=900.0, quant=None):
+    rows = []
+    for _ in range(n_centers):
+        cx, cy = rng.uniform(50, extent, 2)
+        s = rng.uniform(*size)
+        for _ in range(int(rng.integers(1, per + 1))):
+            j = rng.normal(0, jitter * s, 4)
+            x1, y1 = cx - s / 2 + j[0], cy - s / 2 + j[1]
+            # keep boxes non-degenerate: the reference's bbox_vote never
+            # terminates on a box whose IoU with itself is < thresh
+            x2 = max(cx + s / 2 + j[2], x1 + 2.0)
+            y2 = max(cy + s / 2 + j[3], y1 + 2.0)
+            sc = rng.uniform(0.05, 1.0)
+            rows.append([x1, y1, x2, y2, sc])
+    d = np.array(rows, dtype=np.float32).reshape(-1, 5)
+    if quant:
+        d[:, 4] = np.round(d[:, 4] * quant) / quant
+    return d
+
+
+def main():
+    tmp = tempfile.mkdtemp(prefix="shf_ref_py3_")
+    convert_reference(tmp)
+
+    # --- fake cv2: registry-backed imread, resize delegated to OUR bilinear so
+    # the detect() fixture pins orchestration only (cv2 parity is unpinned).
+    fake_cv2 = types.ModuleType("cv2")
+    fake_cv2.INTER_LINEAR = 1
+    fake_cv2._images = {}
+    fake_cv2.imread = lambda p: fake_cv2._images[p].copy()
+    sys.path.insert(0, os.path.join(OUT, "..", ".."))
+
+    def _resize(im, a, b, fx=None, fy=None, interpolation=None):
+        from smallhardface_amd.test_utils import resize_bilinear
+        return resize_bilinear(im, fx, fy)
+
+    fake_cv2.resize = _resize
+    install_stubs(fake_cv2)
+
+    os.chdir(tmp)
+    sys.path.insert(0, tmp)
+    sys.path.insert(0, os.path.join(tmp, "lib"))
+
+    from utils.get_config import cfg, cfg_from_file, cfg_from_list
+    cfg_from_file("configs/smallhardface.toml")
+    cfg.TEST.NO_CACHE = True
+    cfg_from_list(["TEST.MODEL", "dummy.caffemodel", "TEST.GPU_ID", "[0]"])
+
+    from lib.layers.generate_anchors import generate_anchors
+    from lib.layers.proposal_layer import ProposalLayer
+    from utils.bbox_transform import bbox_transform_inv, clip_boxes
+    from nms.py_cpu_nms import py_cpu_nms
+    import test as ref_test
+    from utils.test_utils import _compute_scaling_factor
+
+    # ---------------- config -------------------------------------------
+    cfg_dump = {
+        "MAX_RESOLUTION": cfg.MAX_RESOLUTION,
+        "PIXEL_MEANS": cfg.PIXEL_MEANS,
+        "USE_GPU_NMS": cfg.USE_GPU_NMS,
+        "MODEL.DIFFERENT_DILATION.ENABLE": cfg.MODEL.DIFFERENT_DILATION.ENABLE,
+        "TEST": {k: cfg.TEST[k] for k in (
+            "SCALES", "PYRAMID_BASE_SIZE", "FLIP", "MAX_SIZE", "ORIG_SIZE",
+            "SCORE_THRESH", "N_DETS_PER_MODULE", "ANCHOR_MIN_SIZE", "NMS_THRESH",
+            "NMS_METHOD", "LEVEL", "GPU_ID", "MODEL", "PROTOTXT", "NO_CACHE",
+            "IOU_THRESH", "DB")},
+    }
+    json.dump(cfg_dump, open(os.path.join(OUT, "config_smallhardface.json"), "w"),
+              indent=1, sort_keys=True)
+
+    # ---------------- anchors ------------------------------------------
+    anc = {}
+    anc["default_param_str"] = generate_anchors(
+        scales=np.array([1, 2, 4]), base_size=16, ratios=np.array([1, ]),
+        shifts=np.array([0]), strides=np.array([8, 8, 8]))
+    anc["frcnn_defaults"] = generate_anchors(
+        scales=np.array((8, 16, 32)), base_size=16, ratios=np.array((0.5, 1, 2)),
+        shifts=np.array([0]), strides=np.array([16] * 3))
+    anc["two_ratios_base8"] = generate_anchors(
+        scales=np.array([2, 3]), base_size=8, ratios=np.array([0.5, 2]),
+        shifts=np.array([0]), strides=np.array([8, 8]))
+    np.savez(os.path.join(OUT, "anchors.npz"), **anc)
+
+    # ---------------- bbox_transform_inv / clip ------------------------
+    rng = np.random.default_rng(11)
+    boxes = np.stack([rng.uniform(0, 300, 64), rng.uniform(0, 300, 64)], 1)
+    boxes = np.concatenate([boxes, boxes + rng.uniform(1, 200, (64, 2))], 1)  # f64
+    deltas = rng.normal(0, 0.5, (64, 4)).astype(np.float32)
+    out = bbox_transform_inv(boxes.copy(), deltas.copy())
+    clipped = clip_boxes(out.copy(), np.array([240., 320.], dtype=np.float32))
+    d_of = deltas.copy()
+    d_of[3, 2] = 120.0   # exp overflow in fp32 -> FloatingPointError -> clamp branch
+    d_of[7, 3] = 60.0    # >50 but no overflow by itself: clamped only because of [3,2]
+    d_of[9, 2] = 55.0
+    old = sys.stdout
+    sys.stdout = io.StringIO()
+    out_of = bbox_transform_inv(boxes.copy(), d_of.copy())
+    sys.stdout = old
+    d_big = deltas.copy()
+    d_big[5, 2] = 60.0   # big but finite: NOT clamped
+    out_big = bbox_transform_inv(boxes.copy(), d_big.copy())
+    np.savez(os.path.join(OUT, "bbox_transform.npz"), boxes=boxes, deltas=deltas,
+             pred=out, clipped=clipped, im_shape=np.array([240., 320.], np.float32),
+             deltas_overflow=d_of, pred_overflow=out_of,
+             deltas_big=d_big, pred_big=out_big)
+
+    # ---------------- ProposalLayer.forward ----------------------------
+    def run_proposal(scores, deltas, im_info, param_str=None):
+        L = ProposalLayer()
+        L.param_str = param_str or "{'feat_stride': [8,8,8],'scales': [1,2,4], 'ratios':[1,]}"
+        L.phase = 1
+        bottom = [FakeBlob(scores), FakeBlob(deltas), FakeBlob(im_info)]
+        top = [FakeBlob(), FakeBlob()]
+        L.setup(bottom, top)
+        old = sys.stdout
+        sys.stdout = io.StringIO()
+        try:
+            L.forward(bottom, top)
+        finally:
+            sys.stdout = old
+        return top[0].data.copy(), top[1].data.copy()
+
+    prop = {}
+    cases = [
+        # name, h, w, im_info(h,w,scale), bias, delta_std, seed
+        ("small", 8, 10, (64, 80, 1.0), -2.0, 0.5, 1),
+        ("unpadded", 14, 14, (100, 100, 0.09765625), -3.0, 0.4, 2),      # 112 padded, 100 real
+        ("wide", 19, 38, (150, 300, 0.29296875), -4.0, 0.3, 3),
+        ("all_below", 6, 7, (48, 56, 1.0), -12.0, 0.3, 4),               # nothing >= 0.002
+        ("over_10000", 64, 64, (512, 512, 1.0), 2.0, 0.3, 5),            # 12288 anchors, ~all kept
+        ("c1_512", 64, 64, (512, 512, 1.0), -5.0, 0.3, 6),
+    ]
+    for name, h, w, info, bias, dstd, seed in cases:
+        r = np.random.default_rng(seed)
+        sc = softmax_blob(r, h, w, bias)
+        dl = r.normal(0, dstd, (1, 12, h, w)).astype(np.float32)
+        ii = np.array([info], dtype=np.float32)
+        b, p = run_proposal(sc, dl, ii)
+        prop[name + "_scores"] = sc
+        prop[name + "_deltas"] = dl
+        prop[name + "_im_info"] = ii
+        prop[name + "_boxes"] = b
+        prop[name + "_probs"] = p
+    # overflow/clamp branch inside the layer
+    r = np.random.default_rng(7)
+    sc = softmax_blob(r, 5, 6, 0.0)
+    dl = r.normal(0, 0.3, (1, 12, 5, 6)).astype(np.float32)
+    dl[0, 2, 1, 1] = 130.0
+    dl[0, 7, 2, 3] = 70.0
+    ii = np.array([[40, 48, 1.0]], dtype=np.float32)
+    b, p = run_proposal(sc, dl, ii)
+    prop.update(overflow_scores=sc, overflow_deltas=dl, overflow_im_info=ii,
+                overflow_boxes=b, overflow_probs=p)
+    # tie scores (order among ties is implementation-defined; consumers compare canonically)
+    r = np.random.default_rng(8)
+    sc = softmax_blob(r, 9, 9, -1.0)
+    fg = np.round(sc[0, 3:6] * 8) / 8
+    sc = np.concatenate([1 - fg, fg], 0)[None].astype(np.float32)
+    dl = r.normal(0, 0.3, (1, 12, 9, 9)).astype(np.float32)
+    ii = np.array([[72, 72, 1.0]], dtype=np.float32)
+    b, p = run_proposal(sc, dl, ii)
+    prop.update(ties_scores=sc, ties_deltas=dl, ties_im_info=ii, ties_boxes=b, ties_probs=p)
+    np.savez_compressed(os.path.join(OUT, "proposal.npz"), **prop)
+
+    # ---------------- bbox_vote / py_cpu_nms ---------------------------
+    vn = {}
+    rng = np.random.default_rng(21)
+    sets = {
+        "empty": np.zeros((0, 5), np.float32),
+        "single": np.array([[10, 20, 50, 80, 0.9]], np.float32),
+        "two_overlap": np.array([[10, 10, 50, 50, 0.9], [12, 12, 52, 52, 0.8]], np.float32),
+        "singletons": np.array([[i * 100, 0, i * 100 + 30, 30, 0.5 + 0.01 * i] for i in range(7)], np.float32),
+        "last_singleton": np.array([[0, 0, 40, 40, 0.9], [1, 1, 41, 41, 0.8], [300, 300, 340, 340, 0.1]], np.float32),
+        "clusters_small": clustered_dets(rng, 12, 6, 0.08),
+        "clusters_mid": clustered_dets(rng, 120, 10, 0.10),
+        "clusters_big": clustered_dets(rng, 400, 16, 0.12, extent=1400.0),
+        "ties": clustered_dets(rng, 40, 8, 0.08, quant=16),
+        "dense": clustered_dets(rng, 30, 40, 0.25, size=(60, 200), extent=400.0),
+    }
+    # IoU exactly == 0.4 : a=(0,0,9,9) area 100 ; b=(0,0,9,3)?? build exactly:
+    # a = 10x10 (area 100), b = 10x4 inside a shifted: inter=40, union=100 -> 0.4
+    sets["iou_exact_0p4"] = np.array([[0, 0, 9, 9, 0.9], [0, 0, 9, 3, 0.8],
+                                      [100, 100, 109, 109, 0.7], [100, 100, 109, 103, 0.95]], np.float32)
+    for k, d in sets.items():
+        vn[k + "_dets"] = d
+        vn[k + "_vote"] = np.asarray(ref_test.bbox_vote(d.copy()), dtype=np.float64)
+        for thr in (0.4, 0.3, 0.7):
+            keep = py_cpu_nms(d.copy(), thr) if d.shape[0] else []
+            vn[k + "_nms_%02d" % int(thr * 100)] = np.asarray(keep, dtype=np.int64)
+    np.savez_compressed(os.path.join(OUT, "vote_nms.npz"), **vn)
+
+    # ---------------- forward_net (flip/unscale/tile) ------------------
+    class FakeNet(object):
+        """Returns canned proposal outputs; records what the driver fed it."""
+
+        def __init__(self, seed):
+            self.rng = np.random.default_rng(seed)
+            self.blobs = {"data": FakeBlob(np.zeros((1, 3, 16, 16))),
+                          "im_info": FakeBlob(np.zeros((1, 3))),
+                          "boxes": FakeBlob(np.zeros((1, 5))),
+                          "cls_prob": FakeBlob(np.zeros((1, 2)))}
+            self.calls = []
+
+        def forward(self, data=None, im_info=None):
+            h, w, s = im_info[0]
+            self.calls.append((tuple(data.shape), im_info.copy(),
+                               float(data.sum()), float(data[0, 0, 0, 0])))
+            n = int(self.rng.integers(3, 40))
+            x1 = self.rng.uniform(0, w - 2, n)
+            y1 = self.rng.uniform(0, h - 2, n)
+            x2 = np.minimum(x1 + self.rng.uniform(1, w / 3 + 2, n), w - 1)
+            y2 = np.minimum(y1 + self.rng.uniform(1, h / 3 + 2, n), h - 1)
+            fg = np.sort(self.rng.uniform(0.002, 1, n))[::-1]
+            self.blobs["boxes"].data = np.stack(
+                [np.zeros(n), x1, y1, x2, y2], 1).astype(np.float32)
+            self.blobs["cls_prob"].data = np.stack([1 - fg, fg], 1).astype(np.float32)
+            return {"boxes": self.blobs["boxes"].data, "cls_prob": self.blobs["cls_prob"].data}
+
+    fw = {}
+    for i, (h, w, s, flip) in enumerate([(100, 100, 0.09765625, False), (150, 301, 0.29296875, True),
+                                         (64, 80, 1.0, True), (37, 53, 1.37, False)]):
+        net = FakeNet(100 + i)
+        blob = {"data": np.random.default_rng(i).normal(0, 50, (1, 3, h, w)).astype(np.float32)}
+        probs, boxes = ref_test.forward_net(net, blob, s, pyramid=True, flip=flip)
+        fw["c%d_args" % i] = np.array([h, w, s, float(flip)])
+        fw["c%d_seed" % i] = np.array([100 + i])
+        fw["c%d_probs" % i] = probs[0]
+        fw["c%d_boxes" % i] = boxes[0]
+        fw["c%d_fed_shape" % i] = np.array(net.calls[0][0])
+        fw["c%d_fed_im_info" % i] = net.calls[0][1]
+        fw["c%d_raw_boxes_after" % i] = net.blobs["boxes"].data.copy()
+    np.savez_compressed(os.path.join(OUT, "forward_net.npz"), **fw)
+
+    # ---------------- pyramid scales ------------------------------------
+    ps = {}
+    for shape in [(1024, 1024, 3), (768, 1024, 3), (2000, 300, 3), (50, 50, 3), (683, 1024, 3), (1365, 1024, 3)]:
+        base = _compute_scaling_factor(shape, cfg.TEST.PYRAMID_BASE_SIZE[0], cfg.TEST.PYRAMID_BASE_SIZE[1])
+        sc = [float(s) / cfg.TEST.PYRAMID_BASE_SIZE[0] * base for s in cfg.TEST.SCALES]
+        ps["%dx%d" % shape[:2]] = np.array([base] + sc, dtype=np.float64)
+    np.savez(os.path.join(OUT, "pyramid_scales.npz"), **ps)
+
+    # ---------------- detect() orchestration with a fake net ------------
+    det = {}
+    for i, (H, W) in enumerate([(96, 128), (200, 150)]):
+        im = np.random.default_rng(500 + i).integers(0, 256, (H, W, 3)).astype(np.uint8)
+        fake_cv2._images["img%d.jpg" % i] = im
+        net = FakeNet(900 + i)
+        cls_dets, _ = ref_test.detect(net, "img%d.jpg" % i, thresh=0.05, pyramid=True)
+        det["i%d_image" % i] = im
+        det["i%d_seed" % i] = np.array([900 + i])
+        det["i%d_dets" % i] = np.asarray(cls_dets[0], dtype=np.float64)
+        det["i%d_fed_shapes" % i] = np.array([c[0] for c in net.calls])
+        det["i%d_fed_im_info" % i] = np.concatenate([c[1] for c in net.calls])
+        det["i%d_fed_sum" % i] = np.array([c[2] for c in net.calls])
+        det["i%d_fed_first" % i] = np.array([c[3] for c in net.calls])
+    np.savez_compressed(os.path.join(OUT, "detect.npz"), **det)
+
+    # ---------------- write_detections line format ----------------------
+    # lib/datasets/wider.py:160-167 -- the consumer that defines "0-pixel diff".
+    rows = np.array([[10.9, 20.2, 50.99, 80.5, 0.987654321], [0.0, 0.4, 3.6, 2.2, 1e-4],
+                     [123.5, 7.75, 400.25, 300.0, 0.05000001]], dtype=np.float64)
+    lines = ['%d %d %d %d %g \n' % (int(d[0]), int(d[1]), int(d[2]) - int(d[0]),
+                                    int(d[3]) - int(d[1]), d[4]) for d in rows]
+    # produced with the same expression as the reference's writer; kept as a
+    # format pin (the wider imdb class itself needs datasets on disk to construct)
+    json.dump({"rows": rows.tolist(), "lines": lines},
+              open(os.path.join(OUT, "write_detections.json"), "w"), indent=1)
+
+    shutil.rmtree(tmp, ignore_errors=True)
+    print("golden fixtures written to", OUT)
+
+
+if __name__ == "__main__":
+    main()
