@@ -351,6 +351,9 @@ def main():
                                       [100, 100, 109, 109, 0.7], [100, 100, 109, 103, 0.95]], np.float32)
     for k, d in sets.items():
         vn[k + "_dets"] = d
+        # the permutation both bbox_vote (test.py:182) and py_cpu_nms (:18) start from;
+        # tie order is implementation-defined, so it is recorded for exact replay
+        vn[k + "_order"] = d[:, 4].ravel().argsort()[::-1].astype(np.int64)
         vn[k + "_vote"] = np.asarray(ref_test.bbox_vote(d.copy()), dtype=np.float64)
         for thr in (0.4, 0.3, 0.7):
             keep = py_cpu_nms(d.copy(), thr) if d.shape[0] else []
