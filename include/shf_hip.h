@@ -1,0 +1,125 @@
+/* libshf_hip.so -- C ABI of the MI355X-native detection runtime.
+ *
+ * This is the drop-in boundary for the reference's inference hot path.  Each entry
+ * point names the reference interface it replaces (paths relative to the reference
+ * repo bairdzhang/smallhardface).  All functions return 0 on success (or a valid
+ * pointer) and non-zero / NULL on failure with a message in shf_last_error();
+ * nothing aborts the process (Caffe's glog CHECKs do).
+ *
+ * Layout contract: host-visible blob data is fp32 NCHW exactly like pycaffe
+ * (caffe/python/caffe/_caffe.cpp:222-242); the device keeps activations NHWC.
+ */
+#ifndef SHF_HIP_H_
+#define SHF_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct shf_net shf_net;
+
+/* ---- process / device ------------------------------------------------------ */
+/* caffe.set_mode_gpu()            caffe/python/caffe/_caffe.cpp:52 (set_mode_gpu)   */
+int shf_set_mode_gpu(void);
+/* caffe.set_device(id)            caffe/python/caffe/_caffe.cpp:405 (Caffe::SetDevice) */
+int shf_set_device(int device_id);
+int shf_device_count(void);
+const char* shf_last_error(void);
+const char* shf_version(void);
+
+/* ---- Net ------------------------------------------------------------------- */
+/* caffe.Net(proto, weights, phase) -- legacy 3-arg ctor, _caffe.cpp:137-151
+ * (Net::Net net.cpp:28 + CopyTrainedLayersFrom net.cpp:733).  prototxt_path may
+ * be NULL when prototxt_text is given.  caffemodel may be NULL/"" (parameters are
+ * then zero until set through shf_net_param_*).  phase: 1 = TEST. */
+shf_net* shf_net_create(const char* prototxt_path, const char* prototxt_text,
+                        const char* caffemodel_path, int phase);
+void shf_net_destroy(shf_net* net);
+
+/* Net._blob_names / Net._inputs / Net._outputs          _caffe.cpp:430-443 */
+int shf_net_num_blobs(shf_net* net);
+const char* shf_net_blob_name(shf_net* net, int i);
+int shf_net_num_inputs(shf_net* net);
+int shf_net_input_blob(shf_net* net, int i);   /* index into blobs */
+int shf_net_num_outputs(shf_net* net);
+int shf_net_output_blob(shf_net* net, int i);
+/* Net._layer_names / Layer.type / Layer.blobs           _caffe.cpp:428,480-486 */
+int shf_net_num_layers(shf_net* net);
+const char* shf_net_layer_name(shf_net* net, int i);
+const char* shf_net_layer_type(shf_net* net, int i);
+int shf_net_layer_num_params(shf_net* net, int layer);
+/* shape of param blob `idx` of layer `layer`; returns ndim (<=4) */
+int shf_net_param_shape(shf_net* net, int layer, int idx, int* dims);
+/* Host pointer to the parameter (Caffe layout: conv (Cout,Cin/g,kh,kw), bias (Cout)).
+ * Writing through it and then calling shf_net_param_commit re-packs it on the device
+ * (equivalent of writing net.params[name][i].data[...]).  Shared params
+ * (param { name: } in the prototxt, net.cpp:421-513) alias one buffer. */
+float* shf_net_param_data(shf_net* net, int layer, int idx);
+int shf_net_param_commit(shf_net* net, int layer);
+
+/* Blob.reshape(*dims)              _caffe.cpp:244-256 -> Blob::Reshape blob.cpp:23 */
+int shf_blob_reshape(shf_net* net, int blob, const int* dims, int ndim);
+/* Blob.shape                       _caffe.cpp:455-459; returns ndim */
+int shf_blob_shape(shf_net* net, int blob, int* dims);
+/* Blob.data -> mutable_cpu_data()  _caffe.cpp:222-242, syncedmem.cpp:39-64:
+ * syncs device->host (NHWC->NCHW) if the device copy is newer, marks host as head.
+ * The pointer stays valid until the blob grows. */
+float* shf_blob_mutable_host_data(shf_net* net, int blob);
+/* Net._forward(0, n-1)             _caffe.cpp:421 -> Net::ForwardFromTo net.cpp:516 */
+int shf_net_forward(shf_net* net);
+
+/* The in-graph Python layer reads cfg.TEST.{N_DETS_PER_MODULE,SCORE_THRESH,
+ * ANCHOR_MIN_SIZE} from the global config (lib/layers/proposal_layer.py:88-92);
+ * the native proposal stage takes them here. */
+int shf_net_set_proposal_cfg(shf_net* net, int pre_nms_topN, float score_thresh, float min_size);
+
+/* ---- fused per-image path (device-resident pyramid; lib/test.py:109-178) ---- */
+/* detect(): begin an image */
+int shf_detect_begin(shf_net* net);
+/* forward_net() for one (scale, flip) unit, lib/test.py:21-66: `data` is the level
+ * blob (1,3,H,W) fp32 NCHW already padded to MAX_RESOLUTION, on the device when
+ * data_on_device != 0; im_h/im_w are the UNPADDED dims that go to im_info and
+ * the flip fix; detections with fg prob > thresh are un-flipped, unscaled and
+ * appended to the image's device-side list (test.py:52-54,59-66,163-167). */
+int shf_detect_add_level(shf_net* net, const float* data, int data_on_device,
+                         int H, int W, int im_h, int im_w, float im_scale, int flip, float thresh);
+/* Box merging for the image (test.py:168-175): method 0 = BBOX_VOTE (test.py:181),
+ * 1 = NMS (lib/nms).  out5 rows are (x1,y1,x2,y2,score) as double (bbox_vote
+ * returns float64).  *n_out = number of rows (may exceed cap; only cap written). */
+int shf_detect_finish(shf_net* net, int method, float nms_thresh, double* out5, int cap, int* n_out);
+/* number of >thresh detections gathered so far for the current image */
+int shf_detect_count(shf_net* net);
+
+/* ---- stand-alone box ops ----------------------------------------------------- */
+/* nms(dets, thresh)  lib/nms/nms_wrapper.py:13 -> gpu_nms lib/nms/gpu_nms.pyx:16-31
+ * -> _nms lib/nms/gpu_nms.hpp:1 (nms_kernel.cu:102-155).  Takes UNSORTED dets
+ * (n,5) fp32 host memory and returns indices into it, score-descending, like
+ * gpu_nms.pyx:31 (`order[keep]`).  Suppression predicate IoU > thresh
+ * (nms_kernel.cu:82).  keep must hold n ints. */
+int shf_nms(const float* dets5, int n, float thresh, int device_id, int32_t* keep, int* n_keep);
+/* bbox_vote(det)     lib/test.py:181-217, thresh = cfg.TEST.NMS_THRESH.
+ * dets5 (n,5) fp32 host; out5 (cap,5) double. */
+int shf_bbox_vote(const float* dets5, int n, float thresh, double* out5, int cap, int* n_out);
+/* generate_anchors() lib/layers/generate_anchors.py:11-24; out (n_ratios*n_scales*n_shifts^2, 4) */
+int shf_generate_anchors(int base_size, const double* ratios, int n_ratios, const double* scales,
+                         int n_scales, const double* shifts, int n_shifts, const double* strides,
+                         double* out, int cap_rows);
+
+/* ---- measurement ------------------------------------------------------------- */
+/* Per-kernel-class HIP-event timing on the net's stream.  enable!=0 starts recording
+ * an event pair around every launch; shf_prof_read drains them (synchronises) and
+ * returns, for class `cls`, the number of launches, total ms and algorithmic FLOPs. */
+int shf_prof_enable(shf_net* net, int enable);
+int shf_prof_num_classes(shf_net* net);
+const char* shf_prof_class_name(shf_net* net, int cls);
+int shf_prof_read(shf_net* net, int cls, int64_t* launches, double* total_ms, double* flops, double* bytes);
+int shf_prof_reset(shf_net* net);
+/* stream synchronise (end of a timed region) */
+int shf_net_sync(shf_net* net);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SHF_HIP_H_ */

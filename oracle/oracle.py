@@ -489,6 +489,9 @@ def synth_params(net_msg, seed=1234, cls_bias=3.0):
 def infer_channels(net_msg, in_ch=3):
     """Channel count of every blob (enough shape inference to size weights)."""
     ch = {"data": in_ch, "im_info": 1}
+    for n, shp in zip(net_msg.getall("input"), net_msg.getall("input_shape")):
+        dims = shp.getall("dim")
+        ch[str(n)] = int(dims[1]) if len(dims) > 1 else 1
     for L in net_msg.getall("layer"):
         t = str(L.get("type"))
         bots = [str(b) for b in L.getall("bottom")]

@@ -1,0 +1,253 @@
+"""pycaffe-compatible surface over libshf_hip.so -- exactly the subset the
+reference's inference driver touches:
+
+  caffe.set_mode_gpu / set_device / TEST      caffe/python/caffe/__init__.py:1-8, _caffe.cpp:394-396
+  caffe.Net(proto, weights, phase)            _caffe.cpp:137-151,413
+  net.blobs (OrderedDict, topological order)  pycaffe.py:24-32
+  net.inputs / net.outputs / net.params       pycaffe.py:59-85
+  net.forward(**inputs) + its two exceptions  pycaffe.py:88-134
+  Blob.data (writable zero-copy fp32 view), .shape, .reshape(*dims), .count/.num/...
+                                              _caffe.cpp:222-256,453-477
+  caffe.Layer (param_str / phase attributes)  include/caffe/layers/python_layer.hpp:27-30
+
+Solvers, backward, forward_all, io, Classifier, NCCL are not part of the hot path.
+"""
+import ctypes as C
+from collections import OrderedDict
+
+import numpy as np
+
+from .. import _lib
+
+TRAIN = 0
+TEST = 1
+
+__all__ = ["Net", "Blob", "Layer", "TEST", "TRAIN", "set_mode_gpu", "set_mode_cpu", "set_device"]
+
+
+def set_mode_gpu():
+    _lib.check(_lib.load().shf_set_mode_gpu(), "set_mode_gpu")
+
+
+def set_mode_cpu():
+    raise _lib.ShfError("smallhardface_amd is a GPU-only runtime (no CPU mode)")
+
+
+def set_device(device_id):
+    _lib.check(_lib.load().shf_set_device(int(device_id)), "set_device")
+
+
+class Layer(object):
+    """Base class of Python layers (kept for source compatibility: the proposal
+    layer runs natively inside the runtime, nothing is called back)."""
+    param_str = ""
+    phase = TEST
+
+    def setup(self, bottom, top):
+        pass
+
+    def reshape(self, bottom, top):
+        pass
+
+    def forward(self, bottom, top):
+        pass
+
+    def backward(self, top, propagate_down, bottom):
+        pass
+
+
+class Blob(object):
+    def __init__(self, net, index, name):
+        self._net = net
+        self._i = index
+        self.name = name
+
+    @property
+    def shape(self):
+        dims = (C.c_int * 8)()
+        n = self._net._lib.shf_blob_shape(self._net._h, self._i, dims)
+        return tuple(int(dims[i]) for i in range(n))
+
+    def reshape(self, *dims):
+        arr = (C.c_int * len(dims))(*[int(d) for d in dims])
+        _lib.check(self._net._lib.shf_blob_reshape(self._net._h, self._i, arr, len(dims)), "Blob.reshape")
+
+    @property
+    def data(self):
+        """Writable fp32 view of the blob's host mirror (NCHW), like mutable_cpu_data()."""
+        p = self._net._lib.shf_blob_mutable_host_data(self._net._h, self._i)
+        if not p:
+            raise _lib.ShfError(_lib.last_error())
+        shape = self.shape
+        n = int(np.prod(shape)) if len(shape) else 1
+        if n == 0:
+            return np.zeros(shape, dtype=np.float32)
+        a = np.ctypeslib.as_array(p, shape=(n,)).reshape(shape)
+        a.flags.writeable = True
+        self._keep = self._net  # the view borrows from the net
+        return a
+
+    @property
+    def count(self):
+        return int(np.prod(self.shape))
+
+    num = property(lambda self: self.shape[0])
+    channels = property(lambda self: self.shape[1])
+    height = property(lambda self: self.shape[2])
+    width = property(lambda self: self.shape[3])
+
+
+class _ParamBlob(object):
+    """net.params[name][i]: writing through ``.data[...]`` and calling
+    ``net.commit_params()`` (or the next forward) re-packs the weights on the GPU."""
+
+    def __init__(self, net, layer, idx):
+        self._net, self._layer, self._idx = net, layer, idx
+
+    @property
+    def shape(self):
+        dims = (C.c_int * 4)()
+        n = self._net._lib.shf_net_param_shape(self._net._h, self._layer, self._idx, dims)
+        return tuple(int(dims[i]) for i in range(n))
+
+    @property
+    def data(self):
+        p = self._net._lib.shf_net_param_data(self._net._h, self._layer, self._idx)
+        shape = self.shape
+        self._net._dirty_layers.add(self._layer)
+        return np.ctypeslib.as_array(p, shape=(int(np.prod(shape)),)).reshape(shape)
+
+
+class Net(object):
+    def __init__(self, network_file, weights=None, phase=TEST, prototxt_text=None):
+        if isinstance(weights, int) and phase == TEST and weights in (TRAIN, TEST):
+            # caffe.Net(proto, phase) 2-arg form (_caffe.cpp:152-…)
+            weights, phase = None, weights
+        self._lib = _lib.load()
+        enc = lambda s: None if s is None else str(s).encode()
+        self._h = self._lib.shf_net_create(enc(network_file), enc(prototxt_text), enc(weights or ""), int(phase))
+        if not self._h:
+            raise RuntimeError(_lib.last_error())
+        L = self._lib
+        self._blob_names = [L.shf_net_blob_name(self._h, i).decode() for i in range(L.shf_net_num_blobs(self._h))]
+        self._blobs = [Blob(self, i, n) for i, n in enumerate(self._blob_names)]
+        self._inputs = [L.shf_net_input_blob(self._h, i) for i in range(L.shf_net_num_inputs(self._h))]
+        self._outputs = [L.shf_net_output_blob(self._h, i) for i in range(L.shf_net_num_outputs(self._h))]
+        self._layer_names = [L.shf_net_layer_name(self._h, i).decode() for i in range(L.shf_net_num_layers(self._h))]
+        self._layer_types = [L.shf_net_layer_type(self._h, i).decode() for i in range(L.shf_net_num_layers(self._h))]
+        self._dirty_layers = set()
+        self._apply_cfg()
+
+    def _apply_cfg(self):
+        # the reference's Python layer reads these from the global cfg at forward time
+        from ..config import cfg
+        self.set_proposal_cfg(cfg.TEST.N_DETS_PER_MODULE, cfg.TEST.SCORE_THRESH, cfg.TEST.ANCHOR_MIN_SIZE)
+
+    def set_proposal_cfg(self, pre_nms_topN, score_thresh, min_size):
+        _lib.check(self._lib.shf_net_set_proposal_cfg(self._h, int(pre_nms_topN), float(score_thresh),
+                                                      float(min_size)), "set_proposal_cfg")
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._lib.shf_net_destroy(h)
+
+    # -- pycaffe.py:24-85 ------------------------------------------------------
+    @property
+    def blobs(self):
+        if not hasattr(self, "_blobs_dict"):
+            self._blobs_dict = OrderedDict(zip(self._blob_names, self._blobs))
+        return self._blobs_dict
+
+    @property
+    def params(self):
+        if not hasattr(self, "_params_dict"):
+            d = OrderedDict()
+            for li, name in enumerate(self._layer_names):
+                n = self._lib.shf_net_layer_num_params(self._h, li)
+                if n > 0:
+                    d[name] = [_ParamBlob(self, li, i) for i in range(n)]
+            self._params_dict = d
+        return self._params_dict
+
+    @property
+    def inputs(self):
+        return [self._blob_names[i] for i in self._inputs]
+
+    @property
+    def outputs(self):
+        return [self._blob_names[i] for i in self._outputs]
+
+    def commit_params(self):
+        for li in sorted(self._dirty_layers):
+            _lib.check(self._lib.shf_net_param_commit(self._h, li), "param_commit")
+        self._dirty_layers.clear()
+
+    def _forward(self, start=0, end=None):
+        self.commit_params()
+        _lib.check(self._lib.shf_net_forward(self._h), "Net.forward")
+
+    def forward(self, blobs=None, start=None, end=None, **kwargs):
+        """pycaffe.py:88-134 (whole-net forward only: start/end are not supported)."""
+        if start is not None or end is not None:
+            raise NotImplementedError("partial forward (start/end) is outside the inference hot path")
+        if blobs is None:
+            blobs = []
+        outputs = set(self.outputs + blobs)
+        if kwargs:
+            if set(kwargs.keys()) != set(self.inputs):
+                raise Exception('Input blob arguments do not match net inputs.')
+            for in_, blob in kwargs.items():
+                if blob.shape[0] != self.blobs[in_].shape[0]:
+                    raise Exception('Input is not batch sized')
+                self.blobs[in_].data[...] = blob
+        self._forward()
+        return {out: self.blobs[out].data for out in outputs}
+
+    # -- measurement helpers ------------------------------------------------------
+    def sync(self):
+        _lib.check(self._lib.shf_net_sync(self._h), "sync")
+
+    def prof_enable(self, on=True):
+        self._lib.shf_prof_enable(self._h, 1 if on else 0)
+
+    def prof_reset(self):
+        _lib.check(self._lib.shf_prof_reset(self._h), "prof_reset")
+
+    def prof_read(self):
+        out = OrderedDict()
+        for c in range(self._lib.shf_prof_num_classes(self._h)):
+            n, ms, fl, by = C.c_int64(), C.c_double(), C.c_double(), C.c_double()
+            _lib.check(self._lib.shf_prof_read(self._h, c, C.byref(n), C.byref(ms), C.byref(fl), C.byref(by)))
+            out[self._lib.shf_prof_class_name(self._h, c).decode()] = dict(
+                launches=n.value, ms=ms.value, flops=fl.value, bytes=by.value)
+        return out
+
+    # -- fused per-image path (device-resident pyramid) ----------------------------
+    def detect_begin(self):
+        self.commit_params()
+        _lib.check(self._lib.shf_detect_begin(self._h), "detect_begin")
+
+    def detect_add_level(self, data, H, W, im_h, im_w, im_scale, flip, thresh, on_device=False):
+        """``data``: device pointer (int) when on_device else a C-contiguous fp32 (1,3,H,W) array."""
+        if on_device:
+            ptr = C.c_void_p(int(data))
+        else:
+            data = np.ascontiguousarray(data, dtype=np.float32)
+            ptr = data.ctypes.data_as(C.c_void_p)
+        _lib.check(self._lib.shf_detect_add_level(self._h, ptr, 1 if on_device else 0, int(H), int(W), int(im_h),
+                                                  int(im_w), float(im_scale), 1 if flip else 0, float(thresh)),
+                   "detect_add_level")
+
+    def detect_finish(self, method="BBOX_VOTE", nms_thresh=0.4, cap=None):
+        m = {"BBOX_VOTE": 0, "NMS": 1}[method]
+        cap = cap or 4096
+        while True:
+            out = np.empty((cap, 5), dtype=np.float64)
+            n = C.c_int(0)
+            _lib.check(self._lib.shf_detect_finish(self._h, m, float(nms_thresh),
+                                                   out.ctypes.data_as(C.POINTER(C.c_double)), cap, C.byref(n)),
+                       "detect_finish")
+            if n.value <= cap:
+                return out[:n.value]
+            cap = n.value  # rare: more merged boxes than expected -> the merge is re-run

@@ -1,0 +1,175 @@
+// Bandwidth-bound glue layers on NHWC fp32 activations (all float4-vectorised over
+// channels, grid-stride).  Reference counterparts:
+//   max pool 2x2/2      caffe/src/caffe/layers/pooling_layer.cu:11-47 (+ceil sizing, pooling_layer.cpp:79-123)
+//   depthwise deconv    caffe/src/caffe/layers/deconv_layer.cu:8-23 (256 serial GEMMs + col2im in the reference)
+//   concat              caffe/src/caffe/layers/concat_layer.cu (zero-copy here: producers write channel slices)
+//   NCHW<->NHWC         the host-visible Blob.data layout (caffe/python/caffe/_caffe.cpp:222-242)
+#include "shf_internal.h"
+
+namespace shf {
+
+static inline unsigned grid_for(long long n, int block = 256) {
+  long long g = (n + block - 1) / block;
+  if (g > 256 * 16) g = 256 * 16;  // 256 CUs x 16 blocks, grid-stride the rest
+  if (g < 1) g = 1;
+  return (unsigned)g;
+}
+
+__global__ void maxpool_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int H, int W, int C,
+                               int Ho, int Wo, int k, int stride, int pad, int in_stride, int out_stride) {
+  const int C4 = C >> 2;
+  const long long total = (long long)B * Ho * Wo * C4;
+  for (long long n = (long long)blockIdx.x * blockDim.x + threadIdx.x; n < total;
+       n += (long long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(n % C4);
+    long long P = n / C4;
+    const int ox = (int)(P % Wo), oy = (int)((P / Wo) % Ho), b = (int)(P / ((long long)Wo * Ho));
+    int hs = oy * stride - pad, ws = ox * stride - pad;
+    const int he = min(hs + k, H), we = min(ws + k, W);
+    hs = max(hs, 0);
+    ws = max(ws, 0);
+    float4 m = make_float4(-3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f);
+    for (int y = hs; y < he; ++y)
+      for (int x = ws; x < we; ++x) {
+        const float4 v = *(const float4*)(in + ((size_t)(b * H + y) * W + x) * in_stride + c4 * 4);
+        m.x = v.x > m.x ? v.x : m.x;  // first max wins ('>'), pooling_layer.cpp:160-163
+        m.y = v.y > m.y ? v.y : m.y;
+        m.z = v.z > m.z ? v.z : m.z;
+        m.w = v.w > m.w ? v.w : m.w;
+      }
+    *(float4*)(out + (size_t)P * out_stride + c4 * 4) = m;
+  }
+}
+
+int launch_maxpool(const View& in, const View& out, int k, int stride, int pad, hipStream_t s) {
+  if (in.C % 4 || in.cstride % 4 || in.coff % 4 || out.cstride % 4 || out.coff % 4) {
+    set_error("maxpool: channel count / views must be multiples of 4");
+    return -1;
+  }
+  const long long total = (long long)out.B * out.H * out.W * (in.C / 4);
+  hipLaunchKernelGGL(maxpool_kernel, dim3(grid_for(total)), dim3(256), 0, s, in.p + in.coff, out.p + out.coff, in.B,
+                     in.H, in.W, in.C, out.H, out.W, k, stride, pad, in.cstride, out.cstride);
+  SHF_HIP_OK(hipGetLastError());
+  return 0;
+}
+
+// out[b,y,x,c] = sum_{a,bb} in[b,(y+pad-a)/s,(x+pad-bb)/s,c] * w[c,a,bb] over taps whose
+// source index is integral and in range (col2im accumulation order a-major, like im2col.cpp:168-185).
+__global__ void deconv_dw_kernel(const float* __restrict__ in, const float* __restrict__ w,
+                                 const float* __restrict__ bias, float* __restrict__ out, int B, int H, int W, int C,
+                                 int Ho, int Wo, int k, int stride, int pad, int in_stride, int out_stride) {
+  const int C4 = C >> 2;
+  const long long total = (long long)B * Ho * Wo * C4;
+  for (long long n = (long long)blockIdx.x * blockDim.x + threadIdx.x; n < total;
+       n += (long long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(n % C4);
+    long long P = n / C4;
+    const int ox = (int)(P % Wo), oy = (int)((P / Wo) % Ho), b = (int)(P / ((long long)Wo * Ho));
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int a = 0; a < k; ++a) {
+      const int ty = oy + pad - a;
+      if (ty < 0 || ty % stride) continue;
+      const int iy = ty / stride;
+      if (iy >= H) continue;
+      for (int bb = 0; bb < k; ++bb) {
+        const int tx = ox + pad - bb;
+        if (tx < 0 || tx % stride) continue;
+        const int ix = tx / stride;
+        if (ix >= W) continue;
+        const float4 v = *(const float4*)(in + ((size_t)(b * H + iy) * W + ix) * in_stride + c4 * 4);
+        const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = fmaf(vv[j], w[((size_t)(c4 * 4 + j) * k + a) * k + bb], acc[j]);
+      }
+    }
+    if (bias)
+      for (int j = 0; j < 4; ++j) acc[j] += bias[c4 * 4 + j];
+    *(float4*)(out + (size_t)P * out_stride + c4 * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+  }
+}
+
+int launch_deconv_depthwise(const View& in, const View& out, const float* w, const float* bias, int k, int stride,
+                            int pad, hipStream_t s) {
+  if (in.C % 4 || in.cstride % 4 || in.coff % 4 || out.cstride % 4 || out.coff % 4) {
+    set_error("deconv: channel count / views must be multiples of 4");
+    return -1;
+  }
+  const long long total = (long long)out.B * out.H * out.W * (in.C / 4);
+  hipLaunchKernelGGL(deconv_dw_kernel, dim3(grid_for(total)), dim3(256), 0, s, in.p + in.coff, w, bias,
+                     out.p + out.coff, in.B, in.H, in.W, in.C, out.H, out.W, k, stride, pad, in.cstride,
+                     out.cstride);
+  SHF_HIP_OK(hipGetLastError());
+  return 0;
+}
+
+__global__ void copy_view_kernel(const float* __restrict__ in, float* __restrict__ out, long long pixels, int C,
+                                 int in_stride, int out_stride) {
+  const long long total = pixels * C;
+  for (long long n = (long long)blockIdx.x * blockDim.x + threadIdx.x; n < total;
+       n += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(n % C);
+    const long long P = n / C;
+    out[(size_t)P * out_stride + c] = in[(size_t)P * in_stride + c];
+  }
+}
+
+int launch_copy_view(const View& in, const View& out, hipStream_t s) {
+  const long long pixels = (long long)in.B * in.H * in.W;
+  hipLaunchKernelGGL(copy_view_kernel, dim3(grid_for(pixels * in.C)), dim3(256), 0, s, in.p + in.coff,
+                     out.p + out.coff, pixels, in.C, in.cstride, out.cstride);
+  SHF_HIP_OK(hipGetLastError());
+  return 0;
+}
+
+// 32x32 LDS-tiled transpose between [B][HW][C(strided)] and [B][C][HW]
+__global__ void nhwc_to_nchw_kernel(const float* __restrict__ in, float* __restrict__ out, int HW, int C,
+                                    int in_stride) {
+  __shared__ float t[32][33];
+  const int b = blockIdx.z;
+  const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: 8 rows per pass
+  for (int r = ty; r < 32; r += 8) {
+    const int p = p0 + r, c = c0 + tx;
+    t[r][tx] = (p < HW && c < C) ? in[((size_t)b * HW + p) * in_stride + c] : 0.f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int c = c0 + r, p = p0 + tx;
+    if (p < HW && c < C) out[((size_t)b * C + c) * HW + p] = t[tx][r];
+  }
+}
+
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out, int HW, int C,
+                                    int out_stride) {
+  __shared__ float t[32][33];
+  const int b = blockIdx.z;
+  const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int r = ty; r < 32; r += 8) {
+    const int c = c0 + r, p = p0 + tx;
+    t[r][tx] = (p < HW && c < C) ? in[((size_t)b * C + c) * HW + p] : 0.f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int p = p0 + r, c = c0 + tx;
+    if (p < HW && c < C) out[((size_t)b * HW + p) * out_stride + c] = t[tx][r];
+  }
+}
+
+int launch_nhwc_to_nchw(const View& in, float* out_nchw, hipStream_t s) {
+  const int HW = in.H * in.W;
+  dim3 g((HW + 31) / 32, (in.C + 31) / 32, in.B);
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, g, dim3(256), 0, s, in.p + in.coff, out_nchw, HW, in.C, in.cstride);
+  SHF_HIP_OK(hipGetLastError());
+  return 0;
+}
+
+int launch_nchw_to_nhwc(const float* in_nchw, const View& out, hipStream_t s) {
+  const int HW = out.H * out.W;
+  dim3 g((HW + 31) / 32, (out.C + 31) / 32, out.B);
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, g, dim3(256), 0, s, in_nchw, out.p + out.coff, HW, out.C, out.cstride);
+  SHF_HIP_OK(hipGetLastError());
+  return 0;
+}
+
+}  // namespace shf

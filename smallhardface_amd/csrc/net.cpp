@@ -1,0 +1,1321 @@
+// Net runtime + C ABI (include/shf_hip.h).
+//
+// A static-graph executor for the detector's TEST-phase prototxt: it replaces
+// caffe::Net (caffe/src/caffe/net.cpp:28-257 Init, :421-513 AppendParam sharing,
+// :516-532 ForwardFromTo, :733-768 CopyTrainedLayersFrom), Blob/SyncedMemory
+// (blob.cpp:23-51, syncedmem.cpp:39-91) and the in-graph Python ProposalLayer
+// trampoline (include/caffe/layers/python_layer.hpp:14-51) for the layer types that
+// graph instantiates.  Differences by design (MI355X-first):
+//   * activations stay NHWC on the device; only Blob.data read-back transposes;
+//   * conv + bias + in-place ReLU are one kernel; channel concat is zero-copy
+//     (producers write channel slices of the concat buffer);
+//   * the 1x1 cls/reg convs, concats, softmax, reshape and the proposal layer are
+//     one fused device-side tail (no D2H, no Python re-entry);
+//   * buffers are grow-only and shape changes re-plan nothing but pointers/sizes.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <deque>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <set>
+
+#include "../../include/shf_hip.h"
+#include "proto_text.h"
+#include "shf_internal.h"
+
+namespace shf {
+
+static thread_local std::string g_err;
+void set_error(const std::string& msg) { g_err = msg; }
+
+#define HIP_THROW(expr)                                                                        \
+  do {                                                                                         \
+    hipError_t _e = (expr);                                                                    \
+    if (_e != hipSuccess) throw std::runtime_error(std::string(#expr) + ": " + hipGetErrorString(_e)); \
+  } while (0)
+#define CHECK_RC(expr)                                     \
+  do {                                                     \
+    if ((expr) != 0) throw std::runtime_error(g_err);      \
+  } while (0)
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  void ensure(size_t bytes) {
+    if (bytes <= cap) return;
+    if (p) HIP_THROW(hipFree(p));
+    p = nullptr;
+    size_t want = bytes + bytes / 8;  // grow-only with slack (Blob::Reshape never shrinks, blob.cpp:46-50)
+    want = (want + 255) & ~(size_t)255;
+    HIP_THROW(hipMalloc(&p, want));
+    cap = want;
+  }
+  ~DevBuf() {
+    if (p) (void)hipFree(p);
+  }
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+};
+
+struct HostBuf {
+  float* p = nullptr;
+  size_t cap = 0;
+  void ensure(size_t bytes) {
+    if (bytes <= cap) return;
+    float* np = nullptr;
+    size_t want = std::max<size_t>(bytes + bytes / 8, 64);
+    HIP_THROW(hipHostMalloc((void**)&np, want, hipHostMallocDefault));
+    if (p) {
+      memcpy(np, p, cap);
+      (void)hipHostFree(p);
+    }
+    memset((char*)np + cap, 0, want - cap);
+    p = np;
+    cap = want;
+  }
+  ~HostBuf() {
+    if (p) (void)hipHostFree(p);
+  }
+  HostBuf() = default;
+  HostBuf(const HostBuf&) = delete;
+  HostBuf& operator=(const HostBuf&) = delete;
+};
+
+struct ParamBlob {
+  std::vector<int> shape;
+  std::vector<float> host;
+  DevBuf raw, packed;
+  bool dirty = true;
+  size_t count() const {
+    size_t c = 1;
+    for (int d : shape) c *= (size_t)d;
+    return c;
+  }
+};
+
+enum BlobKind { BK_INPUT_NCHW, BK_NHWC, BK_FLAT, BK_NCHW_MAT, BK_FUSED };
+
+struct Blob {
+  std::string name;
+  std::vector<int> shape;  // logical Caffe shape
+  BlobKind kind = BK_NHWC;
+  int owner = -1;  // blob owning the device buffer (channel-concat views)
+  int coff = 0;
+  DevBuf dev, stage;
+  HostBuf host;
+  bool host_newer = false, dev_newer = false;
+  const float* ext_dev = nullptr;  // externally bound device input (fused path)
+  size_t count() const {
+    size_t c = 1;
+    for (int d : shape) c *= (size_t)d;
+    return c;
+  }
+};
+
+enum OpType { OP_SKIP, OP_CONV, OP_POOL, OP_DECONV, OP_TAIL };
+
+struct Layer {
+  std::string name, type;
+  const PMsg* msg = nullptr;
+  std::vector<int> bottoms, tops;
+  std::vector<std::shared_ptr<ParamBlob>> params;
+  OpType op = OP_SKIP;
+  // conv / deconv / pool hyper-parameters
+  int k = 1, pad = 0, stride = 1, dil = 1, group = 1, nout = 0, relu = 0, bias_term = 1;
+  int kclass = 0;
+};
+
+enum ProfClass { PC_CONV_MFMA, PC_CONV_FIRST, PC_CONV_DIRECT, PC_POOL, PC_DECONV, PC_TAIL, PC_MERGE, PC_LAYOUT, PC_COUNT };
+static const char* kProfNames[PC_COUNT] = {"conv_mfma_f32", "conv_first", "conv_direct", "maxpool",
+                                           "deconv_depthwise", "detect_tail", "box_merge", "layout"};
+
+struct Prof {
+  bool on = false;
+  struct Rec { int cls; hipEvent_t a, b; double flops, bytes; };
+  std::vector<Rec> pending;
+  std::vector<hipEvent_t> pool;
+  int64_t launches[PC_COUNT] = {0};
+  double ms[PC_COUNT] = {0}, flops[PC_COUNT] = {0}, bytes[PC_COUNT] = {0};
+  hipEvent_t get() {
+    if (!pool.empty()) {
+      hipEvent_t e = pool.back();
+      pool.pop_back();
+      return e;
+    }
+    hipEvent_t e;
+    HIP_THROW(hipEventCreate(&e));
+    return e;
+  }
+  void drain() {
+    for (auto& r : pending) {
+      HIP_THROW(hipEventSynchronize(r.b));
+      float t = 0;
+      HIP_THROW(hipEventElapsedTime(&t, r.a, r.b));
+      launches[r.cls]++;
+      ms[r.cls] += t;
+      flops[r.cls] += r.flops;
+      bytes[r.cls] += r.bytes;
+      pool.push_back(r.a);
+      pool.push_back(r.b);
+    }
+    pending.clear();
+  }
+  ~Prof() {
+    for (auto& r : pending) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    for (auto e : pool) (void)hipEventDestroy(e);
+  }
+};
+
+struct ProfScope {
+  Prof& p;
+  hipStream_t s;
+  Prof::Rec r;
+  bool on;
+  ProfScope(Prof& p_, hipStream_t s_, int cls, double flops, double bytes) : p(p_), s(s_), on(p_.on) {
+    if (!on) return;
+    r.cls = cls; r.flops = flops; r.bytes = bytes;
+    r.a = p.get(); r.b = p.get();
+    HIP_THROW(hipEventRecord(r.a, s));
+  }
+  ~ProfScope() {
+    if (!on) return;
+    (void)hipEventRecord(r.b, s);
+    p.pending.push_back(r);
+  }
+};
+
+// ---------------------------------------------------------------------------
+// box merging context (also used stand-alone by shf_nms / shf_bbox_vote)
+// ---------------------------------------------------------------------------
+struct MergeCtx {
+  DevBuf dets, keys, sorted, perm, mask, cluster, heads, counters, out;
+  std::vector<double> hout;
+  std::vector<int> hidx;
+
+  // dets_dev: (n,5) fp32 on the device.  method 0 = vote (>=), 1 = nms (>).
+  // vote: rows -> out5 (cap rows) ; nms: kept ORIGINAL indices -> keep
+  int run(const float* dets_dev, int n, int method, float thr, double* out5, int cap, int* n_out, int32_t* keep,
+          hipStream_t s) {
+    *n_out = 0;
+    if (n <= 0) return 0;
+    size_t npad = 1;
+    while (npad < (size_t)n) npad <<= 1;
+    const size_t nw = ((size_t)n + 63) / 64;
+    keys.ensure(npad * 8);
+    sorted.ensure((size_t)n * 5 * 4);
+    perm.ensure((size_t)n * 4);
+    mask.ensure((size_t)n * nw * 8);
+    cluster.ensure((size_t)n * 4);
+    heads.ensure((size_t)n * 4);
+    counters.ensure(64);
+    out.ensure((size_t)n * 5 * 8 * 2 + (size_t)n * 4 + 64);
+    int* cnt = (int*)counters.p;
+    HIP_THROW(hipMemsetAsync(cnt, 0, 64, s));
+    HIP_THROW(hipMemcpyAsync(cnt + 3, &n, sizeof(int), hipMemcpyHostToDevice, s));
+    CHECK_RC(launch_make_keys(dets_dev, n, (unsigned long long*)keys.p, s));
+    CHECK_RC(launch_sort_desc_u64((unsigned long long*)keys.p, cnt + 3, (size_t)n, s));
+    CHECK_RC(launch_gather_sorted(dets_dev, (unsigned long long*)keys.p, n, (float*)sorted.p, (int*)perm.p, s));
+    CHECK_RC(launch_iou_mask((float*)sorted.p, n, thr, method == 0 ? 1 : 0, (unsigned long long*)mask.p, s));
+    CHECK_RC(launch_greedy_scan((unsigned long long*)mask.p, n, (int*)cluster.p, (int*)heads.p, cnt, s));
+    if (method == 0) {
+      CHECK_RC(launch_vote_accumulate((float*)sorted.p, (unsigned long long*)mask.p, (int*)cluster.p, n,
+                                      (int*)heads.p, cnt, (double*)out.p, cnt + 1, s));
+      int h[2];
+      HIP_THROW(hipMemcpyAsync(h, cnt, 8, hipMemcpyDeviceToHost, s));
+      HIP_THROW(hipStreamSynchronize(s));
+      const int m = h[1];
+      *n_out = m;
+      const int w = std::min(m, cap);
+      if (w > 0) HIP_THROW(hipMemcpy(out5, out.p, (size_t)w * 5 * 8, hipMemcpyDeviceToHost));
+    } else {
+      int nh = 0;
+      HIP_THROW(hipMemcpyAsync(&nh, cnt, 4, hipMemcpyDeviceToHost, s));
+      HIP_THROW(hipStreamSynchronize(s));
+      hidx.resize((size_t)n * 2);
+      HIP_THROW(hipMemcpy(hidx.data(), heads.p, (size_t)nh * 4, hipMemcpyDeviceToHost));
+      HIP_THROW(hipMemcpy(hidx.data() + n, perm.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+      *n_out = nh;
+      if (keep)
+        for (int i = 0; i < nh; ++i) keep[i] = hidx[n + hidx[i]];
+      if (out5) {
+        std::vector<float> hs((size_t)n * 5);
+        HIP_THROW(hipMemcpy(hs.data(), sorted.p, (size_t)n * 5 * 4, hipMemcpyDeviceToHost));
+        for (int i = 0; i < std::min(nh, cap); ++i)
+          for (int j = 0; j < 5; ++j) out5[i * 5 + j] = (double)hs[(size_t)hidx[i] * 5 + j];
+      }
+    }
+    return 0;
+  }
+};
+
+// generate_anchors.py:11-86 in double precision
+static void gen_anchors(int base_size, const std::vector<double>& ratios, const std::vector<double>& scales,
+                        const std::vector<double>& shifts, const std::vector<double>& strides,
+                        std::vector<double>& out) {
+  out.clear();
+  const double bw = base_size, bh = base_size;  // base anchor (0,0,base-1,base-1)
+  const double bxc = 0 + 0.5 * (bw - 1), byc = 0 + 0.5 * (bh - 1);
+  const double size = bw * bh;
+  for (double r : ratios) {
+    const double ws = std::nearbyint(std::sqrt(size / r));
+    const double hs = std::nearbyint(ws * r);
+    // ratio anchor
+    const double rx1 = bxc - 0.5 * (ws - 1), ry1 = byc - 0.5 * (hs - 1);
+    const double rx2 = bxc + 0.5 * (ws - 1), ry2 = byc + 0.5 * (hs - 1);
+    const double w = rx2 - rx1 + 1, h = ry2 - ry1 + 1;
+    const double xc = rx1 + 0.5 * (w - 1), yc = ry1 + 0.5 * (h - 1);
+    const size_t ns = std::min(scales.size(), strides.size());  // zip(scales, strides)
+    for (size_t j = 0; j < ns; ++j) {
+      const double sw = w * scales[j], sh = h * scales[j];
+      const double a[4] = {xc - 0.5 * (sw - 1), yc - 0.5 * (sh - 1), xc + 0.5 * (sw - 1), yc + 0.5 * (sh - 1)};
+      for (double sy : shifts)
+        for (double sx : shifts) {
+          out.push_back(a[0] + sx * strides[j]);
+          out.push_back(a[1] + sy * strides[j]);
+          out.push_back(a[2] + sx * strides[j]);
+          out.push_back(a[3] + sy * strides[j]);
+        }
+    }
+  }
+}
+
+// "{'feat_stride': [8,8,8],'scales': [1,2,4], 'ratios':[1,]}" -> key -> numbers
+static std::map<std::string, std::vector<double>> parse_param_str(const std::string& s) {
+  std::map<std::string, std::vector<double>> out;
+  size_t i = 0;
+  while (i < s.size()) {
+    const size_t q = s.find_first_of("'\"", i);
+    if (q == std::string::npos) break;
+    const size_t q2 = s.find(s[q], q + 1);
+    if (q2 == std::string::npos) break;
+    const std::string key = s.substr(q + 1, q2 - q - 1);
+    size_t c = s.find(':', q2);
+    if (c == std::string::npos) break;
+    ++c;
+    while (c < s.size() && isspace((unsigned char)s[c])) ++c;
+    std::vector<double> vals;
+    size_t end = c;
+    if (c < s.size() && (s[c] == '[' || s[c] == '(')) {
+      end = s.find_first_of("])", c);
+      if (end == std::string::npos) end = s.size();
+      std::string body = s.substr(c + 1, end - c - 1);
+      for (auto& ch : body)
+        if (ch == ',') ch = ' ';
+      std::stringstream ss(body);
+      std::string tok;
+      while (ss >> tok) {
+        if (tok == "True" || tok == "true") vals.push_back(1);
+        else if (tok == "False" || tok == "false") vals.push_back(0);
+        else vals.push_back(std::strtod(tok.c_str(), nullptr));
+      }
+      ++end;
+    } else {
+      end = s.find_first_of(",}", c);
+      if (end == std::string::npos) end = s.size();
+      std::string tok = s.substr(c, end - c);
+      while (!tok.empty() && isspace((unsigned char)tok.back())) tok.pop_back();
+      if (tok == "True" || tok == "true") vals.push_back(1);
+      else if (tok == "False" || tok == "false") vals.push_back(0);
+      else vals.push_back(std::strtod(tok.c_str(), nullptr));
+    }
+    out[key] = vals;
+    i = end;
+  }
+  return out;
+}
+
+static int conv_out(int n, int k, int pad, int stride, int dil) {
+  const int kext = dil * (k - 1) + 1;
+  return (n + 2 * pad - kext) / stride + 1;
+}
+
+}  // namespace shf
+
+using namespace shf;
+
+struct shf_net {
+  std::shared_ptr<PMsg> root;
+  std::deque<Blob> blobs;
+  std::vector<Layer> layers;
+  std::map<std::string, int> blob_index;
+  std::vector<int> inputs, outputs;
+  std::map<std::string, std::shared_ptr<ParamBlob>> shared_params;
+  hipStream_t stream = nullptr;
+  Prof prof;
+  int phase = 1;
+  // tail
+  int tail_layer = -1;
+  std::vector<int> tail_cls_layers, tail_box_layers;  // per head (or single)
+  std::vector<int> tail_feat_blobs;
+  int tail_A = 0, tail_heads = 0, tail_Cf = 0;
+  int tail_cls_blob = -1, tail_box_blob = -1, im_info_blob = -1, boxes_blob = -1, prob_blob = -1, data_blob = -1;
+  std::vector<double> anchors;
+  std::vector<int> sub_stride;
+  int feat_stride = 8;
+  DevBuf tail_W, tail_b;
+  bool tail_w_dirty = true;
+  TailWork tw;
+  DevBuf tw_logits, tw_rec, tw_keys, tw_counters;
+  int pre_nms_topN = 10000;
+  float score_thresh = 0.002f, min_size = 0.f;
+  bool materialize_tail = true;
+  std::vector<int> last_data_shape;
+  // fused per-image path
+  DevBuf img_dets, img_keys, img_count;
+  int img_cap = 0, img_units = 0;
+  MergeCtx merge;
+  float cur_im_info[3] = {0, 0, 1};
+  bool use_blob_im_info = true;
+
+  ~shf_net() {
+    if (stream) {
+      (void)hipStreamSynchronize(stream);
+      (void)hipStreamDestroy(stream);
+    }
+  }
+
+  int add_blob(const std::string& name) {
+    auto it = blob_index.find(name);
+    if (it != blob_index.end()) return it->second;
+    Blob b;
+    b.name = name;
+    blobs.emplace_back();
+    blobs.back().name = name;
+    blob_index[name] = (int)blobs.size() - 1;
+    return (int)blobs.size() - 1;
+  }
+
+  View view_of(int bi) {
+    Blob& b = blobs[bi];
+    const int o = b.owner >= 0 ? b.owner : bi;
+    Blob& ob = blobs[o];
+    View v;
+    v.p = (float*)ob.dev.p;
+    v.B = b.shape[0]; v.C = b.shape[1]; v.H = b.shape[2]; v.W = b.shape[3];
+    v.cstride = ob.shape[1];
+    v.coff = b.coff;
+    return v;
+  }
+
+  void build(const std::string& text, const char* caffemodel);
+  void infer_shapes();
+  void alloc_buffers();
+  void commit_params(int li);
+  void build_tail_weights();
+  void forward_ops(bool fused_path, float im_h, float im_w, float im_scale);
+  void forward();
+  float* host_data(int bi);
+  void load_caffemodel(const std::string& path);
+};
+
+static int geti(const PMsg* m, const char* n, int d) { return m ? (int)m->num(n, d) : d; }
+
+void shf_net::build(const std::string& text, const char* caffemodel) {
+  TextParser tp(text);
+  root = tp.parse();
+  HIP_THROW(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+  CHECK_RC(conv_init_attributes());
+
+  // ---- inputs: legacy `input:` + input_shape / input_dim (upgrade_proto.cpp:966-1000)
+  auto in_names = root->all("input");
+  auto in_shapes = root->all("input_shape");
+  auto in_dims = root->all("input_dim");
+  for (size_t i = 0; i < in_names.size(); ++i) {
+    const int bi = add_blob(in_names[i]->scalar);
+    inputs.push_back(bi);
+    std::vector<int> shp;
+    if (i < in_shapes.size() && in_shapes[i]->msg)
+      for (auto d : in_shapes[i]->msg->all("dim")) shp.push_back(atoi(d->scalar.c_str()));
+    else
+      for (size_t j = 4 * i; j < 4 * i + 4 && j < in_dims.size(); ++j) shp.push_back(atoi(in_dims[j]->scalar.c_str()));
+    if (shp.empty()) shp = {1};
+    blobs[bi].shape = shp;
+  }
+  for (auto lf : root->all("layer")) {
+    const PMsg* lm = lf->msg.get();
+    if (!lm) continue;
+    Layer L;
+    L.msg = lm;
+    L.name = lm->str("name");
+    L.type = lm->str("type");
+    if (L.type == "Input") {
+      auto tops = lm->all("top");
+      const PMsg* ip = lm->sub("input_param");
+      auto shapes = ip ? ip->all("shape") : std::vector<const PField*>();
+      for (size_t i = 0; i < tops.size(); ++i) {
+        const int bi = add_blob(tops[i]->scalar);
+        inputs.push_back(bi);
+        std::vector<int> shp;
+        if (i < shapes.size() && shapes[i]->msg)
+          for (auto d : shapes[i]->msg->all("dim")) shp.push_back(atoi(d->scalar.c_str()));
+        if (shp.empty()) shp = {1};
+        blobs[bi].shape = shp;
+        L.tops.push_back(bi);
+      }
+      layers.push_back(L);
+      continue;
+    }
+    for (auto b : lm->all("bottom")) {
+      auto it = blob_index.find(b->scalar);
+      if (it == blob_index.end())
+        throw std::runtime_error("Unknown bottom blob '" + b->scalar + "' (layer '" + L.name + "')");
+      L.bottoms.push_back(it->second);
+    }
+    for (auto t : lm->all("top")) L.tops.push_back(add_blob(t->scalar));
+    layers.push_back(L);
+  }
+  for (int bi : inputs) {
+    Blob& b = blobs[bi];
+    b.kind = (b.shape.size() == 4) ? BK_INPUT_NCHW : BK_FLAT;
+    if (b.name == "data") data_blob = bi;
+    if (b.name == "im_info") im_info_blob = bi;
+  }
+  if (data_blob < 0) {
+    for (int bi : inputs)
+      if (blobs[bi].shape.size() == 4) { data_blob = bi; break; }
+  }
+  // outputs = tops nobody consumes (net.cpp:240-246)
+  {
+    std::set<int> consumed;
+    for (auto& L : layers)
+      for (int b : L.bottoms) consumed.insert(b);
+    std::set<int> is_in(inputs.begin(), inputs.end());
+    for (size_t i = 0; i < blobs.size(); ++i)
+      if (!consumed.count((int)i) && !is_in.count((int)i)) outputs.push_back((int)i);
+  }
+
+  // ---- layer hyper-parameters, params, op assignment
+  std::map<int, int> producer;  // blob -> last producing layer
+  for (size_t li = 0; li < layers.size(); ++li) {
+    Layer& L = layers[li];
+    if (L.type == "Convolution" || L.type == "Deconvolution") {
+      const PMsg* cp = L.msg->sub("convolution_param");
+      if (!cp) throw std::runtime_error("layer '" + L.name + "': missing convolution_param");
+      L.nout = geti(cp, "num_output", 0);
+      L.k = geti(cp, "kernel_size", 1);
+      L.pad = geti(cp, "pad", 0);
+      L.stride = geti(cp, "stride", 1);
+      L.dil = geti(cp, "dilation", 1);
+      L.group = geti(cp, "group", 1);
+      L.bias_term = cp->str("bias_term", "true") != "false";
+      L.op = (L.type == "Convolution") ? OP_CONV : OP_DECONV;
+    } else if (L.type == "ReLU") {
+      if (L.bottoms.size() != 1 || L.tops.size() != 1 || L.bottoms[0] != L.tops[0])
+        throw std::runtime_error("ReLU '" + L.name + "': only in-place ReLU after a convolution is supported");
+      auto pit = producer.find(L.bottoms[0]);
+      if (pit == producer.end() || layers[pit->second].type != "Convolution")
+        throw std::runtime_error("ReLU '" + L.name + "': producer is not a Convolution");
+      if (L.msg->sub("relu_param") && L.msg->sub("relu_param")->real("negative_slope", 0) != 0)
+        throw std::runtime_error("ReLU negative_slope != 0 unsupported");
+      // nothing may read the pre-activation value between the conv and this ReLU
+      for (size_t lj = pit->second + 1; lj < li; ++lj)
+        for (int b : layers[lj].bottoms)
+          if (b == L.bottoms[0]) throw std::runtime_error("ReLU '" + L.name + "': blob read before activation");
+      layers[pit->second].relu = 1;
+      L.op = OP_SKIP;
+    } else if (L.type == "Pooling") {
+      const PMsg* pp = L.msg->sub("pooling_param");
+      if (pp && pp->str("pool", "MAX") != "MAX") throw std::runtime_error("only MAX pooling is supported");
+      L.k = geti(pp, "kernel_size", 2);
+      L.stride = geti(pp, "stride", 1);
+      L.pad = geti(pp, "pad", 0);
+      L.op = OP_POOL;
+    } else if (L.type == "Python") {
+      const PMsg* py = L.msg->sub("python_param");
+      if (!py || py->str("layer") != "ProposalLayer")
+        throw std::runtime_error("Python layer '" + L.name + "': only ProposalLayer has a native implementation");
+      L.op = OP_TAIL;
+      tail_layer = (int)li;
+    } else if (L.type == "Concat" || L.type == "Softmax" || L.type == "Reshape" || L.type == "Split" ||
+               L.type == "Input") {
+      L.op = OP_SKIP;
+    } else {
+      throw std::runtime_error("Unsupported layer type '" + L.type + "' (layer '" + L.name + "')");
+    }
+    for (int t : L.tops) producer[t] = (int)li;
+  }
+
+  // ---- the fused tail: walk back from the proposal layer
+  std::set<int> fused_layers;
+  if (tail_layer >= 0) {
+    Layer& T = layers[tail_layer];
+    if (T.bottoms.size() != 3 || T.tops.empty())
+      throw std::runtime_error("ProposalLayer: expected bottoms (cls_prob, bbox_pred, im_info)");
+    tail_cls_blob = T.bottoms[0];
+    tail_box_blob = T.bottoms[1];
+    boxes_blob = T.tops[0];
+    prob_blob = T.tops.size() > 1 ? T.tops[1] : -1;
+    auto prod = [&](int blob, const char* want) -> int {
+      auto it = producer.find(blob);
+      if (it == producer.end() || layers[it->second].type != want)
+        throw std::runtime_error(std::string("tail: expected a ") + want + " producing '" + blobs[blob].name + "'");
+      return it->second;
+    };
+    // cls branch: Reshape <- Softmax <- (Concat axis2 of 1x1 convs | Reshape <- 1x1 conv)
+    const int l_rs = prod(tail_cls_blob, "Reshape");
+    const int l_sm = prod(layers[l_rs].bottoms[0], "Softmax");
+    fused_layers.insert(l_rs);
+    fused_layers.insert(l_sm);
+    int pre = layers[l_sm].bottoms[0];
+    auto pit = producer.find(pre);
+    if (pit == producer.end()) throw std::runtime_error("tail: dangling softmax input");
+    if (layers[pit->second].type == "Concat") {
+      const int l_cc = pit->second;
+      if (geti(layers[l_cc].msg->sub("concat_param"), "axis", 1) != 2)
+        throw std::runtime_error("tail: class-score concat must be on axis 2");
+      fused_layers.insert(l_cc);
+      for (int b : layers[l_cc].bottoms) tail_cls_layers.push_back(prod(b, "Convolution"));
+    } else if (layers[pit->second].type == "Reshape") {
+      fused_layers.insert(pit->second);
+      tail_cls_layers.push_back(prod(layers[pit->second].bottoms[0], "Convolution"));
+    } else {
+      throw std::runtime_error("tail: unsupported class-score branch");
+    }
+    // box branch: Concat axis1 of 1x1 convs | single 1x1 conv
+    auto bit = producer.find(tail_box_blob);
+    if (bit == producer.end()) throw std::runtime_error("tail: dangling bbox input");
+    if (layers[bit->second].type == "Concat") {
+      if (geti(layers[bit->second].msg->sub("concat_param"), "axis", 1) != 1)
+        throw std::runtime_error("tail: bbox concat must be on axis 1");
+      fused_layers.insert(bit->second);
+      for (int b : layers[bit->second].bottoms) tail_box_layers.push_back(prod(b, "Convolution"));
+    } else if (layers[bit->second].type == "Convolution") {
+      tail_box_layers.push_back(bit->second);
+    } else {
+      throw std::runtime_error("tail: unsupported bbox branch");
+    }
+    if (tail_cls_layers.size() != tail_box_layers.size())
+      throw std::runtime_error("tail: class / bbox branches disagree");
+    tail_heads = (int)tail_cls_layers.size();
+    for (int i = 0; i < tail_heads; ++i) {
+      Layer& c = layers[tail_cls_layers[i]];
+      Layer& b = layers[tail_box_layers[i]];
+      if (c.k != 1 || b.k != 1 || c.bottoms[0] != b.bottoms[0])
+        throw std::runtime_error("tail: cls/bbox predictors must be 1x1 convs on the same head blob");
+      tail_feat_blobs.push_back(c.bottoms[0]);
+      fused_layers.insert(tail_cls_layers[i]);
+      fused_layers.insert(tail_box_layers[i]);
+    }
+    const PMsg* py = T.msg->sub("python_param");
+    auto ps = parse_param_str(py->str("param_str"));
+    std::vector<double> fs = ps.count("feat_stride") ? ps["feat_stride"] : std::vector<double>{16};
+    std::vector<double> scales = ps.count("scales") ? ps["scales"] : std::vector<double>{8, 16, 32};
+    std::vector<double> ratios = ps.count("ratios") ? ps["ratios"] : std::vector<double>{0.5, 1, 2};
+    std::vector<double> shifts = ps.count("shifts") ? ps["shifts"] : std::vector<double>{0};
+    const int base_size = ps.count("base_size") ? (int)ps["base_size"][0] : 16;
+    const bool subsampled = ps.count("subsampled") ? ps["subsampled"][0] != 0 : true;
+    if (ps.count("num_feats") && ps["num_feats"][0] != 1) throw std::runtime_error("tail: num_feats != 1 unsupported");
+    gen_anchors(base_size, ratios, scales, shifts, fs, anchors);
+    tail_A = (int)anchors.size() / 4;
+    feat_stride = (int)fs[0];
+    sub_stride.assign(tail_A, 1);
+    if (subsampled)
+      for (int i = 0; i < tail_A; ++i) {
+        const size_t idx = (size_t)i / (shifts.size() * shifts.size());
+        sub_stride[i] = (int)fs[std::min(idx, fs.size() - 1)] / (int)fs[0];
+      }
+    if (tail_A > 8) throw std::runtime_error("tail: more than 8 anchors per cell unsupported");
+    if (tail_heads != 1 && tail_heads != tail_A) throw std::runtime_error("tail: heads must be 1 or == anchors");
+    const int ncls = tail_heads == 1 ? 2 * tail_A : 2, nbox = tail_heads == 1 ? 4 * tail_A : 4;
+    for (int i = 0; i < tail_heads; ++i)
+      if (layers[tail_cls_layers[i]].nout != ncls || layers[tail_box_layers[i]].nout != nbox)
+        throw std::runtime_error("tail: predictor channel counts do not match the anchors");
+    for (int li2 : fused_layers) {
+      layers[li2].op = OP_SKIP;
+      for (int t : layers[li2].tops) blobs[t].kind = BK_FUSED;
+    }
+    blobs[tail_cls_blob].kind = BK_NCHW_MAT;
+    blobs[tail_box_blob].kind = BK_NCHW_MAT;
+    blobs[boxes_blob].kind = BK_FLAT;
+    if (prob_blob >= 0) blobs[prob_blob].kind = BK_FLAT;
+  }
+
+  // ---- channel-concat views (zero-copy): bottoms of a non-fused axis-1 Concat live inside the top
+  for (size_t li = 0; li < layers.size(); ++li) {
+    Layer& L = layers[li];
+    if (L.type != "Concat" || fused_layers.count((int)li)) continue;
+    if (geti(L.msg->sub("concat_param"), "axis", 1) != 1)
+      throw std::runtime_error("Concat '" + L.name + "': only channel concat is supported outside the tail");
+    for (int b : L.bottoms) {
+      if (blobs[b].owner >= 0 || std::count(inputs.begin(), inputs.end(), b))
+        throw std::runtime_error("Concat '" + L.name + "': bottom already aliased");
+      blobs[b].owner = L.tops[0];
+    }
+  }
+
+  // ---- params (shapes need channel counts: run shape inference once)
+  infer_shapes();
+  for (size_t li = 0; li < layers.size(); ++li) {
+    Layer& L = layers[li];
+    if (L.type != "Convolution" && L.type != "Deconvolution") continue;
+    const int cin = blobs[L.bottoms[0]].shape[1];
+    std::vector<std::vector<int>> shapes;
+    if (L.type == "Convolution") {
+      if (L.group != 1) throw std::runtime_error("Convolution '" + L.name + "': group != 1 unsupported");
+      if (L.stride != 1) throw std::runtime_error("Convolution '" + L.name + "': stride != 1 unsupported");
+      if (!((L.k == 3 && L.pad == L.dil) || (L.k == 1 && L.pad == 0)))
+        throw std::runtime_error("Convolution '" + L.name + "': only 3x3 pad==dilation and 1x1 pad 0 are supported");
+      shapes.push_back({L.nout, cin, L.k, L.k});
+    } else {
+      if (L.group != cin || L.nout != cin)
+        throw std::runtime_error("Deconvolution '" + L.name + "': only depthwise (group == channels) is supported");
+      shapes.push_back({cin, 1, L.k, L.k});
+    }
+    if (L.bias_term) shapes.push_back({L.nout});
+    auto pspecs = L.msg->all("param");
+    for (size_t pi = 0; pi < shapes.size(); ++pi) {
+      std::string pname = (pi < pspecs.size() && pspecs[pi]->msg) ? pspecs[pi]->msg->str("name") : "";
+      std::shared_ptr<ParamBlob> pb;
+      if (!pname.empty() && shared_params.count(pname)) {
+        pb = shared_params[pname];
+        if (pb->shape != shapes[pi]) throw std::runtime_error("Shared parameter '" + pname + "' shape mismatch");
+      } else {
+        pb = std::make_shared<ParamBlob>();
+        pb->shape = shapes[pi];
+        pb->host.assign(pb->count(), 0.f);
+        if (!pname.empty()) shared_params[pname] = pb;
+      }
+      L.params.push_back(pb);
+    }
+    if (L.type == "Convolution")
+      L.kclass = conv_kernel_class(cin, L.nout, L.k, L.pad, L.dil, blobs[L.bottoms[0]].kind == BK_INPUT_NCHW);
+  }
+  alloc_buffers();
+  if (caffemodel && caffemodel[0]) load_caffemodel(caffemodel);
+  for (size_t li = 0; li < layers.size(); ++li) commit_params((int)li);
+}
+
+void shf_net::infer_shapes() {
+  for (auto& L : layers) {
+    if (L.type == "Input") continue;
+    auto& bs = blobs[L.bottoms.empty() ? 0 : L.bottoms[0]].shape;
+    if (L.type == "Convolution") {
+      if (bs.size() != 4) throw std::runtime_error("Convolution '" + L.name + "': 4-D bottom expected");
+      blobs[L.tops[0]].shape = {bs[0], L.nout, conv_out(bs[2], L.k, L.pad, L.stride, L.dil),
+                                conv_out(bs[3], L.k, L.pad, L.stride, L.dil)};
+    } else if (L.type == "Deconvolution") {
+      blobs[L.tops[0]].shape = {bs[0], L.nout, L.stride * (bs[2] - 1) + L.k - 2 * L.pad,
+                                L.stride * (bs[3] - 1) + L.k - 2 * L.pad};
+    } else if (L.type == "ReLU" || L.type == "Softmax" || L.type == "Split") {
+      for (int t : L.tops) blobs[t].shape = bs;
+    } else if (L.type == "Pooling") {
+      int ho = (int)std::ceil((bs[2] + 2 * L.pad - L.k) / (double)L.stride) + 1;
+      int wo = (int)std::ceil((bs[3] + 2 * L.pad - L.k) / (double)L.stride) + 1;
+      if (L.pad) {
+        if ((ho - 1) * L.stride >= bs[2] + L.pad) --ho;
+        if ((wo - 1) * L.stride >= bs[3] + L.pad) --wo;
+      }
+      blobs[L.tops[0]].shape = {bs[0], bs[1], ho, wo};
+    } else if (L.type == "Concat") {
+      const int axis = geti(L.msg->sub("concat_param"), "axis", 1);
+      std::vector<int> s = bs;
+      int sum = 0;
+      int off = 0;
+      for (int b : L.bottoms) {
+        if (blobs[b].owner == L.tops[0]) blobs[b].coff = off;
+        off += blobs[b].shape[axis];
+        sum += blobs[b].shape[axis];
+      }
+      s[axis] = sum;
+      blobs[L.tops[0]].shape = s;
+    } else if (L.type == "Reshape") {
+      const PMsg* rp = L.msg->sub("reshape_param");
+      std::vector<int> dims;
+      if (rp && rp->sub("shape"))
+        for (auto d : rp->sub("shape")->all("dim")) dims.push_back(atoi(d->scalar.c_str()));
+      std::vector<int> out;
+      int infer = -1;
+      long total = 1, known = 1;
+      for (int d : bs) total *= d;
+      for (size_t i = 0; i < dims.size(); ++i) {
+        if (dims[i] == 0) out.push_back(bs[i]);
+        else if (dims[i] == -1) { infer = (int)i; out.push_back(1); }
+        else out.push_back(dims[i]);
+      }
+      for (int d : out) known *= d;
+      if (infer >= 0) out[infer] = (int)(total / std::max<long>(known, 1));
+      blobs[L.tops[0]].shape = out;
+    } else if (L.type == "Python") {
+      if (blobs[L.tops[0]].shape.size() != 2) blobs[L.tops[0]].shape = {1, 5};
+      if (L.tops.size() > 1 && blobs[L.tops[1]].shape.size() != 2) blobs[L.tops[1]].shape = {1, 2};
+    }
+  }
+  if (data_blob >= 0) last_data_shape = blobs[data_blob].shape;
+}
+
+void shf_net::alloc_buffers() {
+  for (size_t i = 0; i < blobs.size(); ++i) {
+    Blob& b = blobs[i];
+    if (b.kind == BK_FUSED) continue;
+    if (b.owner >= 0) continue;  // view into a concat buffer
+    if (b.kind == BK_FLAT && ((int)i == boxes_blob || (int)i == prob_blob)) continue;  // sized by the tail
+    b.dev.ensure(std::max<size_t>(b.count(), 1) * sizeof(float));
+  }
+  if (tail_layer >= 0) {
+    Blob& f = blobs[tail_feat_blobs[0]];
+    const size_t K = (size_t)f.shape[2] * f.shape[3];
+    const size_t total = K * tail_A;
+    size_t npad = 1;
+    while (npad < total) npad <<= 1;
+    tw_logits.ensure(total * 6 * 4);
+    tw_rec.ensure(total * 6 * 4);
+    tw_keys.ensure(std::max<size_t>(npad, 16384) * 8);
+    tw_counters.ensure(64);
+    tw.logits = (float*)tw_logits.p;
+    tw.rec = (float*)tw_rec.p;
+    tw.keys = (unsigned long long*)tw_keys.p;
+    tw.counters = (int*)tw_counters.p;
+    tw.cap_anchors = total;
+    tw.cap_keys = npad;
+    const size_t rmax = (pre_nms_topN > 0) ? std::min<size_t>(total, (size_t)pre_nms_topN) : total;
+    blobs[boxes_blob].dev.ensure(std::max<size_t>(rmax, 1) * 5 * 4);
+    if (prob_blob >= 0) blobs[prob_blob].dev.ensure(std::max<size_t>(rmax, 1) * 2 * 4);
+  }
+}
+
+void shf_net::build_tail_weights() {
+  if (tail_layer < 0) return;
+  tail_Cf = blobs[tail_feat_blobs[0]].shape[1];
+  const int A = tail_A, Cf = tail_Cf;
+  std::vector<float> W((size_t)A * 6 * Cf, 0.f), B((size_t)A * 6, 0.f);
+  for (int a = 0; a < A; ++a) {
+    const int h = tail_heads == 1 ? 0 : a;
+    Layer& c = layers[tail_cls_layers[h]];
+    Layer& b = layers[tail_box_layers[h]];
+    const float* cw = c.params[0]->host.data();
+    const float* bw = b.params[0]->host.data();
+    const float* cb = c.params.size() > 1 ? c.params[1]->host.data() : nullptr;
+    const float* bb = b.params.size() > 1 ? b.params[1]->host.data() : nullptr;
+    for (int cls = 0; cls < 2; ++cls) {
+      // plain template: cls_score channel = cls*A + a (Reshape (0,2,-1,0)); dilation template: channel = cls
+      const int row = tail_heads == 1 ? cls * A + a : cls;
+      memcpy(&W[((size_t)a * 6 + cls) * Cf], cw + (size_t)row * Cf, Cf * sizeof(float));
+      B[a * 6 + cls] = cb ? cb[row] : 0.f;
+    }
+    for (int j = 0; j < 4; ++j) {
+      const int row = tail_heads == 1 ? a * 4 + j : j;
+      memcpy(&W[((size_t)a * 6 + 2 + j) * Cf], bw + (size_t)row * Cf, Cf * sizeof(float));
+      B[a * 6 + 2 + j] = bb ? bb[row] : 0.f;
+    }
+  }
+  tail_W.ensure(W.size() * 4);
+  tail_b.ensure(B.size() * 4);
+  HIP_THROW(hipMemcpy(tail_W.p, W.data(), W.size() * 4, hipMemcpyHostToDevice));
+  HIP_THROW(hipMemcpy(tail_b.p, B.data(), B.size() * 4, hipMemcpyHostToDevice));
+  tail_w_dirty = false;
+}
+
+void shf_net::commit_params(int li) {
+  Layer& L = layers[li];
+  if (L.params.empty()) return;
+  HIP_THROW(hipStreamSynchronize(stream));
+  const bool in_tail = std::count(tail_cls_layers.begin(), tail_cls_layers.end(), li) ||
+                       std::count(tail_box_layers.begin(), tail_box_layers.end(), li);
+  for (size_t pi = 0; pi < L.params.size(); ++pi) {
+    ParamBlob& p = *L.params[pi];
+    p.raw.ensure(p.count() * 4);
+    HIP_THROW(hipMemcpy(p.raw.p, p.host.data(), p.count() * 4, hipMemcpyHostToDevice));
+    if (pi == 0 && L.type == "Convolution" && L.kclass == 0 && !in_tail) {
+      std::vector<float> packed(p.count());
+      pack_conv_weights(p.host.data(), p.shape[0], p.shape[1], p.shape[2], packed.data());
+      p.packed.ensure(packed.size() * 4);
+      HIP_THROW(hipMemcpy(p.packed.p, packed.data(), packed.size() * 4, hipMemcpyHostToDevice));
+    }
+    p.dirty = false;
+  }
+  if (in_tail) tail_w_dirty = true;
+}
+
+void shf_net::load_caffemodel(const std::string& path) {
+  // CopyTrainedLayersFrom (net.cpp:733-768): match by layer NAME, check shapes, copy blobs
+  auto src = read_caffemodel(path);
+  for (auto& sl : src) {
+    for (auto& L : layers) {
+      if (L.name != sl.name || L.params.empty()) continue;
+      if (sl.blobs.size() != L.params.size())
+        throw std::runtime_error("Incompatible number of blobs for layer " + L.name);
+      for (size_t i = 0; i < L.params.size(); ++i) {
+        ParamBlob& p = *L.params[i];
+        if (sl.blobs[i].data.size() != p.count())
+          throw std::runtime_error("Cannot copy param " + std::to_string(i) + " weights from layer '" + L.name +
+                                   "'; shape mismatch.");
+        std::copy(sl.blobs[i].data.begin(), sl.blobs[i].data.end(), p.host.begin());
+        p.dirty = true;
+      }
+    }
+  }
+}
+
+static double conv_flops(const Layer& L, const std::vector<int>& in, const std::vector<int>& out) {
+  return 2.0 * out[0] * out[2] * out[3] * (double)L.nout * in[1] * L.k * L.k;
+}
+
+void shf_net::forward_ops(bool fused_path, float im_h, float im_w, float im_scale) {
+  if (tail_w_dirty) build_tail_weights();
+  for (size_t li = 0; li < layers.size(); ++li) {
+    Layer& L = layers[li];
+    switch (L.op) {
+      case OP_SKIP: break;
+      case OP_CONV: {
+        ConvArgs a;
+        Blob& ib = blobs[L.bottoms[0]];
+        a.out = view_of(L.tops[0]);
+        a.k = L.k; a.dil = L.dil; a.pad = L.pad; a.relu = L.relu;
+        a.bias = L.params.size() > 1 ? (const float*)L.params[1]->raw.p : nullptr;
+        a.wraw = (const float*)L.params[0]->raw.p;
+        a.wpacked = (const float*)L.params[0]->packed.p;
+        const double fl = conv_flops(L, ib.shape, blobs[L.tops[0]].shape);
+        const double by = 4.0 * (ib.count() + blobs[L.tops[0]].count() + L.params[0]->count());
+        if (L.kclass == 1) {
+          a.in.B = ib.shape[0]; a.in.C = ib.shape[1]; a.in.H = ib.shape[2]; a.in.W = ib.shape[3];
+          const float* src = ib.ext_dev ? ib.ext_dev : (const float*)ib.dev.p;
+          ProfScope ps(prof, stream, PC_CONV_FIRST, fl, by);
+          CHECK_RC(launch_conv_first(src, a, stream));
+        } else {
+          a.in = view_of(L.bottoms[0]);
+          if (L.kclass == 0) {
+            ProfScope ps(prof, stream, PC_CONV_MFMA, fl, by);
+            CHECK_RC(launch_conv_mfma(a, stream));
+          } else {
+            ProfScope ps(prof, stream, PC_CONV_DIRECT, fl, by);
+            CHECK_RC(launch_conv_direct(a, stream));
+          }
+        }
+        break;
+      }
+      case OP_POOL: {
+        ProfScope ps(prof, stream, PC_POOL, 0, 4.0 * (blobs[L.bottoms[0]].count() + blobs[L.tops[0]].count()));
+        CHECK_RC(launch_maxpool(view_of(L.bottoms[0]), view_of(L.tops[0]), L.k, L.stride, L.pad, stream));
+        break;
+      }
+      case OP_DECONV: {
+        ProfScope ps(prof, stream, PC_DECONV, 2.0 * blobs[L.tops[0]].count() * 4,
+                     4.0 * (blobs[L.bottoms[0]].count() + blobs[L.tops[0]].count()));
+        CHECK_RC(launch_deconv_depthwise(view_of(L.bottoms[0]), view_of(L.tops[0]), (const float*)L.params[0]->raw.p,
+                                         L.params.size() > 1 ? (const float*)L.params[1]->raw.p : nullptr, L.k,
+                                         L.stride, L.pad, stream));
+        break;
+      }
+      case OP_TAIL: {
+        TailArgs t;
+        t.A = tail_A; t.heads = tail_heads; t.Cf = tail_Cf;
+        for (int i = 0; i < tail_heads; ++i) t.feat[i] = view_of(tail_feat_blobs[i]);
+        t.wcls[0] = (const float*)tail_W.p;
+        t.bcls[0] = (const float*)tail_b.p;
+        t.h = blobs[tail_feat_blobs[0]].shape[2];
+        t.w = blobs[tail_feat_blobs[0]].shape[3];
+        for (int i = 0; i < tail_A * 4; ++i) t.anchors[i] = (float)anchors[i];
+        for (int i = 0; i < tail_A; ++i) t.sub_stride[i] = sub_stride[i];
+        t.feat_stride = feat_stride;
+        t.im_h = im_h; t.im_w = im_w; t.im_scale = im_scale;
+        t.min_size = min_size; t.score_thresh = score_thresh; t.pre_nms_topN = pre_nms_topN;
+        if (materialize_tail && !fused_path) {
+          t.cls_prob_reshape_nchw = (float*)blobs[tail_cls_blob].dev.p;
+          t.bbox_pred_nchw = (float*)blobs[tail_box_blob].dev.p;
+        }
+        const double K = (double)t.h * t.w;
+        ProfScope ps(prof, stream, PC_TAIL, 2.0 * K * tail_A * 6 * tail_Cf,
+                     4.0 * K * (tail_heads * tail_Cf + tail_A * 18));
+        CHECK_RC(launch_tail(t, tw, (float*)blobs[boxes_blob].dev.p,
+                             prob_blob >= 0 ? (float*)blobs[prob_blob].dev.p : (float*)tw_rec.p, stream));
+        break;
+      }
+    }
+  }
+}
+
+void shf_net::forward() {
+  if (data_blob >= 0 && blobs[data_blob].shape != last_data_shape) {
+    infer_shapes();
+    alloc_buffers();
+  }
+  for (int bi : inputs) {
+    Blob& b = blobs[bi];
+    b.ext_dev = nullptr;
+    if (b.host_newer && b.host.p) {
+      b.dev.ensure(b.count() * 4);
+      HIP_THROW(hipMemcpyAsync(b.dev.p, b.host.p, b.count() * 4, hipMemcpyHostToDevice, stream));
+      b.host_newer = false;
+    }
+  }
+  float ii[3] = {0, 0, 1};
+  if (im_info_blob >= 0 && blobs[im_info_blob].host.p && blobs[im_info_blob].count() >= 3)
+    memcpy(ii, blobs[im_info_blob].host.p, 12);
+  forward_ops(false, ii[0], ii[1], ii[2]);
+  for (size_t i = 0; i < blobs.size(); ++i)
+    if (!std::count(inputs.begin(), inputs.end(), (int)i) && blobs[i].kind != BK_FUSED) blobs[i].dev_newer = true;
+  if (tail_layer >= 0) {
+    int cnt[8];
+    HIP_THROW(hipMemcpyAsync(cnt, tw.counters, sizeof(cnt), hipMemcpyDeviceToHost, stream));
+    HIP_THROW(hipStreamSynchronize(stream));
+    const int R = cnt[2];
+    blobs[boxes_blob].shape = {std::max(R, 1), 5};
+    if (prob_blob >= 0) blobs[prob_blob].shape = {R, 2};
+  } else {
+    HIP_THROW(hipStreamSynchronize(stream));
+  }
+}
+
+float* shf_net::host_data(int bi) {
+  Blob& b = blobs[bi];
+  if (b.kind == BK_FUSED)
+    throw std::runtime_error("blob '" + b.name + "' is fused into the detection tail and not materialised");
+  const size_t n = b.count();
+  b.host.ensure(std::max<size_t>(n, 1) * 4);
+  const bool is_input = std::count(inputs.begin(), inputs.end(), bi) > 0;
+  if (b.dev_newer && n > 0) {
+    if (b.kind == BK_NHWC) {
+      b.stage.ensure(n * 4);
+      {
+        ProfScope ps(prof, stream, PC_LAYOUT, 0, 8.0 * n);
+        CHECK_RC(launch_nhwc_to_nchw(view_of(bi), (float*)b.stage.p, stream));
+      }
+      HIP_THROW(hipMemcpyAsync(b.host.p, b.stage.p, n * 4, hipMemcpyDeviceToHost, stream));
+    } else {
+      HIP_THROW(hipMemcpyAsync(b.host.p, b.dev.p, n * 4, hipMemcpyDeviceToHost, stream));
+    }
+    HIP_THROW(hipStreamSynchronize(stream));
+    b.dev_newer = false;
+  }
+  if (is_input) b.host_newer = true;
+  return b.host.p;
+}
+
+// ---------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------
+#define API_BEGIN try {
+#define API_END(failval)                  \
+  }                                       \
+  catch (const std::exception& e) {       \
+    set_error(e.what());                  \
+    return failval;                       \
+  }                                       \
+  catch (...) {                           \
+    set_error("unknown error");           \
+    return failval;                       \
+  }
+
+static std::mutex g_box_mu;
+static MergeCtx* g_box_ctx = nullptr;
+static hipStream_t g_box_stream = nullptr;
+static DevBuf* g_box_in = nullptr;
+
+extern "C" {
+
+const char* shf_last_error(void) { return g_err.c_str(); }
+const char* shf_version(void) { return "smallhardface_amd 0.1 (gfx950)"; }
+int shf_set_mode_gpu(void) { return 0; }
+
+int shf_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int shf_set_device(int device_id) {
+  API_BEGIN
+  HIP_THROW(hipSetDevice(device_id));
+  return 0;
+  API_END(-1)
+}
+
+shf_net* shf_net_create(const char* prototxt_path, const char* prototxt_text, const char* caffemodel_path,
+                        int phase) {
+  API_BEGIN
+  std::string text;
+  if (prototxt_text && prototxt_text[0]) {
+    text = prototxt_text;
+  } else {
+    if (!prototxt_path) throw std::runtime_error("no prototxt given");
+    std::ifstream f(prototxt_path);
+    if (!f) throw std::runtime_error(std::string("Could not open file ") + prototxt_path);
+    std::stringstream ss;
+    ss << f.rdbuf();
+    text = ss.str();
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    throw std::runtime_error("no HIP device available: the detection runtime has no CPU fallback");
+  std::unique_ptr<shf_net> net(new shf_net());
+  net->phase = phase;
+  net->build(text, caffemodel_path);
+  return net.release();
+  API_END(nullptr)
+}
+
+void shf_net_destroy(shf_net* net) { delete net; }
+
+int shf_net_num_blobs(shf_net* net) { return (int)net->blobs.size(); }
+const char* shf_net_blob_name(shf_net* net, int i) {
+  if (i < 0 || i >= (int)net->blobs.size()) return nullptr;
+  return net->blobs[i].name.c_str();
+}
+int shf_net_num_inputs(shf_net* net) { return (int)net->inputs.size(); }
+int shf_net_input_blob(shf_net* net, int i) { return net->inputs[i]; }
+int shf_net_num_outputs(shf_net* net) { return (int)net->outputs.size(); }
+int shf_net_output_blob(shf_net* net, int i) { return net->outputs[i]; }
+int shf_net_num_layers(shf_net* net) { return (int)net->layers.size(); }
+const char* shf_net_layer_name(shf_net* net, int i) { return net->layers[i].name.c_str(); }
+const char* shf_net_layer_type(shf_net* net, int i) { return net->layers[i].type.c_str(); }
+int shf_net_layer_num_params(shf_net* net, int layer) { return (int)net->layers[layer].params.size(); }
+
+int shf_net_param_shape(shf_net* net, int layer, int idx, int* dims) {
+  auto& p = *net->layers[layer].params[idx];
+  for (size_t i = 0; i < p.shape.size(); ++i) dims[i] = p.shape[i];
+  return (int)p.shape.size();
+}
+
+float* shf_net_param_data(shf_net* net, int layer, int idx) {
+  auto& p = *net->layers[layer].params[idx];
+  p.dirty = true;
+  return p.host.data();
+}
+
+int shf_net_param_commit(shf_net* net, int layer) {
+  API_BEGIN
+  // a shared tensor is committed for every layer that holds it
+  for (size_t li = 0; li < net->layers.size(); ++li) {
+    bool share = (int)li == layer;
+    for (auto& p : net->layers[li].params)
+      for (auto& q : net->layers[layer].params)
+        if (p == q) share = true;
+    if (share) net->commit_params((int)li);
+  }
+  return 0;
+  API_END(-1)
+}
+
+int shf_blob_reshape(shf_net* net, int blob, const int* dims, int ndim) {
+  API_BEGIN
+  if (blob < 0 || blob >= (int)net->blobs.size()) throw std::runtime_error("bad blob index");
+  Blob& b = net->blobs[blob];
+  std::vector<int> s(dims, dims + ndim);
+  for (int d : s)
+    if (d < 0) throw std::runtime_error("negative blob dimension");
+  if (s != b.shape) {
+    b.shape = s;
+    if (std::count(net->inputs.begin(), net->inputs.end(), blob)) {
+      b.dev.ensure(std::max<size_t>(b.count(), 1) * 4);
+      b.host.ensure(std::max<size_t>(b.count(), 1) * 4);
+      b.host_newer = true;
+    }
+  }
+  return 0;
+  API_END(-1)
+}
+
+int shf_blob_shape(shf_net* net, int blob, int* dims) {
+  Blob& b = net->blobs[blob];
+  for (size_t i = 0; i < b.shape.size(); ++i) dims[i] = b.shape[i];
+  return (int)b.shape.size();
+}
+
+float* shf_blob_mutable_host_data(shf_net* net, int blob) {
+  API_BEGIN
+  if (blob < 0 || blob >= (int)net->blobs.size()) throw std::runtime_error("bad blob index");
+  return net->host_data(blob);
+  API_END(nullptr)
+}
+
+int shf_net_forward(shf_net* net) {
+  API_BEGIN
+  net->forward();
+  return 0;
+  API_END(-1)
+}
+
+int shf_net_set_proposal_cfg(shf_net* net, int pre_nms_topN, float score_thresh, float min_size) {
+  API_BEGIN
+  net->pre_nms_topN = pre_nms_topN;
+  net->score_thresh = score_thresh;
+  net->min_size = min_size;
+  net->alloc_buffers();
+  return 0;
+  API_END(-1)
+}
+
+int shf_detect_begin(shf_net* net) {
+  API_BEGIN
+  if (net->tail_layer < 0) throw std::runtime_error("net has no proposal layer");
+  net->img_count.ensure(64);
+  HIP_THROW(hipMemsetAsync(net->img_count.p, 0, 64, net->stream));
+  net->img_units = 0;
+  return 0;
+  API_END(-1)
+}
+
+int shf_detect_add_level(shf_net* net, const float* data, int data_on_device, int H, int W, int im_h, int im_w,
+                         float im_scale, int flip, float thresh) {
+  API_BEGIN
+  Blob& d = net->blobs[net->data_blob];
+  std::vector<int> shp = {1, d.shape.size() == 4 ? d.shape[1] : 3, H, W};
+  if (shp != d.shape) d.shape = shp;
+  if (d.shape != net->last_data_shape) {
+    net->infer_shapes();
+    net->alloc_buffers();
+  }
+  if (data_on_device) {
+    d.ext_dev = data;
+  } else {
+    d.ext_dev = nullptr;
+    d.dev.ensure(d.count() * 4);
+    HIP_THROW(hipMemcpyAsync(d.dev.p, data, d.count() * 4, hipMemcpyHostToDevice, net->stream));
+  }
+  net->forward_ops(true, (float)im_h, (float)im_w, im_scale);
+  d.ext_dev = nullptr;
+  // room for every unit's top-N
+  const int rmax = net->pre_nms_topN > 0 ? net->pre_nms_topN : (int)net->tw.cap_anchors;
+  const int need = (net->img_units + 1) * rmax;
+  if (need > net->img_cap) {
+    // grow geometrically; keep what is already gathered
+    int ncap = std::max(need, std::max(net->img_cap * 2, 16 * rmax));
+    DevBuf nd, nk;
+    nd.ensure((size_t)ncap * 5 * 4);
+    size_t npad = 1;
+    while (npad < (size_t)ncap) npad <<= 1;
+    nk.ensure(npad * 8);
+    if (net->img_dets.p) {
+      HIP_THROW(hipMemcpyAsync(nd.p, net->img_dets.p, (size_t)net->img_cap * 5 * 4, hipMemcpyDeviceToDevice, net->stream));
+      HIP_THROW(hipMemcpyAsync(nk.p, net->img_keys.p, (size_t)net->img_cap * 8, hipMemcpyDeviceToDevice, net->stream));
+      HIP_THROW(hipStreamSynchronize(net->stream));
+    }
+    std::swap(net->img_dets.p, nd.p); std::swap(net->img_dets.cap, nd.cap);
+    std::swap(net->img_keys.p, nk.p); std::swap(net->img_keys.cap, nk.cap);
+    net->img_cap = ncap;
+  }
+  {
+    ProfScope ps(net->prof, net->stream, PC_TAIL, 0, 0);
+    CHECK_RC(launch_append_dets((float*)net->blobs[net->boxes_blob].dev.p,
+                                net->prob_blob >= 0 ? (float*)net->blobs[net->prob_blob].dev.p : (float*)net->tw_rec.p,
+                                net->tw.counters + 2, rmax, (float)im_w, im_scale, flip, thresh, net->img_units,
+                                (float*)net->img_dets.p, (unsigned long long*)net->img_keys.p,
+                                (int*)net->img_count.p, net->img_cap, net->stream));
+  }
+  net->img_units++;
+  return 0;
+  API_END(-1)
+}
+
+int shf_detect_count(shf_net* net) {
+  API_BEGIN
+  int c[2] = {0, 0};
+  HIP_THROW(hipMemcpyAsync(c, net->img_count.p, 8, hipMemcpyDeviceToHost, net->stream));
+  HIP_THROW(hipStreamSynchronize(net->stream));
+  return c[net->img_units & 1];
+  API_END(-1)
+}
+
+int shf_detect_finish(shf_net* net, int method, float nms_thresh, double* out5, int cap, int* n_out) {
+  API_BEGIN
+  const int n = shf_detect_count(net);
+  if (n < 0) return -1;
+  *n_out = 0;
+  if (n == 0) {
+    if (method == 0) {  // bbox_vote on an empty set (test.py:184-186)
+      const double d[5] = {10, 10, 20, 20, 0.0001};
+      if (cap > 0) memcpy(out5, d, sizeof(d));
+      *n_out = 1;
+    }
+    return 0;
+  }
+  ProfScope ps(net->prof, net->stream, PC_MERGE, 0, 0);
+  return net->merge.run((const float*)net->img_dets.p, n, method, nms_thresh, out5, cap, n_out, nullptr, net->stream);
+  API_END(-1)
+}
+
+static void box_ctx_init() {
+  if (g_box_ctx) return;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    throw std::runtime_error("no HIP device available: box merging has no CPU fallback");
+  g_box_ctx = new MergeCtx();
+  g_box_in = new DevBuf();
+  HIP_THROW(hipStreamCreateWithFlags(&g_box_stream, hipStreamNonBlocking));
+}
+
+int shf_nms(const float* dets5, int n, float thresh, int device_id, int32_t* keep, int* n_keep) {
+  API_BEGIN
+  std::lock_guard<std::mutex> lk(g_box_mu);
+  *n_keep = 0;
+  if (n <= 0) return 0;
+  if (device_id >= 0) {
+    int cur = -1;
+    HIP_THROW(hipGetDevice(&cur));
+    if (cur != device_id) HIP_THROW(hipSetDevice(device_id));  // _set_device, nms_kernel.cu:91-100
+  }
+  box_ctx_init();
+  g_box_in->ensure((size_t)n * 5 * 4);
+  HIP_THROW(hipMemcpyAsync(g_box_in->p, dets5, (size_t)n * 5 * 4, hipMemcpyHostToDevice, g_box_stream));
+  return g_box_ctx->run((const float*)g_box_in->p, n, 1, thresh, nullptr, 0, n_keep, keep, g_box_stream);
+  API_END(-1)
+}
+
+int shf_bbox_vote(const float* dets5, int n, float thresh, double* out5, int cap, int* n_out) {
+  API_BEGIN
+  std::lock_guard<std::mutex> lk(g_box_mu);
+  *n_out = 0;
+  if (n <= 0) {
+    const double d[5] = {10, 10, 20, 20, 0.0001};
+    if (cap > 0) memcpy(out5, d, sizeof(d));
+    *n_out = 1;
+    return 0;
+  }
+  box_ctx_init();
+  g_box_in->ensure((size_t)n * 5 * 4);
+  HIP_THROW(hipMemcpyAsync(g_box_in->p, dets5, (size_t)n * 5 * 4, hipMemcpyHostToDevice, g_box_stream));
+  return g_box_ctx->run((const float*)g_box_in->p, n, 0, thresh, out5, cap, n_out, nullptr, g_box_stream);
+  API_END(-1)
+}
+
+int shf_generate_anchors(int base_size, const double* ratios, int n_ratios, const double* scales, int n_scales,
+                         const double* shifts, int n_shifts, const double* strides, double* out, int cap_rows) {
+  API_BEGIN
+  std::vector<double> a;
+  gen_anchors(base_size, std::vector<double>(ratios, ratios + n_ratios), std::vector<double>(scales, scales + n_scales),
+              std::vector<double>(shifts, shifts + n_shifts), std::vector<double>(strides, strides + n_scales), a);
+  const int rows = (int)a.size() / 4;
+  if (rows > cap_rows) throw std::runtime_error("anchor output buffer too small");
+  std::copy(a.begin(), a.end(), out);
+  return rows;
+  API_END(-1)
+}
+
+int shf_prof_enable(shf_net* net, int enable) {
+  net->prof.on = enable != 0;
+  return 0;
+}
+int shf_prof_num_classes(shf_net*) { return PC_COUNT; }
+const char* shf_prof_class_name(shf_net*, int cls) { return (cls >= 0 && cls < PC_COUNT) ? kProfNames[cls] : nullptr; }
+int shf_prof_read(shf_net* net, int cls, int64_t* launches, double* total_ms, double* flops, double* bytes) {
+  API_BEGIN
+  if (cls < 0 || cls >= PC_COUNT) throw std::runtime_error("bad profile class");
+  net->prof.drain();
+  *launches = net->prof.launches[cls];
+  *total_ms = net->prof.ms[cls];
+  *flops = net->prof.flops[cls];
+  *bytes = net->prof.bytes[cls];
+  return 0;
+  API_END(-1)
+}
+int shf_prof_reset(shf_net* net) {
+  API_BEGIN
+  net->prof.drain();
+  for (int i = 0; i < PC_COUNT; ++i) {
+    net->prof.launches[i] = 0;
+    net->prof.ms[i] = net->prof.flops[i] = net->prof.bytes[i] = 0;
+  }
+  return 0;
+  API_END(-1)
+}
+int shf_net_sync(shf_net* net) {
+  API_BEGIN
+  HIP_THROW(hipStreamSynchronize(net->stream));
+  return 0;
+  API_END(-1)
+}
+
+}  // extern "C"

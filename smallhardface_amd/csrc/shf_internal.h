@@ -1,0 +1,118 @@
+// Internal declarations shared by the HIP kernels and the Net runtime.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+namespace shf {
+
+void set_error(const std::string& msg);
+#define SHF_HIP_OK(expr)                                                              \
+  do {                                                                                \
+    hipError_t _e = (expr);                                                           \
+    if (_e != hipSuccess) {                                                           \
+      ::shf::set_error(std::string(#expr) + ": " + hipGetErrorString(_e));            \
+      return -1;                                                                      \
+    }                                                                                 \
+  } while (0)
+
+// ---- tensor view: NHWC fp32 on the device, possibly a channel slice of a wider buffer
+struct View {
+  float* p = nullptr;  // base of the buffer
+  int B = 1, H = 1, W = 1, C = 1;
+  int cstride = 1;  // floats per pixel in the underlying buffer (>= C)
+  int coff = 0;     // first channel of this view inside a pixel
+};
+
+// ---- convolution (stride 1, "same" geometry: pad == dil*(k-1)/2) ------------
+struct ConvArgs {
+  View in, out;
+  const float* wpacked = nullptr;  // [Cin/32][k*k][Cout][32] (see pack_conv_weights)
+  const float* wraw = nullptr;     // Caffe layout (Cout,Cin,k,k) for the direct kernels
+  const float* bias = nullptr;     // [Cout] or null
+  int k = 3, dil = 1, pad = 1;
+  int relu = 0;
+};
+// which kernel class a conv will use: 0 = mfma implicit GEMM, 1 = first-layer direct (NCHW in), 2 = generic direct
+int conv_kernel_class(int Cin, int Cout, int k, int pad, int dil, bool in_nchw);
+int launch_conv_mfma(const ConvArgs& a, hipStream_t s);
+// first layer: input is the NCHW 'data' blob (B,Cin,H,W), Cin <= 8, Cout % 16 == 0
+int launch_conv_first(const float* in_nchw, const ConvArgs& a, hipStream_t s);
+int launch_conv_direct(const ConvArgs& a, hipStream_t s);
+int conv_init_attributes();
+// host-side weight re-pack for the mfma kernel
+void pack_conv_weights(const float* w, int Cout, int Cin, int k, float* dst);
+size_t packed_conv_weight_floats(int Cout, int Cin, int k);
+
+// ---- misc layers -------------------------------------------------------------
+int launch_maxpool(const View& in, const View& out, int k, int stride, int pad, hipStream_t s);
+// depthwise transposed conv (group == C), weights (C,1,k,k) Caffe layout
+int launch_deconv_depthwise(const View& in, const View& out, const float* w, const float* bias, int k,
+                            int stride, int pad, hipStream_t s);
+int launch_copy_view(const View& in, const View& out, hipStream_t s);       // concat fallback
+int launch_nhwc_to_nchw(const View& in, float* out_nchw, hipStream_t s);    // blob.data read-back
+int launch_nchw_to_nhwc(const float* in_nchw, const View& out, hipStream_t s);
+
+// ---- detection tail ------------------------------------------------------------
+struct TailArgs {
+  // per-anchor-set (dilation head) features and 1x1 weights
+  int A = 3;                 // anchors per cell (== number of heads, or 1 head with A outputs)
+  int heads = 3;             // number of distinct feature maps (3: one per dilation; 1: plain template)
+  View feat[8];              // head feature maps (h,w,Cf)
+  const float* wcls[8];      // heads==A: (2,Cf) per head ; heads==1: (2A,Cf)
+  const float* bcls[8];
+  const float* wbox[8];      // heads==A: (4,Cf) per head ; heads==1: (4A,Cf)
+  const float* bbox[8];
+  int h = 0, w = 0, Cf = 128;
+  float anchors[8 * 4];      // base anchors (A,4) as float32 (bbox_transform.py:37 casts)
+  int feat_stride = 8;
+  int sub_stride[8];         // per-anchor subsampling stride ratio (proposal_layer.py:160-169)
+  float im_h = 0, im_w = 0, im_scale = 1;  // im_info
+  float min_size = 0;        // cfg.TEST.ANCHOR_MIN_SIZE (scaled by im_scale in-kernel)
+  float score_thresh = 0.002f;
+  int pre_nms_topN = 10000;
+  // optional materialised Caffe blobs (NCHW), may be null
+  float* cls_prob_reshape_nchw = nullptr;  // (1,2A,h,w)
+  float* bbox_pred_nchw = nullptr;         // (1,4A,h,w)
+};
+struct TailWork {  // device workspace owned by the net, sized for the largest level seen
+  float* logits = nullptr;           // [K][A][6]
+  float* rec = nullptr;              // [K*A][6] = bg, fg, x1,y1,x2,y2
+  unsigned long long* keys = nullptr;  // [pow2 >= K*A]
+  int* counters = nullptr;           // [8]: 0 = n candidates, 1 = overflow flag, 2 = R, 3 = argmax idx
+  size_t cap_anchors = 0, cap_keys = 0;
+};
+// runs logits -> decode -> select -> sort; leaves R (device counters[2]) rows in out_boxes/out_probs
+int launch_tail(const TailArgs& a, TailWork& ws, float* out_boxes5, float* out_probs2, hipStream_t s);
+
+// generic device sort of u64 keys, descending; n_dev points at the element count on the device,
+// n_max is a host-known upper bound (sizes the launch sequence)
+int launch_sort_desc_u64(unsigned long long* keys, const int* n_dev, size_t n_max, hipStream_t s);
+
+// append >thresh detections of one unit to the image list (test.py:52-66,163-167)
+int launch_append_dets(const float* boxes5, const float* probs2, const int* R_dev, int r_max, float im_w,
+                       float im_scale, int flip, float thresh, int unit, float* img_dets5,
+                       unsigned long long* img_keys, int* img_count, int img_cap, hipStream_t s);
+
+// ---- box merging ----------------------------------------------------------------
+struct MergeWork {
+  float* sorted = nullptr;                // [n][5] score-descending
+  unsigned long long* mask = nullptr;     // [n][ceil(n/64)]
+  int* cluster = nullptr;                 // [n] cluster head of each box (-1: none)
+  int* heads = nullptr;                   // [n] kept head indices (sorted order)
+  int* counters = nullptr;                // [4]: 0 = number of heads
+  double* out = nullptr;                  // [n][5]
+  int* out_idx = nullptr;                 // [n]
+  size_t cap_n = 0, cap_mask_words = 0;
+};
+// dets sorted descending on the device -> greedy clustering.
+// ge_pred: 1 -> IoU >= thr (bbox_vote), 0 -> IoU > thr (nms)
+int launch_iou_mask(const float* sorted5, int n, float thr, int ge_pred, unsigned long long* mask, hipStream_t s);
+int launch_greedy_scan(const unsigned long long* mask, int n, int* cluster, int* heads, int* counters, hipStream_t s);
+int launch_vote_accumulate(const float* sorted5, const unsigned long long* mask, const int* cluster, int n,
+                           const int* heads, const int* counters, double* out5, int* n_out, hipStream_t s);
+int launch_gather_sorted(const float* dets5, const unsigned long long* keys, int n, float* sorted5, int* perm,
+                         hipStream_t s);
+int launch_make_keys(const float* dets5, int n, unsigned long long* keys, hipStream_t s);
+
+}  // namespace shf

@@ -1,0 +1,255 @@
+"""Multi-GPU multi-scale inference driver.
+
+Mirrors /root/reference/lib/test.py (same function names, arguments, return values
+and error behaviour) on top of the pycaffe-compatible shim:
+
+  forward_net       test.py:21-106   pad to MAX_RESOLUTION, im_info, forward, flip fix, unscale, tile
+  detect            test.py:109-178  pyramid x flip loop, >thresh cut, bbox_vote / NMS
+  bbox_vote         test.py:181-217  (device implementation, see nms.py)
+  inference_worker  test.py:220-267  one worker per GPU
+  test_net          test.py:290-356  shard the image range over cfg.TEST.GPU_ID, gather
+
+plus ``detect_fused`` -- the same computation with the pyramid resident in HBM and all
+per-unit post-processing on the device (C ABI shf_detect_*), which is what bench.py times.
+The reference's ``"NMS"`` branch calls a name it never imports; here it
+is wired to lib/nms's GPU semantics.
+"""
+from __future__ import print_function
+
+import logging
+import os
+import pickle
+import sys
+
+import numpy as np
+
+from . import caffe
+from .config import cfg
+from .nms import bbox_vote, nms
+from .test_utils import _compute_scaling_factor, _get_image_blob
+from .timer import Timer
+
+logger = logging.getLogger(__name__)
+
+
+def _imread(path):
+    """cv2.imread stand-in (BGR uint8) -- OpenCV is not in the image."""
+    try:
+        import cv2
+        return cv2.imread(path)
+    except ImportError:
+        from PIL import Image
+        return np.asarray(Image.open(path).convert("RGB"))[:, :, ::-1].copy()
+
+
+def forward_net(net, blob, im_scale, pyramid=False, flip=False):
+    """Run one (scale, flip) unit; returns ([probs (R,2)], [pred_boxes (R,8)])."""
+    blob['im_info'] = np.array([[blob['data'].shape[2], blob['data'].shape[3], im_scale]], dtype=np.float32)
+
+    h, w = blob['data'].shape[2:]
+    new_h = int(np.ceil(1.0 * h / cfg.MAX_RESOLUTION) * cfg.MAX_RESOLUTION)
+    new_w = int(np.ceil(1.0 * w / cfg.MAX_RESOLUTION) * cfg.MAX_RESOLUTION)
+    data = np.pad(blob['data'], ((0, 0), (0, 0), (0, new_h - h), (0, new_w - w)), 'constant')
+
+    net.blobs['data'].reshape(*(data.shape))
+    net.blobs['im_info'].reshape(*(blob['im_info'].shape))
+    net_args = {'data': data.astype(np.float32, copy=False),
+                'im_info': blob['im_info'].astype(np.float32, copy=False)}
+    blobs_out = net.forward(**net_args)
+
+    if flip:
+        for i in [k for k in blobs_out.keys() if k.startswith('boxes')]:
+            blobs_out[i][:, [1, 3]] = w - blobs_out[i][:, [3, 1]]
+
+    pred_boxes = []
+    probs = []
+    if 'boxes' in net.blobs:
+        if not pyramid:
+            raise NotImplementedError("Please complete this part!")  # test.py:84-88
+        levels = [None]
+    else:
+        levels = [k.split('_')[-1] for k in net.blobs.keys() if k.startswith('boxes')]
+        if len(cfg.TEST.LEVEL) > 0:
+            logger.warning('Subset of levels selected for evaluation: {}'.format(cfg.TEST.LEVEL))
+            levels = cfg.TEST.LEVEL
+    for level in levels:
+        suffix = '' if level is None else '_{}'.format(level)
+        cur_boxes = net.blobs['boxes' + suffix].data
+        cur_boxes = cur_boxes[:, 1:5] / im_scale  # back to raw image space
+        cur_probs = net.blobs['cls_prob' + suffix].data
+        pred_boxes.append(np.tile(cur_boxes, (1, cur_probs.shape[1])))
+        probs.append(cur_probs)
+    return probs, pred_boxes
+
+
+def _merge_class_dets(probs, boxes, thresh):
+    """The per-class >thresh cut and box merging of detect() (test.py:161-176)."""
+    cls_dets = [None] * (probs.shape[1] - 1)
+    for class_i in range(1, probs.shape[1]):
+        inds = np.where(probs[:, class_i] > thresh)[0]
+        probs_i = probs[inds, class_i]
+        boxes_i = boxes[inds, :]
+        dets = np.hstack((boxes_i, probs_i[:, np.newaxis])).astype(np.float32, copy=False)
+        if cfg.TEST.NMS_METHOD == "BBOX_VOTE":
+            cls_dets[class_i - 1] = bbox_vote(dets)
+        elif cfg.TEST.NMS_METHOD == "NMS":
+            keep = nms(dets, cfg.TEST.NMS_THRESH)
+            cls_dets[class_i - 1] = dets[keep, :]
+        else:
+            raise NotImplementedError("Unknown NMS method: {}".format(cfg.TEST.NMS_METHOD))
+    assert all([_ is not None for _ in cls_dets]), 'None in detection results'
+    return cls_dets
+
+
+def detect(net, im_path, thresh=0.05, timers=None, pyramid=False, im=None):
+    if not timers:
+        timers = {'detect': Timer(), 'misc': Timer()}
+    if im is None:
+        im = _imread(im_path)
+    sys.stdout.flush()
+    timers['detect'].tic()
+
+    if not pyramid:
+        im_scale = _compute_scaling_factor(im.shape, cfg.TEST.SCALES[0], cfg.TEST.MAX_SIZE)
+        im_blob = _get_image_blob(im, [im_scale])
+        probs, boxes = forward_net(net, im_blob[0], im_scale, pyramid=False)
+        if isinstance(probs, list):
+            probs = np.vstack(probs)
+            boxes = np.vstack(boxes)
+        boxes = boxes[:, 0:4]
+    else:
+        all_probs = []
+        all_boxes = []
+        base_scale = _compute_scaling_factor(im.shape, cfg.TEST.PYRAMID_BASE_SIZE[0],
+                                             cfg.TEST.PYRAMID_BASE_SIZE[1])
+        pyramid_scales = [float(scale) / cfg.TEST.PYRAMID_BASE_SIZE[0] * base_scale for scale in cfg.TEST.SCALES]
+        im_blobs = _get_image_blob(im, pyramid_scales)
+        for i in range(len(pyramid_scales)):
+            probs, boxes = forward_net(net, im_blobs[i], pyramid_scales[i], pyramid=True)
+            for j in range(len(probs)):
+                all_boxes.append(boxes[j][:, 0:4])
+                all_probs.append(probs[j].copy())
+            if cfg.TEST.FLIP:
+                probs, boxes = forward_net(net, {'data': im_blobs[i]['data'][..., ::-1]}, pyramid_scales[i],
+                                           pyramid=True, flip=True)
+                for j in range(len(probs)):
+                    all_boxes.append(boxes[j][:, 0:4])
+                    all_probs.append(probs[j].copy())
+        probs = np.concatenate(all_probs)
+        boxes = np.concatenate(all_boxes)
+    timers['detect'].toc()
+    timers['misc'].tic()
+    cls_dets = _merge_class_dets(probs, boxes, thresh)
+    timers['misc'].toc()
+    return cls_dets, timers
+
+
+def pyramid_units(im, scales=None):
+    """The (blob, scale, flip) units detect() feeds the net for one image, padded to
+    MAX_RESOLUTION (test.py:35-38,141-155).  Yields (data (1,3,H,W) f32, H, W, im_h, im_w, scale, flip)."""
+    if scales is None:
+        base_scale = _compute_scaling_factor(im.shape, cfg.TEST.PYRAMID_BASE_SIZE[0],
+                                             cfg.TEST.PYRAMID_BASE_SIZE[1])
+        scales = [float(scale) / cfg.TEST.PYRAMID_BASE_SIZE[0] * base_scale for scale in cfg.TEST.SCALES]
+    im_blobs = _get_image_blob(im, scales)
+    m = cfg.MAX_RESOLUTION
+    for blob, s in zip(im_blobs, scales):
+        for flip in ([False, True] if cfg.TEST.FLIP else [False]):
+            d = blob['data'][..., ::-1] if flip else blob['data']
+            h, w = d.shape[2:]
+            nh, nw = int(np.ceil(1.0 * h / m) * m), int(np.ceil(1.0 * w / m) * m)
+            d = np.pad(d, ((0, 0), (0, 0), (0, nh - h), (0, nw - w)), 'constant')
+            yield np.ascontiguousarray(d, dtype=np.float32), nh, nw, h, w, s, flip
+
+
+def detect_fused(net, units, thresh=0.05, on_device=False):
+    """detect() with every per-unit step on the device.  ``units`` is an iterable of
+    (data, H, W, im_h, im_w, scale, flip) where data is a host array or a device pointer."""
+    net.detect_begin()
+    for data, H, W, im_h, im_w, s, flip in units:
+        net.detect_add_level(data, H, W, im_h, im_w, s, flip, thresh, on_device=on_device)
+    return [net.detect_finish(cfg.TEST.NMS_METHOD, cfg.TEST.NMS_THRESH)]
+
+
+def inference_worker(rank, imdb, target_test, start, end, thresh, result_queue=None):
+    cfg.GPU_ID = cfg.TEST.GPU_ID[rank]
+    caffe.set_mode_gpu()
+    caffe.set_device(cfg.GPU_ID)
+    net = caffe.Net(str(target_test), str(cfg.TEST.MODEL), caffe.TEST)
+
+    timers = {'detect': Timer(), 'misc': Timer()}
+    pyramid = True if len(cfg.TEST.SCALES) > 1 else False
+    dets = [[[] for _ in range(start, end)] for _ in range(imdb.num_classes)]
+    for i in range(start, end):
+        im_path = imdb.image_path_at(i)
+        dets_, _ = detect(net, im_path, thresh, timers=timers, pyramid=pyramid)
+        for c in range(imdb.num_classes - 1):
+            dets[c + 1][i - start] = dets_[c]
+        if rank == 0:
+            print('\r{:02d}% detect-time: {:.3f}s, misc-time:{:.3f}s, remain-time: {:.3f}s'.format(
+                int(100 * (i + 1 - start) / (end - start)), timers['detect'].average_time,
+                timers['misc'].average_time,
+                (end - i - 1) * (timers['detect'].average_time + timers['misc'].average_time)), end='')
+    if result_queue:
+        result_queue.put((rank, dets))
+        return
+    return dets
+
+
+def _worker_entry(cfg_state, rank, imdb, target_test, start, end, thresh, result_queue):
+    cfg.clear()
+    cfg.update(cfg_state)
+    inference_worker(rank, imdb, target_test, start, end, thresh, result_queue)
+
+
+def test_net(imdb, output_dir, target_test, thresh=0.05, no_cache=False, step=0):
+    logger.info('Evaluating {} on {}'.format(cfg.NAME, imdb.name))
+    run_inference = True
+    dets = None
+    if not no_cache:
+        det_file = os.path.join(output_dir, 'detections.pkl')
+        if os.path.exists(det_file):
+            try:
+                with open(det_file, 'rb') as f:
+                    dets = pickle.load(f)
+                    run_inference = False
+                    logger.info('Loading detections from cache: {}'.format(det_file))
+            except Exception:
+                logger.warning('Could not load the cached detections file, detecting from scratch!')
+
+    if run_inference:
+        if isinstance(cfg.TEST.GPU_ID, int):
+            cfg.TEST.GPU_ID = [cfg.TEST.GPU_ID]
+        assert len(cfg.TEST.GPU_ID) >= 1, "You must specify at least one GPU"
+        if len(cfg.TEST.GPU_ID) == 1:
+            dets = inference_worker(0, imdb, target_test, 0, len(imdb), thresh)
+        else:
+            # one process per GPU (spawn, not fork: a HIP context does not survive fork)
+            import multiprocessing as mp
+            ctx = mp.get_context("spawn")
+            result_queue = ctx.Queue()
+            procs = []
+            len_per_gpu = int(np.ceil(1. * len(imdb) / len(cfg.TEST.GPU_ID)))
+            for rank in range(len(cfg.TEST.GPU_ID)):
+                p = ctx.Process(target=_worker_entry,
+                                args=(dict(cfg), rank, imdb, target_test, len_per_gpu * rank,
+                                      min(len_per_gpu * (rank + 1), len(imdb)), thresh, result_queue))
+                p.daemon = True
+                p.start()
+                procs.append(p)
+            dets = [result_queue.get() for _ in procs]
+            for p in procs:
+                p.join()
+            dets = [det[1] for det in sorted(dets, key=lambda x: x[0])]
+            dets = [[_ for det in dets for _ in det[i]] for i in range(imdb.num_classes)]
+        assert len(dets[0]) == len(imdb), "Detection result compromised"
+        det_file = os.path.join(output_dir, 'detections.pkl')
+        if not no_cache:
+            with open(det_file, 'wb') as f:
+                pickle.dump(dets, f, pickle.HIGHEST_PROTOCOL)
+
+    logger.info('Evaluating detections')
+    result = imdb.evaluate_detections(all_boxes=dets, output_dir=output_dir, method_name=cfg.NAME, step=step)
+    logger.info(result)
+    logger.info('All Done!')
+    return dets

@@ -1,0 +1,279 @@
+"""GPU parity tests (run on an MI355X: ``pytest -m gpu``).  Everything goes through
+the C ABI (libshf_hip.so) and is checked against the CPU oracle / golden vectors.
+
+Tolerances: conv-stack activations 2e-5 relative to the blob's max (fp32 MFMA vs
+OpenBLAS summation order); scores 1e-4 absolute (north-star bar); box coordinates
+1e-3 px; integer indices / orders exact.
+"""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from smallhardface_amd import prototxt as P
+from smallhardface_amd.config import cfg
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+ACT_TOL = 2e-5
+SCORE_TOL = 1e-4
+BOX_TOL = 1e-3
+
+
+def conv_layer(name, bottom, nout, k, pad, dil=1, relu=True):
+    s = ('layer { name: "%s" type: "Convolution" bottom: "%s" top: "%s" convolution_param { num_output: %d '
+         'kernel_size: %d pad: %d dilation: %d } }\n' % (name, bottom, name, nout, k, pad, dil))
+    if relu:
+        s += 'layer { name: "%s_relu" type: "ReLU" bottom: "%s" top: "%s" }\n' % (name, name, name)
+    return s
+
+
+@pytest.mark.parametrize("cin,cout,k,dil,h,w,relu", [
+    (64, 64, 3, 1, 37, 53, True),      # BN=64 tile (conv1_2 shape class), ragged edges
+    (64, 128, 3, 1, 32, 48, True),     # BN=128 tile
+    (128, 256, 3, 1, 19, 21, False),   # no ReLU, negative outputs kept
+    (512, 512, 3, 1, 16, 24, True),    # conv4/5 class, 16 K-chunks
+    (512, 256, 1, 1, 9, 13, True),     # 1x1 (conv5_256 / conv4_256)
+    (128, 128, 3, 2, 22, 26, True),    # head_2
+    (128, 128, 3, 4, 22, 26, True),    # head_4
+    (128, 128, 3, 4, 5, 6, True),      # map smaller than the dilation halo
+])
+def test_conv_mfma(cin, cout, k, dil, h, w, relu):
+    pad = dil if k == 3 else 0
+    txt = H.single_layer_net(conv_layer("c0", "data", cin, 3, 1) + conv_layer("c1", "c0", cout, k, pad, dil, relu),
+                             3, h, w)
+    msg = P.parse(txt)
+    gnet, onet = H.make_pair(msg, seed=5)
+    # give the biases some life
+    rng = np.random.default_rng(3)
+    for name in ("c0", "c1"):
+        b = rng.normal(0, 0.5, onet.params[name][1].shape).astype(np.float32)
+        onet.params[name][1][...] = b
+    H.load_params(gnet, onet.params)
+    data = rng.normal(0, 1, (1, 3, h, w)).astype(np.float32)
+    go, oo = H.run_both(gnet, onet, data, np.array([[h, w, 1]], np.float32))
+    assert go["c1"].shape == oo["c1"].shape == (1, cout, h, w)
+    assert H.rel_err(go["c1"], oo["c1"]) < ACT_TOL
+    assert H.rel_err(gnet.blobs["c0"].data, onet.blobs["c0"].data) < ACT_TOL
+    if not relu:
+        assert (go["c1"] < 0).any()
+
+
+def test_conv_identity_is_transpose_detecting():
+    """A = I with an ASYMMETRIC weight pattern: catches swapped rows/cols in the MFMA epilogue."""
+    h, w, c = 8, 16, 64
+    txt = H.single_layer_net(conv_layer("c0", "data", c, 3, 1, relu=False) +
+                             conv_layer("c1", "c0", 128, 1, 0, relu=False), 3, h, w)
+    msg = P.parse(txt)
+    gnet, onet = H.make_pair(msg, seed=1)
+    w1 = np.zeros((128, c, 1, 1), np.float32)
+    for o in range(128):
+        for i in range(c):
+            w1[o, i, 0, 0] = (o * 3 + i * 7) % 11 - 5 + 0.25 * (o > i)
+    onet.params["c1"][0][...] = w1
+    H.load_params(gnet, onet.params)
+    data = np.random.default_rng(0).normal(0, 1, (1, 3, h, w)).astype(np.float32)
+    go, oo = H.run_both(gnet, onet, data, np.array([[h, w, 1]], np.float32))
+    assert H.rel_err(go["c1"], oo["c1"]) < ACT_TOL
+
+
+def test_pool_deconv_concat():
+    h, w = 18, 26
+    txt = H.single_layer_net(
+        conv_layer("c0", "data", 64, 3, 1) +
+        'layer { name: "p" type: "Pooling" bottom: "c0" top: "p" pooling_param { pool: MAX kernel_size: 2 stride: 2 } }\n' +
+        conv_layer("c1", "p", 64, 1, 0) +
+        'layer { name: "up" type: "Deconvolution" bottom: "c1" top: "up" convolution_param { kernel_size: 4 stride: 2 '
+        'num_output: 64 group: 64 pad: 1 weight_filler: { type: "bilinear" } bias_term: false } }\n' +
+        conv_layer("c2", "c0", 64, 1, 0) +
+        'layer { name: "cat" type: "Concat" bottom: "up" bottom: "c2" top: "cat" concat_param { axis: 1 } }\n' +
+        conv_layer("c3", "cat", 64, 3, 1), 3, h, w)
+    gnet, onet = H.make_pair(P.parse(txt), seed=9)
+    data = np.random.default_rng(1).normal(0, 1, (1, 3, h, w)).astype(np.float32)
+    go, oo = H.run_both(gnet, onet, data, np.array([[h, w, 1]], np.float32))
+    np.testing.assert_array_equal(gnet.blobs["p"].data >= 0, True)
+    for name in ("c0", "p", "c1", "up", "c2", "cat", "c3"):
+        a, b = gnet.blobs[name].data, onet.blobs[name].data
+        assert a.shape == b.shape, name
+        assert H.rel_err(a, b) < ACT_TOL, name
+    # max-pool is a pure selection: exact given identical inputs
+    np.testing.assert_array_equal(gnet.blobs["p"].data, O.max_pool_2x2_fast(gnet.blobs["c0"].data))
+
+
+def test_pool_known_answer_gpu():
+    """Caffe's TestForwardSquare literal (test_pooling_layer.cpp:49-119) needs stride 1 on a 3x5 map;
+    the GPU pool kernel is generic in k/stride."""
+    # route the literal through a 1x1 identity conv so the blob is NHWC on the device
+    row = np.array([[1, 2, 5, 2, 3], [9, 4, 1, 4, 8], [1, 2, 5, 2, 3]], np.float32)
+    txt = H.single_layer_net(conv_layer("c0", "data", 64, 3, 1, relu=False) +
+                             'layer { name: "p" type: "Pooling" bottom: "c0" top: "p" pooling_param { pool: MAX '
+                             'kernel_size: 2 stride: 1 } }\n', 4, 3, 5)
+    gnet, onet = H.make_pair(P.parse(txt), seed=2)
+    wid = np.zeros((64, 4, 3, 3), np.float32)
+    wid[:4, :, 1, 1] = np.eye(4)
+    onet.params["c0"][0][...] = wid
+    H.load_params(gnet, onet.params)
+    data = np.tile(row, (1, 4, 1, 1)).astype(np.float32)
+    go, _ = H.run_both(gnet, onet, data, np.array([[3, 5, 1]], np.float32))
+    exp = np.array([[9, 5, 5, 8], [9, 5, 5, 8]], np.float32)
+    np.testing.assert_array_equal(go["p"][0, :4], np.tile(exp, (4, 1, 1)))
+
+
+@pytest.mark.parametrize("dd,h,w,im", [(True, 64, 80, (61, 77)), (True, 112, 112, (100, 100)),
+                                       (False, 48, 64, (48, 64))])
+def test_detector_end_to_end(dd, h, w, im):
+    msg = H.detector_msg(dd)
+    gnet, onet = H.make_pair(msg)
+    data = H.synth_image_blob(h, w, seed=4)
+    info = np.array([[im[0], im[1], 0.75]], np.float32)
+    go, oo = H.run_both(gnet, onet, data, info)
+    names = ["conv1_1", "conv1_2", "pool1", "conv2_2", "conv3_3", "conv4_3", "pool4", "conv5_3", "conv5_256",
+             "conv5_256_up", "conv4_256", "conv4_fuse", "conv4_fuse_final"]
+    names += ["head_1", "head_2", "head_4"] if dd else ["head"]
+    for n in names:
+        a, b = gnet.blobs[n].data, onet.blobs[n].data
+        assert a.shape == b.shape, n
+        assert H.rel_err(a, b) < 5e-5, n
+    gp = gnet.blobs["cls_prob_reshape_output"].data
+    gd = gnet.blobs["bbox_pred_output"].data
+    assert np.abs(gp - onet.blobs["cls_prob_reshape_output"].data).max() < SCORE_TOL
+    assert np.abs(gd - onet.blobs["bbox_pred_output"].data).max() < 1e-3
+    # stage parity of the proposal tail on IDENTICAL inputs: order / indices exact
+    pb, pp = O.proposal_forward(gp, gd, info)
+    gb, gs = go["boxes"], go["cls_prob"]
+    assert gb.shape == pb.shape and gs.shape == pp.shape
+    np.testing.assert_array_equal(gs, pp)            # same scores in the same order
+    assert np.abs(gb - pb).max() < BOX_TOL
+    assert gb[:, 3].max() <= im[1] - 1 and gb[:, 4].max() <= im[0] - 1
+    # end to end vs the oracle net: match rows by score rank
+    ob, os_ = oo["boxes"], oo["cls_prob"]
+    n = min(len(ob), len(gb))
+    assert abs(len(ob) - len(gb)) <= max(2, 0.01 * len(ob))
+    assert np.abs(np.sort(gs[:, 1])[::-1][:n] - np.sort(os_[:, 1])[::-1][:n]).max() < SCORE_TOL
+    # blobs fused into the tail are not materialised and say so
+    if dd:
+        with pytest.raises(Exception, match="fused"):
+            gnet.blobs["cls_score_1_output"].data
+
+
+def test_net_surface():
+    msg = H.detector_msg(True)
+    gnet, onet = H.make_pair(msg)
+    assert list(gnet.blobs.keys())[:3] == ["data", "im_info", "conv1_1"]
+    assert gnet.inputs == ["data", "im_info"] and set(gnet.outputs) == {"boxes", "cls_prob"}
+    assert 'boxes' in gnet.blobs
+    assert list(gnet.blobs.keys()) == list(onet.blobs.keys())
+    with pytest.raises(Exception, match="Input blob arguments do not match net inputs."):
+        gnet.forward(data=np.zeros((1, 3, 16, 16), np.float32))
+    gnet.blobs["data"].reshape(1, 3, 16, 16)
+    with pytest.raises(Exception, match="Input is not batch sized"):
+        gnet.forward(data=np.zeros((2, 3, 16, 16), np.float32), im_info=np.zeros((1, 3), np.float32))
+    assert gnet.params["head_1"][0].shape == (128, 128, 3, 3)
+    # shared head weights alias one tensor (net.cpp:421-513)
+    gnet.params["head_2"][0].data[0, 0, 0, 0] = 42.0
+    assert gnet.params["head_4"][0].data[0, 0, 0, 0] == 42.0
+    d = gnet.blobs["data"].data
+    d[...] = 1.0
+    assert gnet.blobs["data"].data[0, 0, 0, 0] == 1.0  # writable zero-copy view
+
+
+def test_proposal_edge_cases():
+    """all-below-threshold keeps the single best anchor; >10000 candidates are cut at N_DETS_PER_MODULE."""
+    msg = H.detector_msg(True)
+    for bias, expect in ((12.0, "one"), (-6.0, "topn")):
+        gnet, onet = H.make_pair(msg, cls_bias=bias)
+        data = H.synth_image_blob(512 if expect == "topn" else 64, 512 if expect == "topn" else 64, seed=1)
+        h = data.shape[2]
+        info = np.array([[h, h, 1.0]], np.float32)
+        for net in (gnet,):
+            net.blobs['data'].reshape(*data.shape)
+            net.blobs['im_info'].reshape(1, 3)
+        go = gnet.forward(data=data, im_info=info)
+        gp = gnet.blobs["cls_prob_reshape_output"].data
+        gd = gnet.blobs["bbox_pred_output"].data
+        pb, pp = O.proposal_forward(gp, gd, info)
+        assert go["boxes"].shape == pb.shape
+        np.testing.assert_array_equal(go["cls_prob"], pp)
+        assert np.abs(go["boxes"] - pb).max() < BOX_TOL
+        if expect == "one":
+            assert pb.shape[0] == 1 and pp[0, 1] < 0.002
+        else:
+            assert pb.shape[0] == 10000
+
+
+VOTE_SETS = ["empty", "single", "two_overlap", "singletons", "last_singleton", "clusters_small",
+             "clusters_mid", "clusters_big", "dense", "iou_exact_0p4"]
+
+
+@pytest.mark.parametrize("name", VOTE_SETS)
+def test_bbox_vote_golden(golden, name):
+    from smallhardface_amd.nms import bbox_vote
+    g = golden("vote_nms.npz")
+    out = bbox_vote(g[name + "_dets"], 0.4)
+    ref = g[name + "_vote"]
+    assert out.shape == ref.shape and out.dtype == np.float64
+    np.testing.assert_array_equal(out, ref)   # bit-exact, incl. numpy's summation order
+
+
+@pytest.mark.parametrize("name", VOTE_SETS)
+@pytest.mark.parametrize("thr", [0.4, 0.3, 0.7])
+def test_nms_golden(golden, name, thr):
+    from smallhardface_amd.nms import nms
+    g = golden("vote_nms.npz")
+    keep = nms(g[name + "_dets"], thr)
+    np.testing.assert_array_equal(np.asarray(keep, dtype=np.int64), g[name + "_nms_%02d" % int(thr * 100)])
+
+
+def test_ties_are_canonical(golden):
+    """Equal scores: lower input index first (the oracle's canonical order)."""
+    from smallhardface_amd.nms import bbox_vote, nms
+    d = golden("vote_nms.npz")["ties_dets"]
+    np.testing.assert_array_equal(np.asarray(nms(d, 0.4)), O.nms(d, 0.4))
+    np.testing.assert_array_equal(bbox_vote(d, 0.4), np.asarray(O.bbox_vote(d, 0.4), dtype=np.float64))
+
+
+@pytest.mark.parametrize("n", [20000, 40000])
+def test_nms_vote_large(n):
+    """Multi-chunk device sort + long scans; checked against the oracle."""
+    from smallhardface_amd.nms import bbox_vote, nms
+    rng = np.random.default_rng(n)
+    c = rng.uniform(0, 3000, (n, 2))
+    s = rng.uniform(8, 80, (n, 2))
+    d = np.hstack([c, c + s, rng.uniform(0.05, 1, (n, 1))]).astype(np.float32)
+    keep = np.asarray(nms(d, 0.4))
+    np.testing.assert_array_equal(keep, O.nms(d, 0.4))
+    assert np.all(np.diff(d[keep, 4]) <= 0)  # sortedness property
+    if n == 20000:
+        np.testing.assert_array_equal(bbox_vote(d, 0.4), np.asarray(O.bbox_vote(d, 0.4), dtype=np.float64))
+    # idempotence: NMS of the kept set keeps everything
+    assert len(nms(d[keep], 0.4)) == len(keep)
+
+
+def test_detect_driver_vs_fused_vs_oracle():
+    """lib/test.py control flow on the GPU net, the fused device path, and the oracle net."""
+    from smallhardface_amd import test as T
+    cfg.MODEL.DIFFERENT_DILATION.ENABLE = True
+    cfg.TEST.SCALES = [100, 300]
+    msg = H.detector_msg(True)
+    gnet, onet = H.make_pair(msg, cls_bias=1.0)
+    im = np.random.default_rng(7).integers(0, 256, (96, 128, 3)).astype(np.uint8)
+    for method in ("BBOX_VOTE", "NMS"):
+        cfg.TEST.NMS_METHOD = method
+        dets, _ = T.detect(gnet, None, thresh=0.05, pyramid=True, im=im)
+        fused = T.detect_fused(gnet, T.pyramid_units(im), thresh=0.05)
+        assert dets[0].shape == fused[0].shape
+        np.testing.assert_array_equal(np.asarray(dets[0], dtype=np.float64), fused[0])
+        assert dets[0].shape[0] > 0
+    # the same driver over the oracle net (CPU checker) agrees within tolerance
+    cfg.TEST.NMS_METHOD = "NMS"
+    gd, _ = T.detect(gnet, None, thresh=0.05, pyramid=True, im=im)
+    import smallhardface_amd.test as tm
+    old = tm.nms
+    tm.nms = lambda d, t: list(O.nms(d, t))
+    try:
+        od, _ = T.detect(onet, None, thresh=0.05, pyramid=True, im=im)
+    finally:
+        tm.nms = old
+    assert abs(len(gd[0]) - len(od[0])) <= max(2, 0.02 * len(od[0]))
+    n = min(len(gd[0]), len(od[0]))
+    assert np.abs(gd[0][:n, 4] - od[0][:n, 4]).max() < SCORE_TOL * 5 or n == 0
