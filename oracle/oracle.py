@@ -441,9 +441,11 @@ def _ints(msg, name, default):
     return int(v[0]) if v else default
 
 
-def synth_params(net_msg, seed=1234, cls_bias=3.0):
-    """Seeded synthetic weights: He-normal conv weights, zero
-    biases except cls_score* = (+b,-b), bbox_pred* x0.1, bilinear deconv; layers
+def synth_params(net_msg, seed=1234, cls_bias=6.0):
+    """Seeded synthetic weights: He-normal conv weights (the conv
+    that reads the mean-subtracted image is scaled by 1/64 so activations and
+    logits are O(1) like a trained net's), zero biases except cls_score* = (+b,-b)
+    (b=6: ~1% of anchors above 0.05, WIDER-like), bbox_pred* x0.1, bilinear deconv; layers
     naming the same ``param {name:}`` share one tensor.  Returns
     {layer_name: [w, b]} with Caffe blob shapes.  Used by BOTH the oracle net and
     the HIP net (through Net.params) so they hold identical values."""
@@ -480,6 +482,8 @@ def synth_params(net_msg, seed=1234, cls_bias=3.0):
             b[cout // 2:] = -cls_bias
         if name.startswith("bbox_pred"):
             w *= F32(0.1)
+        if str(L.get("bottom")) == "data":
+            w *= F32(1.0 / 64.0)
         params[name] = [w, b] if bias_term else [w]
         if key:
             shared[key] = params[name]
@@ -548,7 +552,16 @@ class OracleNet(object):
         for L in self.layers:
             for tp in L.getall("top"):
                 produced_last[str(tp)] = True
-        self.outputs = [n for n in self.blobs if n not in consumed and n not in self.inputs]
+        # Net::Init available_blobs (net.cpp:95-110,240-246): name-ordered set
+        avail = set(self.inputs)
+        for L in self.layers:
+            if str(L.get("type")) == "Input":
+                continue
+            for b in L.getall("bottom"):
+                avail.discard(str(b))
+            for tp in L.getall("top"):
+                avail.add(str(tp))
+        self.outputs = sorted(avail)
         self.params = params if params is not None else synth_params(net_msg)
         self.pp = proposal_cfg or ProposalParams()
 

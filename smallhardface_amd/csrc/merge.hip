@@ -127,7 +127,9 @@ __global__ __launch_bounds__(64) void greedy_scan_kernel(const u64* __restrict__
     for (int j = 0; j < cnt; ++j) {
       if ((rem >> j) & 1ull) continue;
       kept |= 1ull << j;
-      const u64 row = ((u64)__builtin_amdgcn_readlane(dhi, j) << 32) | (u64)__builtin_amdgcn_readlane(dlo, j);
+      // readlane returns a signed int: go through unsigned or bit 31 smears over the high word
+      const u64 row = ((u64)(unsigned)__builtin_amdgcn_readlane((int)dhi, j) << 32) |
+                      (u64)(unsigned)__builtin_amdgcn_readlane((int)dlo, j);
       const u64 nb = row & ~rem;
       if (((nb >> lane) & 1ull) || lane == j) cl = base + j;
       rem |= nb | (1ull << j);

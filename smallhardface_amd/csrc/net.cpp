@@ -477,14 +477,18 @@ void shf_net::build(const std::string& text, const char* caffemodel) {
     for (int bi : inputs)
       if (blobs[bi].shape.size() == 4) { data_blob = bi; break; }
   }
-  // outputs = tops nobody consumes (net.cpp:240-246)
+  // outputs = blobs still "available" after the last layer (net.cpp:95-110,240-246): a bottom
+  // takes a blob off the set, a top (also an in-place one) puts it back; the set is ordered
+  // by NAME (std::set<string>), and an input nobody reads is an output too.
   {
-    std::set<int> consumed;
-    for (auto& L : layers)
-      for (int b : L.bottoms) consumed.insert(b);
-    std::set<int> is_in(inputs.begin(), inputs.end());
-    for (size_t i = 0; i < blobs.size(); ++i)
-      if (!consumed.count((int)i) && !is_in.count((int)i)) outputs.push_back((int)i);
+    std::set<std::string> avail;
+    for (int bi : inputs) avail.insert(blobs[bi].name);
+    for (auto& L : layers) {
+      if (L.type == "Input") continue;
+      for (int b : L.bottoms) avail.erase(blobs[b].name);
+      for (int t : L.tops) avail.insert(blobs[t].name);
+    }
+    for (auto& n : avail) outputs.push_back(blob_index[n]);
   }
 
   // ---- layer hyper-parameters, params, op assignment
@@ -1268,6 +1272,32 @@ int shf_bbox_vote(const float* dets5, int n, float thresh, double* out5, int cap
   g_box_in->ensure((size_t)n * 5 * 4);
   HIP_THROW(hipMemcpyAsync(g_box_in->p, dets5, (size_t)n * 5 * 4, hipMemcpyHostToDevice, g_box_stream));
   return g_box_ctx->run((const float*)g_box_in->p, n, 0, thresh, out5, cap, n_out, nullptr, g_box_stream);
+  API_END(-1)
+}
+
+// diagnostics: run the merge pipeline and hand back its intermediates (tests only)
+int shf_debug_merge(const float* dets5, int n, float thresh, int ge_pred, unsigned long long* mask_out,
+                    int* cluster_out, int* heads_out, int* n_heads, float* sorted_out, int* perm_out) {
+  API_BEGIN
+  std::lock_guard<std::mutex> lk(g_box_mu);
+  box_ctx_init();
+  g_box_in->ensure((size_t)n * 5 * 4);
+  HIP_THROW(hipMemcpyAsync(g_box_in->p, dets5, (size_t)n * 5 * 4, hipMemcpyHostToDevice, g_box_stream));
+  int nk = 0;
+  std::vector<int32_t> keep(n);
+  std::vector<double> tmp((size_t)n * 5);
+  CHECK_RC(g_box_ctx->run((const float*)g_box_in->p, n, ge_pred ? 0 : 1, thresh, tmp.data(), n, &nk, keep.data(),
+                          g_box_stream));
+  const size_t nw = ((size_t)n + 63) / 64;
+  HIP_THROW(hipMemcpy(mask_out, g_box_ctx->mask.p, (size_t)n * nw * 8, hipMemcpyDeviceToHost));
+  HIP_THROW(hipMemcpy(cluster_out, g_box_ctx->cluster.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+  HIP_THROW(hipMemcpy(sorted_out, g_box_ctx->sorted.p, (size_t)n * 5 * 4, hipMemcpyDeviceToHost));
+  HIP_THROW(hipMemcpy(perm_out, g_box_ctx->perm.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+  int cnt[2];
+  HIP_THROW(hipMemcpy(cnt, g_box_ctx->counters.p, 8, hipMemcpyDeviceToHost));
+  *n_heads = cnt[0];
+  HIP_THROW(hipMemcpy(heads_out, g_box_ctx->heads.p, (size_t)cnt[0] * 4, hipMemcpyDeviceToHost));
+  return 0;
   API_END(-1)
 }
 
