@@ -1,0 +1,231 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec over the full multi-scale test pyramid.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one window of N images (N = number of GPUs, weak scaling), each image being
+the reference's whole test pyramid (configs/smallhardface.toml: scales
+[100,300,600,1000,1400] x flip = 10 forward units, lib/test.py:141-155) of a synthetic
+1024x1024 source, followed by the >0.05 cut and bbox_vote (lib/test.py:161-175).  The
+pyramid blobs are resident in HBM before the timed region.  Units are sharded over the
+ranks so that each rank runs one unit of every (level, flip) kind per window; the
+detections of an image are gathered on its owner rank with an RCCL all_gather
+(smallhardface_amd/pyramid.py).
+
+Rank 0 prints ONE JSON line (contract in the task description) with two extra objects:
+  roofline      dominant kernel (fp32 MFMA implicit-GEMM conv) measured live with HIP
+                events on the runtime's own stream over the timed region
+  cpu_baseline  the numpy/OpenBLAS oracle (Caffe's im2col+SGEMM algorithm) timed on the
+                host cores on one pyramid level and scaled by algorithmic FLOPs
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 2.4 GHz
+SRC_H = SRC_W = 1024
+
+
+def build_units(image_index):
+    """The 10 (data, H, W, im_h, im_w, scale, flip) units of one synthetic 1024^2 image."""
+    from smallhardface_amd.test import pyramid_units
+    rng = np.random.default_rng(1000 + image_index)
+    im = rng.integers(0, 256, (SRC_H, SRC_W, 3)).astype(np.uint8)
+    return list(pyramid_units(im))
+
+
+def cpu_baseline(msg, params, seconds_budget=25.0):
+    """Oracle (port of Caffe's CPU algorithm: im2col + OpenBLAS SGEMM + numpy ProposalLayer)
+    on ONE pyramid level of the same workload, scaled to images/s by algorithmic FLOPs."""
+    from oracle import oracle as O
+    from smallhardface_amd.pyramid import level_flops
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    onet = O.OracleNet(msg, params=params)
+    img_flops = sum(2 * level_flops(s, s) for s in (112, 304, 608, 1008, 1408))
+    result = None
+    for side in (304, 608):
+        rng = np.random.default_rng(7)
+        data = (rng.integers(0, 256, (1, 3, side, side)).astype(np.float32) - 115.0)
+        onet.blobs['data'].reshape(*data.shape)
+        onet.blobs['im_info'].reshape(1, 3)
+        t0 = time.perf_counter()
+        onet.forward(data=data, im_info=np.array([[side - 4, side - 4, side / 1024.0]], np.float32))
+        dt = time.perf_counter() - t0
+        fl = level_flops(side, side)
+        result = {"value": (fl / img_flops) / dt, "unit": "images/s", "cores": int(threads), "kind": "port",
+                  "sample": "one %dx%d pyramid level (%.1f GFLOP of the %.1f GFLOP image) through the numpy/OpenBLAS "
+                            "oracle in %.2f s, scaled by algorithmic FLOPs" % (side, side, fl / 1e9, img_flops / 1e9, dt),
+                  "sample_seconds": dt, "sample_gflops_per_s": fl / dt / 1e9}
+        if dt * (level_flops(608, 608) / fl) > seconds_budget:
+            break
+    return result
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-events", action="store_true", help="do not record per-launch HIP events")
+    ap.add_argument("--method", default=None, help="BBOX_VOTE (default, the reference's) or NMS")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world))
+
+    import torch
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+
+    from smallhardface_amd import caffe, prototxt as P, pyramid, weights
+    from smallhardface_amd.config import cfg, cfg_from_file
+    cfg_from_file(os.path.join(ROOT, "configs", "smallhardface.toml"))
+    if args.method:
+        cfg.TEST.NMS_METHOD = args.method
+    caffe.set_mode_gpu()
+    caffe.set_device(local_rank)
+
+    msg = P._add_dimension_reduction(P.build_test_template(True))
+    params = weights.synth_params(msg, seed=1234)
+    net = caffe.Net(None, prototxt_text=P.dumps(msg))
+    for name, blobs in params.items():
+        for i, arr in enumerate(blobs):
+            net.params[name][i].data[...] = arr
+    net.commit_params()
+
+    # ---- the window: `world` images, this rank's share of their units resident in HBM
+    n_units = len(cfg.TEST.SCALES) * (2 if cfg.TEST.FLIP else 1)
+    mine = pyramid.my_units(rank, world, world, n_units)
+    units = {}
+    cache = {}
+    for (i, u) in mine:
+        if i not in cache:
+            cache = {i: build_units(i)}
+        data, H, W, im_h, im_w, s, flip = cache[i][u]
+        t = torch.from_numpy(data).to(dev)
+        units[(i, u)] = (t, H, W, im_h, im_w, s, flip)
+    del cache
+    flops_per_image = sum(pyramid.level_flops(v[1], v[2]) for v in units.values()) * (1.0 if world == 1 else 0.0)
+    exp_cap = n_units * cfg.TEST.N_DETS_PER_MODULE
+    export = [torch.empty((exp_cap, 5), dtype=torch.float32, device=dev) for _ in range(world)] if world > 1 else None
+    thresh = 0.05
+    last = {}
+
+    def step():
+        if world == 1:
+            net.detect_begin()
+            for u in range(n_units):
+                t, H, W, im_h, im_w, s, flip = units[(0, u)]
+                net.detect_add_level(t.data_ptr(), H, W, im_h, im_w, s, flip, thresh, on_device=True)
+            last[0] = net.detect_finish(cfg.TEST.NMS_METHOD, cfg.TEST.NMS_THRESH)
+            return
+        local = {}
+        for i in range(world):
+            net.detect_begin()
+            for u in range(n_units):
+                if (i, u) in units:
+                    t, H, W, im_h, im_w, s, flip = units[(i, u)]
+                    net.detect_add_level(t.data_ptr(), H, W, im_h, im_w, s, flip, thresh, on_device=True)
+            n = net.detect_export(export[i].data_ptr(), exp_cap)
+            local[i] = export[i][:min(n, exp_cap)]
+        got = pyramid.gather_window(local, world, rank, world, device=dev)
+        torch.cuda.synchronize()
+        for i, t in got.items():
+            net.detect_begin()
+            t = t.contiguous()
+            net.detect_import(t.data_ptr(), int(t.shape[0]))
+            last[i] = net.detect_finish(cfg.TEST.NMS_METHOD, cfg.TEST.NMS_THRESH)
+
+    def fence():
+        net.sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    if not args.no_events:
+        net.prof_enable(True)
+        net.prof_reset()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    prof = net.prof_read() if not args.no_events else {}
+    net.prof_enable(False)
+    if dist is not None:
+        te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te.item())
+
+    if rank == 0:
+        images = world * args.steps
+        value = images / elapsed
+        out = {
+            "metric": "images_per_sec_full_multiscale_pyramid", "value": value, "unit": "images/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": "C5: full smallhardface.toml test pyramid of a 1024x1024 source: scales "
+                            "[100,300,600,1000,1400] -> padded 112/304/608/1008/1408, x flip = 10 units/image "
+                            "(5021.6 GFLOP), VGG-16 + shared-weight dilated heads (different_dilation + dim_red), "
+                            "fp32, proposal tail + >0.05 cut + %s on device" % cfg.TEST.NMS_METHOD,
+                "images_per_step": world, "units_per_image": n_units, "parallelism":
+                    "pyramid units sharded 1-of-each-kind per GPU per window; RCCL all_gather of detections to the "
+                    "image's owner rank" if world > 1 else "single GPU",
+                "weights": "seeded synthetic (no trained caffemodel exists in the reference tree)",
+                "detections_last_image": int(len(next(iter(last.values())))) if last else 0,
+            },
+        }
+        # ---- roofline of the dominant kernel -----------------------------------------
+        convs = {k: v for k, v in prof.items() if k.startswith("conv_mfma") and v["launches"] > 0}
+        if convs:
+            name, dom = max(convs.items(), key=lambda kv: kv[1]["ms"])
+            ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+            all_ms = sum(v["ms"] for v in prof.values())
+            out["roofline"] = {
+                "bound": "mfma", "kernel": name, "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                "launches": dom["launches"], "avg_launch_ms": dom["ms"] / dom["launches"],
+                "algorithmic_gflop_per_launch": dom["flops"] / dom["launches"] / 1e9,
+                "all_conv_mfma_achieved": sum(v["flops"] for v in convs.values()) /
+                                          (sum(v["ms"] for v in convs.values()) * 1e-3) / 1e12,
+                "kernel_ms_share": {k: round(v["ms"] / all_ms, 4) for k, v in prof.items() if v["ms"] > 0},
+                "kernel_ms_per_image": {k: round(v["ms"] / args.steps, 3) for k, v in prof.items() if v["ms"] > 0},
+            }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(msg, params)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -21,9 +21,9 @@ extern "C" {
 typedef struct shf_net shf_net;
 
 /* ---- process / device ------------------------------------------------------ */
-/* caffe.set_mode_gpu()            caffe/python/caffe/_caffe.cpp:52 (set_mode_gpu)   */
+/* caffe.set_mode_gpu()            caffe/python/caffe/_caffe.cpp:52,394 (set_mode_gpu) */
 int shf_set_mode_gpu(void);
-/* caffe.set_device(id)            caffe/python/caffe/_caffe.cpp:405 (Caffe::SetDevice) */
+/* caffe.set_device(id)            caffe/python/caffe/_caffe.cpp:396 (Caffe::SetDevice) */
 int shf_set_device(int device_id);
 int shf_device_count(void);
 const char* shf_last_error(void);
@@ -38,14 +38,14 @@ shf_net* shf_net_create(const char* prototxt_path, const char* prototxt_text,
                         const char* caffemodel_path, int phase);
 void shf_net_destroy(shf_net* net);
 
-/* Net._blob_names / Net._inputs / Net._outputs          _caffe.cpp:430-443 */
+/* Net._blob_names / Net._inputs / Net._outputs          _caffe.cpp:432-440 */
 int shf_net_num_blobs(shf_net* net);
 const char* shf_net_blob_name(shf_net* net, int i);
 int shf_net_num_inputs(shf_net* net);
 int shf_net_input_blob(shf_net* net, int i);   /* index into blobs */
 int shf_net_num_outputs(shf_net* net);
 int shf_net_output_blob(shf_net* net, int i);
-/* Net._layer_names / Layer.type / Layer.blobs           _caffe.cpp:428,480-486 */
+/* Net._layer_names / Layer.type / Layer.blobs           _caffe.cpp:434,483-487 */
 int shf_net_num_layers(shf_net* net);
 const char* shf_net_layer_name(shf_net* net, int i);
 const char* shf_net_layer_type(shf_net* net, int i);
@@ -67,7 +67,7 @@ int shf_blob_shape(shf_net* net, int blob, int* dims);
  * syncs device->host (NHWC->NCHW) if the device copy is newer, marks host as head.
  * The pointer stays valid until the blob grows. */
 float* shf_blob_mutable_host_data(shf_net* net, int blob);
-/* Net._forward(0, n-1)             _caffe.cpp:421 -> Net::ForwardFromTo net.cpp:516 */
+/* Net._forward(0, n-1)             _caffe.cpp:414 -> Net::ForwardFromTo net.cpp:516 */
 int shf_net_forward(shf_net* net);
 
 /* The in-graph Python layer reads cfg.TEST.{N_DETS_PER_MODULE,SCORE_THRESH,
@@ -91,6 +91,13 @@ int shf_detect_add_level(shf_net* net, const float* data, int data_on_device,
 int shf_detect_finish(shf_net* net, int method, float nms_thresh, double* out5, int cap, int* n_out);
 /* number of >thresh detections gathered so far for the current image */
 int shf_detect_count(shf_net* net);
+/* Pyramid sharding across GPUs (the reference gathers per-worker results through a
+ * multiprocessing.Queue, lib/test.py:327-344; here units of ONE image may live on several
+ * GPUs): export copies the current image's (x1,y1,x2,y2,score) fp32 rows to a caller-owned
+ * DEVICE buffer (for an RCCL gather); import appends rows gathered from other ranks (device
+ * pointer) to the current image before shf_detect_finish. */
+int shf_detect_export(shf_net* net, float* dst_dev5, int cap_rows, int* n_rows);
+int shf_detect_import(shf_net* net, const float* src_dev5, int n_rows);
 
 /* ---- stand-alone box ops ----------------------------------------------------- */
 /* nms(dets, thresh)  lib/nms/nms_wrapper.py:13 -> gpu_nms lib/nms/gpu_nms.pyx:16-31
@@ -106,6 +113,12 @@ int shf_bbox_vote(const float* dets5, int n, float thresh, double* out5, int cap
 int shf_generate_anchors(int base_size, const double* ratios, int n_ratios, const double* scales,
                          int n_scales, const double* shifts, int n_shifts, const double* strides,
                          double* out, int cap_rows);
+
+/* ---- diagnostics (tests) ------------------------------------------------------ */
+/* runs the merge pipeline on host dets and returns its intermediates: the IoU bit matrix
+ * (n x ceil(n/64) words, upper triangle), cluster head per box, kept heads, sorted dets, perm */
+int shf_debug_merge(const float* dets5, int n, float thresh, int ge_pred, unsigned long long* mask_out,
+                    int* cluster_out, int* heads_out, int* n_heads, float* sorted_out, int* perm_out);
 
 /* ---- measurement ------------------------------------------------------------- */
 /* Per-kernel-class HIP-event timing on the net's stream.  enable!=0 starts recording

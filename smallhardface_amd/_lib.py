@@ -88,6 +88,9 @@ def _declare(lib):
         "shf_detect_add_level": (ci, [vp, vp, ci, ci, ci, ci, ci, cf, ci, cf]),
         "shf_detect_finish": (ci, [vp, ci, cf, dp, ci, ip]),
         "shf_detect_count": (ci, [vp]),
+        "shf_detect_export": (ci, [vp, vp, ci, ip]),
+        "shf_detect_import": (ci, [vp, vp, ci]),
+        "shf_debug_merge": (ci, [vp, ci, cf, ci, vp, vp, vp, ip, vp, vp]),
         "shf_nms": (ci, [fp, ci, cf, ci, C.POINTER(C.c_int32), ip]),
         "shf_bbox_vote": (ci, [fp, ci, cf, dp, ci, ip]),
         "shf_generate_anchors": (ci, [ci, dp, ci, dp, ci, dp, ci, dp, dp, ci]),

@@ -239,6 +239,22 @@ class Net(object):
                                                   int(im_w), float(im_scale), 1 if flip else 0, float(thresh)),
                    "detect_add_level")
 
+    def detect_count(self):
+        n = self._lib.shf_detect_count(self._h)
+        if n < 0:
+            raise _lib.ShfError(_lib.last_error())
+        return n
+
+    def detect_export(self, dst_ptr, cap_rows):
+        """Copy this image's rows to a device buffer (e.g. a torch tensor's data_ptr()); returns the row count."""
+        n = C.c_int(0)
+        _lib.check(self._lib.shf_detect_export(self._h, C.c_void_p(int(dst_ptr)), int(cap_rows), C.byref(n)),
+                   "detect_export")
+        return n.value
+
+    def detect_import(self, src_ptr, n_rows):
+        _lib.check(self._lib.shf_detect_import(self._h, C.c_void_p(int(src_ptr)), int(n_rows)), "detect_import")
+
     def detect_finish(self, method="BBOX_VOTE", nms_thresh=0.4, cap=None):
         m = {"BBOX_VOTE": 0, "NMS": 1}[method]
         cap = cap or 4096

@@ -128,8 +128,9 @@ struct Layer {
   int kclass = 0;
 };
 
-enum ProfClass { PC_CONV_MFMA, PC_CONV_FIRST, PC_CONV_DIRECT, PC_POOL, PC_DECONV, PC_TAIL, PC_MERGE, PC_LAYOUT, PC_COUNT };
-static const char* kProfNames[PC_COUNT] = {"conv_mfma_f32", "conv_first", "conv_direct", "maxpool",
+enum ProfClass { PC_CONV_MFMA, PC_CONV_MFMA_3x3_BN64, PC_CONV_MFMA_1x1_BN128, PC_CONV_MFMA_1x1_BN64, PC_CONV_FIRST, PC_CONV_DIRECT, PC_POOL, PC_DECONV, PC_TAIL, PC_MERGE, PC_LAYOUT, PC_COUNT };
+static const char* kProfNames[PC_COUNT] = {"conv_mfma_f32<3,128,8,16>", "conv_mfma_f32<3,64,16,16>",
+                                           "conv_mfma_f32<1,128,8,16>", "conv_mfma_f32<1,64,16,16>", "conv_first", "conv_direct", "maxpool",
                                            "deconv_depthwise", "detect_tail", "box_merge", "layout"};
 
 struct Prof {
@@ -881,7 +882,9 @@ void shf_net::forward_ops(bool fused_path, float im_h, float im_w, float im_scal
         } else {
           a.in = view_of(L.bottoms[0]);
           if (L.kclass == 0) {
-            ProfScope ps(prof, stream, PC_CONV_MFMA, fl, by);
+            const int pc = (L.k == 3) ? (L.nout % 128 == 0 ? PC_CONV_MFMA : PC_CONV_MFMA_3x3_BN64)
+                                      : (L.nout % 128 == 0 ? PC_CONV_MFMA_1x1_BN128 : PC_CONV_MFMA_1x1_BN64);
+            ProfScope ps(prof, stream, pc, fl, by);
             CHECK_RC(launch_conv_mfma(a, stream));
           } else {
             ProfScope ps(prof, stream, PC_CONV_DIRECT, fl, by);
@@ -1210,6 +1213,48 @@ int shf_detect_count(shf_net* net) {
   HIP_THROW(hipMemcpyAsync(c, net->img_count.p, 8, hipMemcpyDeviceToHost, net->stream));
   HIP_THROW(hipStreamSynchronize(net->stream));
   return c[net->img_units & 1];
+  API_END(-1)
+}
+
+int shf_detect_export(shf_net* net, float* dst_dev5, int cap_rows, int* n_rows) {
+  API_BEGIN
+  const int n = shf_detect_count(net);
+  if (n < 0) return -1;
+  *n_rows = n;
+  const int w = std::min(n, cap_rows);
+  if (w > 0) {
+    HIP_THROW(hipMemcpyAsync(dst_dev5, net->img_dets.p, (size_t)w * 5 * 4, hipMemcpyDeviceToDevice, net->stream));
+    HIP_THROW(hipStreamSynchronize(net->stream));
+  }
+  return 0;
+  API_END(-1)
+}
+
+int shf_detect_import(shf_net* net, const float* src_dev5, int n_rows) {
+  API_BEGIN
+  if (n_rows <= 0) return 0;
+  const int have = shf_detect_count(net);
+  if (have < 0) return -1;
+  const int need = have + n_rows;
+  if (need > net->img_cap) {
+    const int ncap = std::max(need, net->img_cap * 2);
+    DevBuf nd, nk;
+    nd.ensure((size_t)ncap * 5 * 4);
+    size_t npad = 1;
+    while (npad < (size_t)ncap) npad <<= 1;
+    nk.ensure(npad * 8);
+    if (net->img_dets.p && have > 0)
+      HIP_THROW(hipMemcpy(nd.p, net->img_dets.p, (size_t)have * 5 * 4, hipMemcpyDeviceToDevice));
+    std::swap(net->img_dets.p, nd.p); std::swap(net->img_dets.cap, nd.cap);
+    std::swap(net->img_keys.p, nk.p); std::swap(net->img_keys.cap, nk.cap);
+    net->img_cap = ncap;
+  }
+  HIP_THROW(hipMemcpyAsync((float*)net->img_dets.p + (size_t)have * 5, src_dev5, (size_t)n_rows * 5 * 4,
+                           hipMemcpyDeviceToDevice, net->stream));
+  int c[2] = {need, need};
+  HIP_THROW(hipMemcpyAsync(net->img_count.p, c, 8, hipMemcpyHostToDevice, net->stream));
+  HIP_THROW(hipStreamSynchronize(net->stream));
+  return 0;
   API_END(-1)
 }
 
