@@ -82,6 +82,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-events", action="store_true", help="do not record per-launch HIP events")
     ap.add_argument("--method", default=None, help="BBOX_VOTE (default, the reference's) or NMS")
+    ap.add_argument("--lanes", type=int, default=5, help="execution lanes (HIP streams) per GPU in --mode streams")
+    ap.add_argument("--mode", default="group", choices=["group", "streams"],
+                    help="group: one grid per conv layer over all units of the image; streams: units on HIP streams")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -133,23 +136,39 @@ def main():
     thresh = 0.05
     last = {}
 
+    from smallhardface_amd.test import FusedDetector
+    fd = FusedDetector(net, n_lanes=(n_units if args.mode == 'group' else args.lanes), mode=args.mode)
+    lanes = fd.lanes
+    if world == 1:
+        unit_list = [(units[(0, u)][0].data_ptr(),) + units[(0, u)][1:] for u in range(n_units)]
+
     def step():
         if world == 1:
-            net.detect_begin()
-            for u in range(n_units):
-                t, H, W, im_h, im_w, s, flip = units[(0, u)]
-                net.detect_add_level(t.data_ptr(), H, W, im_h, im_w, s, flip, thresh, on_device=True)
-            last[0] = net.detect_finish(cfg.TEST.NMS_METHOD, cfg.TEST.NMS_THRESH)
+            last[0] = fd.detect(unit_list, thresh, on_device=True)[0]
             return
         local = {}
-        for i in range(world):
-            net.detect_begin()
+        pending = {}  # lane index -> window image whose units are in flight on it
+
+        def flush(k):
+            j = pending.pop(k)
+            n = lanes[k].detect_export(export[j].data_ptr(), exp_cap)
+            local[j] = export[j][:min(n, exp_cap)]
+
+        # heaviest images first; up to len(lanes) images in flight
+        cost = lambda i: sum(v[1] * v[2] for (ii, _), v in units.items() if ii == i)
+        for i in sorted(range(world), key=lambda i: -cost(i)):
+            k = min(range(len(lanes)), key=lambda q: (q in pending, q))
+            if k in pending:
+                k = next(iter(pending))
+                flush(k)
+            lanes[k].detect_begin()
             for u in range(n_units):
                 if (i, u) in units:
                     t, H, W, im_h, im_w, s, flip = units[(i, u)]
-                    net.detect_add_level(t.data_ptr(), H, W, im_h, im_w, s, flip, thresh, on_device=True)
-            n = net.detect_export(export[i].data_ptr(), exp_cap)
-            local[i] = export[i][:min(n, exp_cap)]
+                    lanes[k].detect_add_level(t.data_ptr(), H, W, im_h, im_w, s, flip, thresh, on_device=True)
+            pending[k] = i
+        for k in list(pending):
+            flush(k)
         got = pyramid.gather_window(local, world, rank, world, device=dev)
         torch.cuda.synchronize()
         for i, t in got.items():
@@ -159,7 +178,8 @@ def main():
             last[i] = net.detect_finish(cfg.TEST.NMS_METHOD, cfg.TEST.NMS_THRESH)
 
     def fence():
-        net.sync()
+        for ln in lanes:
+            ln.sync()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -169,15 +189,22 @@ def main():
         step()
     fence()
     if not args.no_events:
-        net.prof_enable(True)
-        net.prof_reset()
+        for ln in lanes:
+            ln.prof_enable(True)
+            ln.prof_reset()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     fence()
     elapsed = time.perf_counter() - t0
-    prof = net.prof_read() if not args.no_events else {}
-    net.prof_enable(False)
+    prof = {}
+    if not args.no_events:
+        for ln in lanes:
+            for k, v in ln.prof_read().items():
+                a = prof.setdefault(k, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
+                for f in a:
+                    a[f] += v[f]
+            ln.prof_enable(False)
     if dist is not None:
         te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
@@ -196,7 +223,7 @@ def main():
                             "[100,300,600,1000,1400] -> padded 112/304/608/1008/1408, x flip = 10 units/image "
                             "(5021.6 GFLOP), VGG-16 + shared-weight dilated heads (different_dilation + dim_red), "
                             "fp32, proposal tail + >0.05 cut + %s on device" % cfg.TEST.NMS_METHOD,
-                "images_per_step": world, "units_per_image": n_units, "parallelism":
+                "images_per_step": world, "units_per_image": n_units, "lanes_per_gpu": len(lanes), "unit_execution": args.mode, "parallelism":
                     "pyramid units sharded 1-of-each-kind per GPU per window; RCCL all_gather of detections to the "
                     "image's owner rank" if world > 1 else "single GPU",
                 "weights": "seeded synthetic (no trained caffemodel exists in the reference tree)",

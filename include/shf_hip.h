@@ -36,6 +36,10 @@ const char* shf_version(void);
  * then zero until set through shf_net_param_*).  phase: 1 = TEST. */
 shf_net* shf_net_create(const char* prototxt_path, const char* prototxt_text,
                         const char* caffemodel_path, int phase);
+/* Execution lane: a second net over the SAME parameter tensors (Net::ShareTrainedLayersWith,
+ * net.cpp:665-685) with its own activations, workspace and HIP stream, so independent
+ * pyramid units overlap on the GPU.  Destroy lanes before the net they were cloned from. */
+shf_net* shf_net_clone(shf_net* src);
 void shf_net_destroy(shf_net* net);
 
 /* Net._blob_names / Net._inputs / Net._outputs          _caffe.cpp:432-440 */
@@ -85,6 +89,15 @@ int shf_detect_begin(shf_net* net);
  * appended to the image's device-side list (test.py:52-54,59-66,163-167). */
 int shf_detect_add_level(shf_net* net, const float* data, int data_on_device,
                          int H, int W, int im_h, int im_w, float im_scale, int flip, float thresh);
+/* The same for a GROUP of units at once (the whole pyramid of an image): every MFMA conv
+ * layer runs as ONE grid over all units (they share the layer's weights, not the spatial
+ * size), so the small levels do not serialise latency-bound launches.  members[i] supplies
+ * the activation buffers of unit i: `net` itself and/or lanes made with shf_net_clone, all
+ * distinct; the work is enqueued on `net`'s stream and the detections land in `net`'s image
+ * list in unit order. */
+int shf_detect_add_levels(shf_net* net, int n, shf_net** members, const float* const* data,
+                          int data_on_device, const int* H, const int* W, const int* im_h,
+                          const int* im_w, const float* im_scale, const int* flip, float thresh);
 /* Box merging for the image (test.py:168-175): method 0 = BBOX_VOTE (test.py:181),
  * 1 = NMS (lib/nms).  out5 rows are (x1,y1,x2,y2,score) as double (bbox_vote
  * returns float64).  *n_out = number of rows (may exceed cap; only cap written). */

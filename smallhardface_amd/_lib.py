@@ -65,6 +65,7 @@ def _declare(lib):
         "shf_last_error": (C.c_char_p, []),
         "shf_version": (C.c_char_p, []),
         "shf_net_create": (vp, [C.c_char_p, C.c_char_p, C.c_char_p, ci]),
+        "shf_net_clone": (vp, [vp]),
         "shf_net_destroy": (None, [vp]),
         "shf_net_num_blobs": (ci, [vp]),
         "shf_net_blob_name": (C.c_char_p, [vp, ci]),
@@ -86,6 +87,7 @@ def _declare(lib):
         "shf_net_set_proposal_cfg": (ci, [vp, ci, cf, cf]),
         "shf_detect_begin": (ci, [vp]),
         "shf_detect_add_level": (ci, [vp, vp, ci, ci, ci, ci, ci, cf, ci, cf]),
+        "shf_detect_add_levels": (ci, [vp, ci, C.POINTER(vp), C.POINTER(vp), ci, ip, ip, ip, ip, fp, ip, cf]),
         "shf_detect_finish": (ci, [vp, ci, cf, dp, ci, ip]),
         "shf_detect_count": (ci, [vp]),
         "shf_detect_export": (ci, [vp, vp, ci, ip]),

@@ -138,6 +138,21 @@ class Net(object):
         self._dirty_layers = set()
         self._apply_cfg()
 
+    def clone(self):
+        """A lane: same parameter tensors, own activations / workspace / HIP stream
+        (cf. Net::ShareTrainedLayersWith).  Keep ``self`` alive while the lane is used."""
+        self.commit_params()
+        h = self._lib.shf_net_clone(self._h)
+        if not h:
+            raise RuntimeError(_lib.last_error())
+        lane = Net.__new__(Net)
+        lane._lib, lane._h, lane._parent = self._lib, h, self
+        for k in ("_blob_names", "_inputs", "_outputs", "_layer_names", "_layer_types"):
+            setattr(lane, k, getattr(self, k))
+        lane._blobs = [Blob(lane, i, n) for i, n in enumerate(lane._blob_names)]
+        lane._dirty_layers = set()
+        return lane
+
     def _apply_cfg(self):
         # the reference's Python layer reads these from the global cfg at forward time
         from ..config import cfg
@@ -238,6 +253,26 @@ class Net(object):
         _lib.check(self._lib.shf_detect_add_level(self._h, ptr, 1 if on_device else 0, int(H), int(W), int(im_h),
                                                   int(im_w), float(im_scale), 1 if flip else 0, float(thresh)),
                    "detect_add_level")
+
+    def detect_add_levels(self, members, units, thresh, on_device=False):
+        """One grouped pass over several units (C ABI shf_detect_add_levels).  ``members``: distinct
+        nets (self and/or lanes) lending their activation buffers, one per unit."""
+        n = len(units)
+        keep = []
+        ptrs = (C.c_void_p * n)()
+        for i, u in enumerate(units):
+            if on_device:
+                ptrs[i] = int(u[0])
+            else:
+                a = np.ascontiguousarray(u[0], dtype=np.float32)
+                keep.append(a)
+                ptrs[i] = a.ctypes.data
+        mem = (C.c_void_p * n)(*[m._h for m in members[:n]])
+        ia = lambda k: (C.c_int * n)(*[int(u[k]) for u in units])
+        sc = (C.c_float * n)(*[float(u[5]) for u in units])
+        fl = (C.c_int * n)(*[1 if u[6] else 0 for u in units])
+        _lib.check(self._lib.shf_detect_add_levels(self._h, n, mem, ptrs, 1 if on_device else 0, ia(1), ia(2),
+                                                   ia(3), ia(4), sc, fl, float(thresh)), "detect_add_levels")
 
     def detect_count(self):
         n = self._lib.shf_detect_count(self._h)

@@ -24,15 +24,27 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int KC = 32;   // input channels per K chunk
 constexpr int LDK = 36;  // LDS row pitch in floats (32 + 4 pad: conflict-free ds_read_b128)
 
-struct ConvK {
+constexpr int MAX_GROUP = 16;
+
+// One launch covers a GROUP of independent problems that share the layer (weights,
+// channels, dilation) but not the spatial size: the 10 (level, flip) units of an image's
+// test pyramid go through each conv layer in ONE grid, so the latency-bound small levels
+// ride along with the large ones instead of paying a whole K loop on a mostly idle chip.
+struct ConvMember {
   const float* in;   // already offset to the view's first channel
+  float* out;        // already offset to the view's first channel
+  int B, H, W;
+  int tiles_x, tiles_per_img, tile_start;  // tile_start: first pixel-tile index of this member
+};
+
+struct ConvK {
   const float* wp;   // packed weights
   const float* bias;
-  float* out;        // already offset to the view's first channel
-  int B, H, W, Cin, Cout;
+  int Cin, Cout;
   int in_stride, out_stride;
   int dil, relu;
-  int tiles_x, tiles_y, nct;
+  int nct, nmem;
+  ConvMember m[MAX_GROUP];
 };
 
 // row i (0..31) of a 32-row MFMA tile -> pixel inside the wave's 2x16 strip.
@@ -61,10 +73,18 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_f32_kernel(ConvK p) {
   const int bid = blockIdx.x;
   const int ct = bid % p.nct;
   int pt = bid / p.nct;
-  const int tpi = p.tiles_x * p.tiles_y;
-  const int b = pt / tpi;
-  pt -= b * tpi;
-  const int ty0 = (pt / p.tiles_x) * TH, tx0 = (pt % p.tiles_x) * TW;
+  int mi = 0;
+#pragma unroll 1
+  for (int q = 1; q < p.nmem; ++q)
+    if (pt >= p.m[q].tile_start) mi = q;
+  const ConvMember& mem = p.m[mi];
+  pt -= mem.tile_start;
+  const int b = pt / mem.tiles_per_img;
+  pt -= b * mem.tiles_per_img;
+  const int ty0 = (pt / mem.tiles_x) * TH, tx0 = (pt % mem.tiles_x) * TW;
+  const int H = mem.H, W = mem.W;
+  const float* __restrict__ gin = mem.in;
+  float* __restrict__ gout = mem.out;
 
   const int i = lane & 31, kh = lane >> 5;
   int dy, px;
@@ -99,14 +119,14 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_f32_kernel(ConvK p) {
   for (int s = 0; s < S; ++s) {
     const int c = s / TAPS, tap = s - c * TAPS;
     if (tap == 0) {
-      const float* inc = p.in + c * KC;
+      const float* inc = gin + c * KC;
       for (int idx = tid; idx < HP * 8; idx += 256) {
         const int hp = idx >> 3, q = idx & 7;
         const int hy = hp / HTW, hx = hp - hy * HTW;
         const int gy = ty0 - pad + hy, gx = tx0 - pad + hx;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if ((unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W)
-          v = *(const float4*)(inc + ((size_t)(b * p.H + gy) * p.W + gx) * p.in_stride + q * 4);
+        if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W)
+          v = *(const float4*)(inc + ((size_t)(b * H + gy) * W + gx) * p.in_stride + q * 4);
         *(float4*)(As + hp * LDK + q * 4) = v;
       }
     }
@@ -154,10 +174,10 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_f32_kernel(ConvK p) {
         int dy2, px2;
         row_to_pixel(row, dy2, px2);
         const int gy = ty0 + wm * 4 + tm * 2 + dy2, gx = tx0 + px2;
-        if (gy < p.H && gx < p.W) {
+        if (gy < H && gx < W) {
           float v = acc[tm][tn][r] + bv;
           if (p.relu) v = fmaxf(v, 0.f);
-          p.out[((size_t)(b * p.H + gy) * p.W + gx) * p.out_stride + cout] = v;
+          gout[((size_t)(b * H + gy) * W + gx) * p.out_stride + cout] = v;
         }
       }
     }
@@ -273,19 +293,36 @@ static size_t mfma_lds_bytes(int k, int dil, int BN, int TH, int TW) {
 }
 
 template <int KS, int BN, int TH, int TW>
-static int launch_mfma_t(const ConvArgs& a, hipStream_t s) {
+static int launch_mfma_t(const ConvArgs* as, int n, hipStream_t s) {
+  const ConvArgs& a = as[0];
   ConvK p;
-  p.in = a.in.p + a.in.coff;
   p.wp = a.wpacked;
   p.bias = a.bias;
-  p.out = a.out.p + a.out.coff;
-  p.B = a.in.B; p.H = a.in.H; p.W = a.in.W; p.Cin = a.in.C; p.Cout = a.out.C;
+  p.Cin = a.in.C; p.Cout = a.out.C;
   p.in_stride = a.in.cstride; p.out_stride = a.out.cstride;
   p.dil = a.dil; p.relu = a.relu;
-  p.tiles_x = (p.W + TW - 1) / TW; p.tiles_y = (p.H + TH - 1) / TH; p.nct = p.Cout / BN;
+  p.nct = p.Cout / BN;
+  p.nmem = n;
+  long long tiles = 0;
+  for (int i = 0; i < n; ++i) {
+    const ConvArgs& q = as[i];
+    if (q.in.C != p.Cin || q.out.C != p.Cout || q.in.cstride != p.in_stride || q.out.cstride != p.out_stride ||
+        q.dil != p.dil || q.wpacked != p.wp) {
+      set_error("conv group: members must share the layer");
+      return -1;
+    }
+    ConvMember& m = p.m[i];
+    m.in = q.in.p + q.in.coff;
+    m.out = q.out.p + q.out.coff;
+    m.B = q.in.B; m.H = q.in.H; m.W = q.in.W;
+    m.tiles_x = (m.W + TW - 1) / TW;
+    m.tiles_per_img = m.tiles_x * ((m.H + TH - 1) / TH);
+    m.tile_start = (int)tiles;
+    tiles += (long long)m.tiles_per_img * m.B;
+  }
   const size_t lds = mfma_lds_bytes(KS, a.dil, BN, TH, TW);
   if (lds > 160 * 1024) { set_error("conv: dilation too large for the LDS halo tile"); return -1; }
-  const long long blocks = (long long)p.tiles_x * p.tiles_y * p.B * p.nct;
+  const long long blocks = tiles * p.nct;
   hipLaunchKernelGGL((conv_mfma_f32_kernel<KS, BN, TH, TW>), dim3((unsigned)blocks), dim3(256), lds, s, p);
   SHF_HIP_OK(hipGetLastError());
   return 0;
@@ -304,12 +341,17 @@ int conv_init_attributes() {
   return 0;
 }
 
-int launch_conv_mfma(const ConvArgs& a, hipStream_t s) {
-  if ((a.in.cstride % 4) || (a.in.coff % 4)) { set_error("conv: input view not 16-byte aligned"); return -1; }
+int launch_conv_mfma_group(const ConvArgs* as, int n, hipStream_t s) {
+  if (n < 1 || n > MAX_GROUP) { set_error("conv group: 1..16 members"); return -1; }
+  for (int i = 0; i < n; ++i)
+    if ((as[i].in.cstride % 4) || (as[i].in.coff % 4)) { set_error("conv: input view not 16-byte aligned"); return -1; }
+  const ConvArgs& a = as[0];
   const bool bn128 = (a.out.C % 128 == 0);
-  if (a.k == 3) return bn128 ? launch_mfma_t<3, 128, 8, 16>(a, s) : launch_mfma_t<3, 64, 16, 16>(a, s);
-  return bn128 ? launch_mfma_t<1, 128, 8, 16>(a, s) : launch_mfma_t<1, 64, 16, 16>(a, s);
+  if (a.k == 3) return bn128 ? launch_mfma_t<3, 128, 8, 16>(as, n, s) : launch_mfma_t<3, 64, 16, 16>(as, n, s);
+  return bn128 ? launch_mfma_t<1, 128, 8, 16>(as, n, s) : launch_mfma_t<1, 64, 16, 16>(as, n, s);
 }
+
+int launch_conv_mfma(const ConvArgs& a, hipStream_t s) { return launch_conv_mfma_group(&a, 1, s); }
 
 int launch_conv_first(const float* in_nchw, const ConvArgs& a, hipStream_t s) {
   const int Cin = a.in.C, Cout = a.out.C;

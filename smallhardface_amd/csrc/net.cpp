@@ -358,6 +358,10 @@ struct shf_net {
   int feat_stride = 8;
   DevBuf tail_W, tail_b;
   bool tail_w_dirty = true;
+  std::string proto_text;
+  shf_net* clone_src = nullptr;     // lanes share the parameter tensors of the net they were cloned from
+  std::shared_ptr<int> wgen = std::make_shared<int>(0);  // bumped by every param commit
+  int tail_gen = -1;
   TailWork tw;
   DevBuf tw_logits, tw_rec, tw_keys, tw_counters;
   int pre_nms_topN = 10000;
@@ -406,7 +410,10 @@ struct shf_net {
   void alloc_buffers();
   void commit_params(int li);
   void build_tail_weights();
-  void forward_ops(bool fused_path, float im_h, float im_w, float im_scale);
+  void forward_ops(bool fused_path, float im_h, float im_w, float im_scale, hipStream_t s_override = nullptr,
+                   Prof* prof_override = nullptr, int only_layer = -1, ConvArgs* collect = nullptr);
+  void prepare_unit(const float* data, int data_on_device, int H, int W, hipStream_t st);
+  void ensure_img_cap(int units_after);
   void forward();
   float* host_data(int bi);
   void load_caffemodel(const std::string& path);
@@ -415,7 +422,8 @@ struct shf_net {
 static int geti(const PMsg* m, const char* n, int d) { return m ? (int)m->num(n, d) : d; }
 
 void shf_net::build(const std::string& text, const char* caffemodel) {
-  TextParser tp(text);
+  proto_text = text;
+  TextParser tp(proto_text);
   root = tp.parse();
   HIP_THROW(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
   CHECK_RC(conv_init_attributes());
@@ -674,7 +682,9 @@ void shf_net::build(const std::string& text, const char* caffemodel) {
     for (size_t pi = 0; pi < shapes.size(); ++pi) {
       std::string pname = (pi < pspecs.size() && pspecs[pi]->msg) ? pspecs[pi]->msg->str("name") : "";
       std::shared_ptr<ParamBlob> pb;
-      if (!pname.empty() && shared_params.count(pname)) {
+      if (clone_src) {
+        pb = clone_src->layers[li].params[pi];
+      } else if (!pname.empty() && shared_params.count(pname)) {
         pb = shared_params[pname];
         if (pb->shape != shapes[pi]) throw std::runtime_error("Shared parameter '" + pname + "' shape mismatch");
       } else {
@@ -689,6 +699,14 @@ void shf_net::build(const std::string& text, const char* caffemodel) {
       L.kclass = conv_kernel_class(cin, L.nout, L.k, L.pad, L.dil, blobs[L.bottoms[0]].kind == BK_INPUT_NCHW);
   }
   alloc_buffers();
+  if (clone_src) {
+    wgen = clone_src->wgen;
+    pre_nms_topN = clone_src->pre_nms_topN;
+    score_thresh = clone_src->score_thresh;
+    min_size = clone_src->min_size;
+    alloc_buffers();
+    return;
+  }
   if (caffemodel && caffemodel[0]) load_caffemodel(caffemodel);
   for (size_t li = 0; li < layers.size(); ++li) commit_params((int)li);
 }
@@ -811,6 +829,7 @@ void shf_net::build_tail_weights() {
   HIP_THROW(hipMemcpy(tail_W.p, W.data(), W.size() * 4, hipMemcpyHostToDevice));
   HIP_THROW(hipMemcpy(tail_b.p, B.data(), B.size() * 4, hipMemcpyHostToDevice));
   tail_w_dirty = false;
+  tail_gen = *wgen;
 }
 
 void shf_net::commit_params(int li) {
@@ -832,6 +851,7 @@ void shf_net::commit_params(int li) {
     p.dirty = false;
   }
   if (in_tail) tail_w_dirty = true;
+  ++*wgen;
 }
 
 void shf_net::load_caffemodel(const std::string& path) {
@@ -858,9 +878,13 @@ static double conv_flops(const Layer& L, const std::vector<int>& in, const std::
   return 2.0 * out[0] * out[2] * out[3] * (double)L.nout * in[1] * L.k * L.k;
 }
 
-void shf_net::forward_ops(bool fused_path, float im_h, float im_w, float im_scale) {
-  if (tail_w_dirty) build_tail_weights();
+void shf_net::forward_ops(bool fused_path, float im_h, float im_w, float im_scale, hipStream_t s_override,
+                          Prof* prof_override, int only_layer, ConvArgs* collect) {
+  if (tail_w_dirty || tail_gen != *wgen) build_tail_weights();
+  hipStream_t st = s_override ? s_override : stream;
+  Prof& pf = prof_override ? *prof_override : prof;
   for (size_t li = 0; li < layers.size(); ++li) {
+    if (only_layer >= 0 && (int)li != only_layer) continue;
     Layer& L = layers[li];
     switch (L.op) {
       case OP_SKIP: break;
@@ -877,33 +901,35 @@ void shf_net::forward_ops(bool fused_path, float im_h, float im_w, float im_scal
         if (L.kclass == 1) {
           a.in.B = ib.shape[0]; a.in.C = ib.shape[1]; a.in.H = ib.shape[2]; a.in.W = ib.shape[3];
           const float* src = ib.ext_dev ? ib.ext_dev : (const float*)ib.dev.p;
-          ProfScope ps(prof, stream, PC_CONV_FIRST, fl, by);
-          CHECK_RC(launch_conv_first(src, a, stream));
+          ProfScope ps(pf, st, PC_CONV_FIRST, fl, by);
+          CHECK_RC(launch_conv_first(src, a, st));
         } else {
           a.in = view_of(L.bottoms[0]);
-          if (L.kclass == 0) {
+          if (L.kclass == 0 && collect) {
+            *collect = a;  // grouped launch: the caller batches this layer over several units
+          } else if (L.kclass == 0) {
             const int pc = (L.k == 3) ? (L.nout % 128 == 0 ? PC_CONV_MFMA : PC_CONV_MFMA_3x3_BN64)
                                       : (L.nout % 128 == 0 ? PC_CONV_MFMA_1x1_BN128 : PC_CONV_MFMA_1x1_BN64);
-            ProfScope ps(prof, stream, pc, fl, by);
-            CHECK_RC(launch_conv_mfma(a, stream));
+            ProfScope ps(pf, st, pc, fl, by);
+            CHECK_RC(launch_conv_mfma(a, st));
           } else {
-            ProfScope ps(prof, stream, PC_CONV_DIRECT, fl, by);
-            CHECK_RC(launch_conv_direct(a, stream));
+            ProfScope ps(pf, st, PC_CONV_DIRECT, fl, by);
+            CHECK_RC(launch_conv_direct(a, st));
           }
         }
         break;
       }
       case OP_POOL: {
-        ProfScope ps(prof, stream, PC_POOL, 0, 4.0 * (blobs[L.bottoms[0]].count() + blobs[L.tops[0]].count()));
-        CHECK_RC(launch_maxpool(view_of(L.bottoms[0]), view_of(L.tops[0]), L.k, L.stride, L.pad, stream));
+        ProfScope ps(pf, st, PC_POOL, 0, 4.0 * (blobs[L.bottoms[0]].count() + blobs[L.tops[0]].count()));
+        CHECK_RC(launch_maxpool(view_of(L.bottoms[0]), view_of(L.tops[0]), L.k, L.stride, L.pad, st));
         break;
       }
       case OP_DECONV: {
-        ProfScope ps(prof, stream, PC_DECONV, 2.0 * blobs[L.tops[0]].count() * 4,
+        ProfScope ps(pf, st, PC_DECONV, 2.0 * blobs[L.tops[0]].count() * 4,
                      4.0 * (blobs[L.bottoms[0]].count() + blobs[L.tops[0]].count()));
         CHECK_RC(launch_deconv_depthwise(view_of(L.bottoms[0]), view_of(L.tops[0]), (const float*)L.params[0]->raw.p,
                                          L.params.size() > 1 ? (const float*)L.params[1]->raw.p : nullptr, L.k,
-                                         L.stride, L.pad, stream));
+                                         L.stride, L.pad, st));
         break;
       }
       case OP_TAIL: {
@@ -924,10 +950,10 @@ void shf_net::forward_ops(bool fused_path, float im_h, float im_w, float im_scal
           t.bbox_pred_nchw = (float*)blobs[tail_box_blob].dev.p;
         }
         const double K = (double)t.h * t.w;
-        ProfScope ps(prof, stream, PC_TAIL, 2.0 * K * tail_A * 6 * tail_Cf,
+        ProfScope ps(pf, st, PC_TAIL, 2.0 * K * tail_A * 6 * tail_Cf,
                      4.0 * K * (tail_heads * tail_Cf + tail_A * 18));
         CHECK_RC(launch_tail(t, tw, (float*)blobs[boxes_blob].dev.p,
-                             prob_blob >= 0 ? (float*)blobs[prob_blob].dev.p : (float*)tw_rec.p, stream));
+                             prob_blob >= 0 ? (float*)blobs[prob_blob].dev.p : (float*)tw_rec.p, st));
         break;
       }
     }
@@ -1054,6 +1080,17 @@ shf_net* shf_net_create(const char* prototxt_path, const char* prototxt_text, co
   API_END(nullptr)
 }
 
+shf_net* shf_net_clone(shf_net* src) {
+  API_BEGIN
+  std::unique_ptr<shf_net> net(new shf_net());
+  net->phase = src->phase;
+  net->clone_src = src;
+  net->build(src->proto_text, nullptr);
+  net->clone_src = nullptr;
+  return net.release();
+  API_END(nullptr)
+}
+
 void shf_net_destroy(shf_net* net) { delete net; }
 
 int shf_net_num_blobs(shf_net* net) { return (int)net->blobs.size(); }
@@ -1155,54 +1192,108 @@ int shf_detect_begin(shf_net* net) {
   API_END(-1)
 }
 
-int shf_detect_add_level(shf_net* net, const float* data, int data_on_device, int H, int W, int im_h, int im_w,
-                         float im_scale, int flip, float thresh) {
-  API_BEGIN
-  Blob& d = net->blobs[net->data_blob];
+void shf_net::prepare_unit(const float* data, int data_on_device, int H, int W, hipStream_t st) {
+  Blob& d = blobs[data_blob];
   std::vector<int> shp = {1, d.shape.size() == 4 ? d.shape[1] : 3, H, W};
   if (shp != d.shape) d.shape = shp;
-  if (d.shape != net->last_data_shape) {
-    net->infer_shapes();
-    net->alloc_buffers();
+  if (d.shape != last_data_shape) {
+    infer_shapes();
+    alloc_buffers();
   }
   if (data_on_device) {
     d.ext_dev = data;
   } else {
     d.ext_dev = nullptr;
     d.dev.ensure(d.count() * 4);
-    HIP_THROW(hipMemcpyAsync(d.dev.p, data, d.count() * 4, hipMemcpyHostToDevice, net->stream));
+    HIP_THROW(hipMemcpyAsync(d.dev.p, data, d.count() * 4, hipMemcpyHostToDevice, st));
   }
-  net->forward_ops(true, (float)im_h, (float)im_w, im_scale);
-  d.ext_dev = nullptr;
-  // room for every unit's top-N
-  const int rmax = net->pre_nms_topN > 0 ? net->pre_nms_topN : (int)net->tw.cap_anchors;
-  const int need = (net->img_units + 1) * rmax;
-  if (need > net->img_cap) {
-    // grow geometrically; keep what is already gathered
-    int ncap = std::max(need, std::max(net->img_cap * 2, 16 * rmax));
-    DevBuf nd, nk;
-    nd.ensure((size_t)ncap * 5 * 4);
-    size_t npad = 1;
-    while (npad < (size_t)ncap) npad <<= 1;
-    nk.ensure(npad * 8);
-    if (net->img_dets.p) {
-      HIP_THROW(hipMemcpyAsync(nd.p, net->img_dets.p, (size_t)net->img_cap * 5 * 4, hipMemcpyDeviceToDevice, net->stream));
-      HIP_THROW(hipMemcpyAsync(nk.p, net->img_keys.p, (size_t)net->img_cap * 8, hipMemcpyDeviceToDevice, net->stream));
-      HIP_THROW(hipStreamSynchronize(net->stream));
-    }
-    std::swap(net->img_dets.p, nd.p); std::swap(net->img_dets.cap, nd.cap);
-    std::swap(net->img_keys.p, nk.p); std::swap(net->img_keys.cap, nk.cap);
-    net->img_cap = ncap;
+}
+
+void shf_net::ensure_img_cap(int units_after) {
+  const int rmax = pre_nms_topN > 0 ? pre_nms_topN : (int)tw.cap_anchors;
+  const int need = units_after * rmax;
+  if (need <= img_cap) return;
+  // grow geometrically; keep what is already gathered
+  const int ncap = std::max(need, std::max(img_cap * 2, 16 * rmax));
+  DevBuf nd, nk;
+  nd.ensure((size_t)ncap * 5 * 4);
+  size_t npad = 1;
+  while (npad < (size_t)ncap) npad <<= 1;
+  nk.ensure(npad * 8);
+  if (img_dets.p) {
+    HIP_THROW(hipMemcpyAsync(nd.p, img_dets.p, (size_t)img_cap * 5 * 4, hipMemcpyDeviceToDevice, stream));
+    HIP_THROW(hipMemcpyAsync(nk.p, img_keys.p, (size_t)img_cap * 8, hipMemcpyDeviceToDevice, stream));
+    HIP_THROW(hipStreamSynchronize(stream));
   }
-  {
-    ProfScope ps(net->prof, net->stream, PC_TAIL, 0, 0);
-    CHECK_RC(launch_append_dets((float*)net->blobs[net->boxes_blob].dev.p,
-                                net->prob_blob >= 0 ? (float*)net->blobs[net->prob_blob].dev.p : (float*)net->tw_rec.p,
-                                net->tw.counters + 2, rmax, (float)im_w, im_scale, flip, thresh, net->img_units,
-                                (float*)net->img_dets.p, (unsigned long long*)net->img_keys.p,
-                                (int*)net->img_count.p, net->img_cap, net->stream));
-  }
+  std::swap(img_dets.p, nd.p); std::swap(img_dets.cap, nd.cap);
+  std::swap(img_keys.p, nk.p); std::swap(img_keys.cap, nk.cap);
+  img_cap = ncap;
+}
+
+// append one finished unit (whose proposals sit in `src`'s output blobs) to `net`'s image list
+static void append_unit(shf_net* net, shf_net* src, int im_w, float im_scale, int flip, float thresh) {
+  net->ensure_img_cap(net->img_units + 1);
+  const int rmax = src->pre_nms_topN > 0 ? src->pre_nms_topN : (int)src->tw.cap_anchors;
+  ProfScope ps(net->prof, net->stream, PC_TAIL, 0, 0);
+  CHECK_RC(launch_append_dets((float*)src->blobs[src->boxes_blob].dev.p,
+                              src->prob_blob >= 0 ? (float*)src->blobs[src->prob_blob].dev.p : (float*)src->tw_rec.p,
+                              src->tw.counters + 2, rmax, (float)im_w, im_scale, flip, thresh, net->img_units,
+                              (float*)net->img_dets.p, (unsigned long long*)net->img_keys.p,
+                              (int*)net->img_count.p, net->img_cap, net->stream));
   net->img_units++;
+}
+
+int shf_detect_add_level(shf_net* net, const float* data, int data_on_device, int H, int W, int im_h, int im_w,
+                         float im_scale, int flip, float thresh) {
+  API_BEGIN
+  net->prepare_unit(data, data_on_device, H, W, net->stream);
+  net->forward_ops(true, (float)im_h, (float)im_w, im_scale);
+  net->blobs[net->data_blob].ext_dev = nullptr;
+  append_unit(net, net, im_w, im_scale, flip, thresh);
+  return 0;
+  API_END(-1)
+}
+
+int shf_detect_add_levels(shf_net* net, int n, shf_net** members, const float* const* data, int data_on_device,
+                          const int* H, const int* W, const int* im_h, const int* im_w, const float* im_scale,
+                          const int* flip, float thresh) {
+  API_BEGIN
+  if (n < 1 || n > 16) throw std::runtime_error("detect_add_levels: 1..16 units per group");
+  for (int m = 0; m < n; ++m) {
+    for (int q = 0; q < m; ++q)
+      if (members[q] == members[m]) throw std::runtime_error("detect_add_levels: members must be distinct nets");
+    if (members[m]->layers.size() != net->layers.size())
+      throw std::runtime_error("detect_add_levels: members must be lanes of the same net");
+    members[m]->prepare_unit(data[m], data_on_device, H[m], W[m], net->stream);
+  }
+  std::vector<ConvArgs> group(n);
+  for (size_t li = 0; li < net->layers.size(); ++li) {
+    Layer& L = net->layers[li];
+    if (L.op == OP_SKIP) continue;
+    if (L.op == OP_CONV && L.kclass == 0) {
+      double fl = 0, by = 4.0 * L.params[0]->count();
+      for (int m = 0; m < n; ++m) {
+        shf_net* mb = members[m];
+        mb->forward_ops(true, (float)im_h[m], (float)im_w[m], im_scale[m], net->stream, &net->prof, (int)li,
+                        &group[m]);
+        fl += conv_flops(mb->layers[li], mb->blobs[mb->layers[li].bottoms[0]].shape,
+                         mb->blobs[mb->layers[li].tops[0]].shape);
+        by += 4.0 * (mb->blobs[mb->layers[li].bottoms[0]].count() + mb->blobs[mb->layers[li].tops[0]].count());
+      }
+      const int pc = (L.k == 3) ? (L.nout % 128 == 0 ? PC_CONV_MFMA : PC_CONV_MFMA_3x3_BN64)
+                                : (L.nout % 128 == 0 ? PC_CONV_MFMA_1x1_BN128 : PC_CONV_MFMA_1x1_BN64);
+      ProfScope ps(net->prof, net->stream, pc, fl, by);
+      CHECK_RC(launch_conv_mfma_group(group.data(), n, net->stream));
+    } else {
+      for (int m = 0; m < n; ++m)
+        members[m]->forward_ops(true, (float)im_h[m], (float)im_w[m], im_scale[m], net->stream, &net->prof, (int)li,
+                                nullptr);
+    }
+  }
+  for (int m = 0; m < n; ++m) {
+    members[m]->blobs[members[m]->data_blob].ext_dev = nullptr;
+    append_unit(net, members[m], im_w[m], im_scale[m], flip[m], thresh);
+  }
   return 0;
   API_END(-1)
 }

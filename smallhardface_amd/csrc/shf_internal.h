@@ -36,6 +36,8 @@ struct ConvArgs {
 // which kernel class a conv will use: 0 = mfma implicit GEMM, 1 = first-layer direct (NCHW in), 2 = generic direct
 int conv_kernel_class(int Cin, int Cout, int k, int pad, int dil, bool in_nchw);
 int launch_conv_mfma(const ConvArgs& a, hipStream_t s);
+// one grid over up to 16 problems that share the layer (weights/channels) but not H x W
+int launch_conv_mfma_group(const ConvArgs* as, int n, hipStream_t s);
 // first layer: input is the NCHW 'data' blob (B,Cin,H,W), Cin <= 8, Cout % 16 == 0
 int launch_conv_first(const float* in_nchw, const ConvArgs& a, hipStream_t s);
 int launch_conv_direct(const ConvArgs& a, hipStream_t s);

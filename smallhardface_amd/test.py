@@ -162,9 +162,75 @@ def pyramid_units(im, scales=None):
             yield np.ascontiguousarray(d, dtype=np.float32), nh, nw, h, w, s, flip
 
 
+def lane_ranges(costs, n_lanes):
+    """Split the unit sequence into ``n_lanes`` CONTIGUOUS ranges of roughly equal cost
+    (contiguous so that concatenating the lanes' detection lists in lane order is the
+    reference's unit order, test.py:141-158)."""
+    n_lanes = max(1, min(n_lanes, len(costs)))
+    total = float(sum(costs))
+    ranges, start, acc = [], 0, 0.0
+    for i, c in enumerate(costs):
+        acc += c
+        left_units = len(costs) - (i + 1)
+        left_lanes = n_lanes - len(ranges) - 1
+        if left_lanes > 0 and (acc >= total * (len(ranges) + 1) / n_lanes or left_units == left_lanes):
+            ranges.append((start, i + 1))
+            start = i + 1
+    ranges.append((start, len(costs)))
+    return ranges
+
+
+class FusedDetector(object):
+    """detect() with every per-unit step on the device (C ABI shf_detect_*), the units of an
+    image spread over execution lanes (own HIP stream + activations, shared weights) so the
+    latency-bound small pyramid levels overlap with the large ones."""
+
+    def __init__(self, net, n_lanes=4, mode="streams"):
+        """mode "streams": units spread over lanes running on their own HIP streams;
+        mode "group": the lanes only lend activation buffers and every MFMA conv layer runs as
+        ONE grid over all units of the image (shf_detect_add_levels)."""
+        self.net = net
+        self.mode = mode
+        self.lanes = [net] + [net.clone() for _ in range(max(1, n_lanes) - 1)]
+        self._xbuf = None
+
+    def detect(self, units, thresh=0.05, on_device=False):
+        """``units``: list of (data, H, W, im_h, im_w, scale, flip); data = host array or device pointer."""
+        units = list(units)
+        if self.mode == "group":
+            while len(self.lanes) < min(len(units), 16):
+                self.lanes.append(self.net.clone())
+            head = self.lanes[0]
+            head.detect_begin()
+            for a in range(0, len(units), 16):
+                chunk = units[a:a + 16]
+                head.detect_add_levels(self.lanes[:len(chunk)], chunk, thresh, on_device=on_device)
+            return [head.detect_finish(cfg.TEST.NMS_METHOD, cfg.TEST.NMS_THRESH)]
+        ranges = lane_ranges([u[1] * u[2] for u in units], len(self.lanes))
+        used = []
+        # issue the most expensive ranges first
+        order = sorted(range(len(ranges)), key=lambda k: -sum(u[1] * u[2] for u in units[ranges[k][0]:ranges[k][1]]))
+        for k in range(len(ranges)):
+            self.lanes[k].detect_begin()
+        for k in order:
+            a, b = ranges[k]
+            for data, H, W, im_h, im_w, s, flip in units[a:b]:
+                self.lanes[k].detect_add_level(data, H, W, im_h, im_w, s, flip, thresh, on_device=on_device)
+            used.append(k)
+        head = self.lanes[0]
+        if len(ranges) > 1:
+            import torch  # device staging buffer for the lane -> lane hand-off
+            cap = sum(cfg.TEST.N_DETS_PER_MODULE for _ in units)
+            if self._xbuf is None or self._xbuf.shape[0] < cap:
+                self._xbuf = torch.empty((cap, 5), dtype=torch.float32, device="cuda")
+            for k in range(1, len(ranges)):
+                n = self.lanes[k].detect_export(self._xbuf.data_ptr(), cap)
+                head.detect_import(self._xbuf.data_ptr(), min(n, cap))
+        return [head.detect_finish(cfg.TEST.NMS_METHOD, cfg.TEST.NMS_THRESH)]
+
+
 def detect_fused(net, units, thresh=0.05, on_device=False):
-    """detect() with every per-unit step on the device.  ``units`` is an iterable of
-    (data, H, W, im_h, im_w, scale, flip) where data is a host array or a device pointer."""
+    """Single-lane form of FusedDetector.detect."""
     net.detect_begin()
     for data, H, W, im_h, im_w, s, flip in units:
         net.detect_add_level(data, H, W, im_h, im_w, s, flip, thresh, on_device=on_device)

@@ -26,11 +26,11 @@ def bilinear_filler(shape):
     return w
 
 
-def synth_params(net_msg, seed=1234, cls_bias=6.0):
+def synth_params(net_msg, seed=1234, cls_bias=4.0):
     """Seeded synthetic weights: He-normal conv weights (the conv
     that reads the mean-subtracted image is scaled by 1/64 so activations and
     logits are O(1) like a trained net's), zero biases except cls_score* = (+b,-b)
-    (b=6: ~1% of anchors above 0.05, WIDER-like), bbox_pred* x0.1, bilinear deconv; layers
+    (b=4: ~0.5% of anchors above 0.05 on the bench pyramid, WIDER-like), bbox_pred* x0.1, bilinear deconv; layers
     naming the same ``param {name:}`` share one tensor.  Returns
     {layer_name: [w, b]} with Caffe blob shapes.  Used by BOTH the oracle net and
     the HIP net (through Net.params) so they hold identical values."""

@@ -23,7 +23,7 @@ def load_params(gpu_net, params):
     gpu_net.commit_params()
 
 
-def make_pair(msg, seed=1234, cls_bias=6.0):
+def make_pair(msg, seed=1234, cls_bias=4.0):
     """(gpu_net, oracle_net) holding identical parameters."""
     from smallhardface_amd import caffe
     params = O.synth_params(msg, seed=seed, cls_bias=cls_bias)

@@ -264,6 +264,12 @@ def test_detect_driver_vs_fused_vs_oracle():
         assert dets[0].shape == fused[0].shape
         np.testing.assert_array_equal(np.asarray(dets[0], dtype=np.float64), fused[0])
         assert dets[0].shape[0] > 0
+        # units spread over 3 execution lanes (streams): same detections, same order
+        laned = T.FusedDetector(gnet, n_lanes=3).detect(list(T.pyramid_units(im)), thresh=0.05)
+        np.testing.assert_array_equal(laned[0], fused[0])
+        # ... and as one grouped pass (one grid per conv layer over all units)
+        grouped = T.FusedDetector(gnet, n_lanes=1, mode="group").detect(list(T.pyramid_units(im)), thresh=0.05)
+        np.testing.assert_array_equal(grouped[0], fused[0])
     # the same driver over the oracle net (CPU checker) agrees within tolerance
     cfg.TEST.NMS_METHOD = "NMS"
     gd, _ = T.detect(gnet, None, thresh=0.05, pyramid=True, im=im)
