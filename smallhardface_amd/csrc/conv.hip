@@ -14,6 +14,9 @@
 //   * bias + ReLU fused in the accumulator epilogue, stores are 128-B cout runs;
 //   * block id = pixel_tile * n_cout_tiles + cout_tile, so the blocks an XCD sees
 //     (id % 8) share the same weight slab in that XCD's private L2.
+#include <cstdio>
+#include <cstdlib>
+
 #include "shf_internal.h"
 
 namespace shf {
@@ -44,6 +47,7 @@ struct ConvK {
   int in_stride, out_stride;
   int dil, relu;
   int nct, nmem;
+  unsigned long long* dbg;  // SHF_CONV_TIMING builds only: per-wave phase cycle sums
   ConvMember m[MAX_GROUP];
 };
 
@@ -55,16 +59,23 @@ __device__ __forceinline__ void row_to_pixel(int i, int& dy, int& px) {
   px = ((i >> 2) << 1) | (i & 1);
 }
 
-template <int KS, int BN, int TH, int TW>
-__global__ __launch_bounds__(256, 2) void conv_mfma_f32_kernel(ConvK p) {
+// DIL is a template parameter (1/2/4 in the detector, 0 = "1x1, no halo") so the halo tile
+// size is a compile-time constant: its loads are fully unrolled, all issued back to back
+// into registers UNDER the last tap of the previous chunk, and written to LDS after the
+// end-of-chunk barrier (a runtime-bound loop made the compiler serialise load->wait->ds_write
+// round trips: 6-12 exposed memory latencies per chunk).
+template <int KS, int DIL, int BN, int TH, int TW>
+__global__ __launch_bounds__(256, 1) void conv_mfma_f32_kernel(ConvK p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int TAPS = KS * KS;
   constexpr int WN = BN / 64;  // waves along cout
   constexpr int WM = 4 / WN;   // waves along pixels
   static_assert(TH == 4 * WM && TW == 16, "tile shape");
-  const int pad = (KS == 3) ? p.dil : 0;
-  const int HTW = TW + 2 * pad, HTH = TH + 2 * pad;
-  const int HP = HTH * HTW;
+  constexpr int PAD = (KS == 3) ? DIL : 0;
+  constexpr int HTW = TW + 2 * PAD, HTH = TH + 2 * PAD;
+  constexpr int HP = HTH * HTW;
+  constexpr int ALD = (HP * 8 + 255) / 256;  // float4 halo pieces per thread
+  constexpr int BLD = BN * 8 / 256;          // float4 weight pieces per thread
   float* As = smem;              // [HP][LDK]
   float* Bs = smem + HP * LDK;   // [2][BN][LDK]
 
@@ -107,37 +118,108 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_f32_kernel(ConvK p) {
   const int S = nchunks * TAPS;
   const size_t wstep = (size_t)p.Cout * KC;
   const float* wbase = p.wp + (size_t)ct * BN * KC;
-  constexpr int BLD = BN * 8 / 256;
-  float4 breg[BLD];
+  // named scalars, not an array: the staged weights are loop-carried (loaded in step s, parked in
+  // LDS in step s+1) and hipcc keeps a loop-carried local ARRAY in scratch memory
+  float4 bq0, bq1, bq2 = make_float4(0.f, 0.f, 0.f, 0.f), bq3 = make_float4(0.f, 0.f, 0.f, 0.f);
+  static_assert(BLD == 2 || BLD == 4, "weight staging");
+  float4 areg[ALD];
   const int brow = tid >> 3, bq = tid & 7;
 
+  // per-thread halo piece geometry (chunk-invariant): global offset or -1 when outside the image
+  int a_goff[ALD];  // element offsets fit 32 bits (largest activation: 1408^2 x 64 floats)
+  int a_loff[ALD];
 #pragma unroll
-  for (int j = 0; j < BLD; ++j) breg[j] = *(const float4*)(wbase + (size_t)(brow + 32 * j) * KC + bq * 4);
+  for (int j = 0; j < ALD; ++j) {
+    const int idx = tid + 256 * j;
+    const int hp = idx >> 3, q = idx & 7;
+    const int hy = hp / HTW, hx = hp - hy * HTW;
+    const int gy = ty0 - PAD + hy, gx = tx0 - PAD + hx;
+    const bool in = (idx < HP * 8) && ((unsigned)gy < (unsigned)H) && ((unsigned)gx < (unsigned)W);
+    a_goff[j] = in ? ((b * H + gy) * W + gx) * p.in_stride + q * 4 : -1;
+    a_loff[j] = (idx < HP * 8) ? hp * LDK + q * 4 : -1;
+  }
+  // prologue: halo(0) and B(0) into LDS, B(1) in flight in registers
+  {
+    const float* inc_ = gin + (0) * KC;
 #pragma unroll
-  for (int j = 0; j < BLD; ++j) *(float4*)(Bs + (brow + 32 * j) * LDK + bq * 4) = breg[j];
+    for (int j = 0; j < ALD; ++j)
+      areg[j] = (a_goff[j] >= 0) ? *(const float4*)(inc_ + a_goff[j]) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  {
+    const float* wn_ = wbase + (size_t)((p.relu & 2) ? 0 : (0)) * wstep + (size_t)brow * KC + bq * 4;
+    bq0 = *(const float4*)(wn_);
+    bq1 = *(const float4*)(wn_ + 32 * KC);
+    if constexpr (BLD == 4) {
+      bq2 = *(const float4*)(wn_ + 64 * KC);
+      bq3 = *(const float4*)(wn_ + 96 * KC);
+    }
+  }
+  {
+#pragma unroll
+    for (int j = 0; j < ALD; ++j)
+      if (a_loff[j] >= 0) *(float4*)(As + a_loff[j]) = areg[j];
+  }
+  {
+    float* Bn_ = Bs + (0) * (BN * LDK) + brow * LDK + bq * 4;
+    *(float4*)(Bn_) = bq0;
+    *(float4*)(Bn_ + 32 * LDK) = bq1;
+    if constexpr (BLD == 4) {
+      *(float4*)(Bn_ + 64 * LDK) = bq2;
+      *(float4*)(Bn_ + 96 * LDK) = bq3;
+    }
+  }
+  if (S > 1) {
+    const float* wn_ = wbase + (size_t)((p.relu & 2) ? 0 : (1)) * wstep + (size_t)brow * KC + bq * 4;
+    bq0 = *(const float4*)(wn_);
+    bq1 = *(const float4*)(wn_ + 32 * KC);
+    if constexpr (BLD == 4) {
+      bq2 = *(const float4*)(wn_ + 64 * KC);
+      bq3 = *(const float4*)(wn_ + 96 * KC);
+    }
+  }
 
+  int c = 0, tap = 0;
+#ifdef SHF_CONV_TIMING
+  unsigned long long tb = 0, ti = 0, tc = 0, tx = 0, t0, t1, t2, t3;
+#define SHF_T(x) x = __builtin_amdgcn_s_memtime()
+#else
+#define SHF_T(x)
+#endif
   for (int s = 0; s < S; ++s) {
-    const int c = s / TAPS, tap = s - c * TAPS;
-    if (tap == 0) {
-      const float* inc = gin + c * KC;
-      for (int idx = tid; idx < HP * 8; idx += 256) {
-        const int hp = idx >> 3, q = idx & 7;
-        const int hy = hp / HTW, hx = hp - hy * HTW;
-        const int gy = ty0 - pad + hy, gx = tx0 - pad + hx;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W)
-          v = *(const float4*)(inc + ((size_t)(b * H + gy) * W + gx) * p.in_stride + q * 4);
-        *(float4*)(As + hp * LDK + q * 4) = v;
-      }
-    }
-    __syncthreads();
+    SHF_T(t0);
+    __syncthreads();  // B(s) [and the halo of chunk c] visible; everyone is done with step s-1
+    SHF_T(t1);
+    // B(s+1) was loaded during step s-1: park it in the other buffer now (free since the barrier),
+    // then start B(s+2); nothing but the barrier is left after the MFMAs of this step.
     if (s + 1 < S) {
-      const float* wn_ = wbase + (size_t)(s + 1) * wstep;
-#pragma unroll
-      for (int j = 0; j < BLD; ++j) breg[j] = *(const float4*)(wn_ + (size_t)(brow + 32 * j) * KC + bq * 4);
+    float* Bn_ = Bs + ((s + 1) & 1) * (BN * LDK) + brow * LDK + bq * 4;
+    *(float4*)(Bn_) = bq0;
+    *(float4*)(Bn_ + 32 * LDK) = bq1;
+    if constexpr (BLD == 4) {
+      *(float4*)(Bn_ + 64 * LDK) = bq2;
+      *(float4*)(Bn_ + 96 * LDK) = bq3;
     }
+  }
+    if (s + 2 < S && !(p.relu & 4)) {
+    const float* wn_ = wbase + (size_t)((p.relu & 2) ? 0 : (s + 2)) * wstep + (size_t)brow * KC + bq * 4;
+    bq0 = *(const float4*)(wn_);
+    bq1 = *(const float4*)(wn_ + 32 * KC);
+    if constexpr (BLD == 4) {
+      bq2 = *(const float4*)(wn_ + 64 * KC);
+      bq3 = *(const float4*)(wn_ + 96 * KC);
+    }
+  }
+    const bool last_tap = (tap == TAPS - 1);
+    const bool more_chunks = (c + 1 < nchunks);
+    if (last_tap && more_chunks) {
+    const float* inc_ = gin + (c + 1) * KC;
+#pragma unroll
+    for (int j = 0; j < ALD; ++j)
+      areg[j] = (a_goff[j] >= 0) ? *(const float4*)(inc_ + a_goff[j]) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+    SHF_T(t2);
     const int ky = (KS == 3) ? tap / 3 : 0, kx = (KS == 3) ? tap - ky * 3 : 0;
-    const float* Ap = As + (ky * p.dil * HTW + kx * p.dil) * LDK;
+    const float* Ap = As + (ky * DIL * HTW + kx * DIL) * LDK;
     const float* Bp = Bs + (s & 1) * (BN * LDK);
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
@@ -153,13 +235,36 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_f32_kernel(ConvK p) {
         acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[t], b1[t], acc[1][1], 0, 0, 0);
       }
     }
-    if (s + 1 < S) {
-      float* Bn = Bs + ((s + 1) & 1) * (BN * LDK);
+#ifdef SHF_CONV_TIMING
+    asm volatile("s_nop 0" ::: "memory");
+    SHF_T(t3);
+    tb += t1 - t0; ti += t2 - t1; tc += t3 - t2;
+#endif
+    if (last_tap) {
+      if (more_chunks) {
+        __syncthreads();  // every wave is done reading the halo tile of chunk c
+        {
 #pragma unroll
-      for (int j = 0; j < BLD; ++j) *(float4*)(Bn + (brow + 32 * j) * LDK + bq * 4) = breg[j];
-    }
-    if (tap == TAPS - 1) __syncthreads();  // the halo tile is rewritten next step
+    for (int j = 0; j < ALD; ++j)
+      if (a_loff[j] >= 0) *(float4*)(As + a_loff[j]) = areg[j];
   }
+      }
+      tap = 0;
+      ++c;
+    } else {
+      ++tap;
+    }
+#ifdef SHF_CONV_TIMING
+    SHF_T(t0);
+    tx += t0 - t3;
+#endif
+  }
+#ifdef SHF_CONV_TIMING
+  if (p.dbg && lane == 0 && (bid == 0 || bid == 300)) {
+    unsigned long long* d = p.dbg + ((bid ? 1 : 0) * 4 + wave) * 5;
+    d[0] = tb; d[1] = ti; d[2] = tc; d[3] = tx; d[4] = S;
+  }
+#endif
 
   // epilogue: C row = (r&3) + 8*(r>>2) + 4*(lane>>5), C col = lane&31
 #pragma unroll
@@ -176,7 +281,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_f32_kernel(ConvK p) {
         const int gy = ty0 + wm * 4 + tm * 2 + dy2, gx = tx0 + px2;
         if (gy < H && gx < W) {
           float v = acc[tm][tn][r] + bv;
-          if (p.relu) v = fmaxf(v, 0.f);
+          if (p.relu & 1) v = fmaxf(v, 0.f);
           gout[((size_t)(b * H + gy) * W + gx) * p.out_stride + cout] = v;
         }
       }
@@ -282,7 +387,7 @@ void pack_conv_weights(const float* w, int Cout, int Cin, int k, float* dst) {
 
 int conv_kernel_class(int Cin, int Cout, int k, int pad, int dil, bool in_nchw) {
   if (in_nchw) return 1;
-  const bool same = (k == 3 && pad == dil) || (k == 1 && pad == 0);
+  const bool same = (k == 3 && pad == dil && (dil == 1 || dil == 2 || dil == 4)) || (k == 1 && pad == 0);
   if (same && Cin % KC == 0 && Cout % 64 == 0) return 0;
   return 2;
 }
@@ -292,7 +397,7 @@ static size_t mfma_lds_bytes(int k, int dil, int BN, int TH, int TW) {
   return ((size_t)(TH + 2 * pad) * (TW + 2 * pad) * LDK + 2 * (size_t)BN * LDK) * sizeof(float);
 }
 
-template <int KS, int BN, int TH, int TW>
+template <int KS, int DIL, int BN, int TH, int TW>
 static int launch_mfma_t(const ConvArgs* as, int n, hipStream_t s) {
   const ConvArgs& a = as[0];
   ConvK p;
@@ -301,6 +406,8 @@ static int launch_mfma_t(const ConvArgs* as, int n, hipStream_t s) {
   p.Cin = a.in.C; p.Cout = a.out.C;
   p.in_stride = a.in.cstride; p.out_stride = a.out.cstride;
   p.dil = a.dil; p.relu = a.relu;
+  static const int dbg_flags = getenv("SHF_CONV_DBGFLAGS") ? atoi(getenv("SHF_CONV_DBGFLAGS")) : 0;  // experiments only
+  p.relu |= dbg_flags;
   p.nct = p.Cout / BN;
   p.nmem = n;
   long long tiles = 0;
@@ -320,24 +427,46 @@ static int launch_mfma_t(const ConvArgs* as, int n, hipStream_t s) {
     m.tile_start = (int)tiles;
     tiles += (long long)m.tiles_per_img * m.B;
   }
-  const size_t lds = mfma_lds_bytes(KS, a.dil, BN, TH, TW);
-  if (lds > 160 * 1024) { set_error("conv: dilation too large for the LDS halo tile"); return -1; }
+  p.dbg = nullptr;
+#ifdef SHF_CONV_TIMING
+  static unsigned long long* dbg_dev = nullptr;
+  if (!dbg_dev) hipMalloc((void**)&dbg_dev, 8 * 5 * 8);
+  hipMemset(dbg_dev, 0, 8 * 5 * 8);
+  p.dbg = dbg_dev;
+#endif
+  size_t lds = mfma_lds_bytes(KS, DIL, BN, TH, TW);
+  static const int lds_pad = getenv("SHF_CONV_LDS_PAD") ? atoi(getenv("SHF_CONV_LDS_PAD")) : 0;  // tuning knob
+  if (lds + lds_pad <= 160 * 1024) lds += lds_pad;
   const long long blocks = tiles * p.nct;
-  hipLaunchKernelGGL((conv_mfma_f32_kernel<KS, BN, TH, TW>), dim3((unsigned)blocks), dim3(256), lds, s, p);
+  hipLaunchKernelGGL((conv_mfma_f32_kernel<KS, DIL, BN, TH, TW>), dim3((unsigned)blocks), dim3(256), lds, s, p);
   SHF_HIP_OK(hipGetLastError());
+#ifdef SHF_CONV_TIMING
+  {
+    unsigned long long h[40];
+    hipStreamSynchronize(s);
+    hipMemcpy(h, dbg_dev, sizeof(h), hipMemcpyDeviceToHost);
+    for (int w = 0; w < 8; ++w)
+      if (h[w * 5 + 4])
+        fprintf(stderr, "[conv timing] blk%d wave%d steps %llu: per-step cycles barrier %.0f issue %.0f compute %.0f tail %.0f\n",
+                w / 4 ? 300 : 0, w % 4, h[w * 5 + 4], (double)h[w * 5] / h[w * 5 + 4], (double)h[w * 5 + 1] / h[w * 5 + 4],
+                (double)h[w * 5 + 2] / h[w * 5 + 4], (double)h[w * 5 + 3] / h[w * 5 + 4]);
+  }
+#endif
+  return 0;
+}
+
+template <int KS, int DIL, int BN, int TH, int TW>
+static int set_attr_t() {
+  SHF_HIP_OK(hipFuncSetAttribute((const void*)conv_mfma_f32_kernel<KS, DIL, BN, TH, TW>,
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   return 0;
 }
 
 int conv_init_attributes() {
-  const int maxlds = 160 * 1024;
-  SHF_HIP_OK(hipFuncSetAttribute((const void*)conv_mfma_f32_kernel<3, 128, 8, 16>,
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, maxlds));
-  SHF_HIP_OK(hipFuncSetAttribute((const void*)conv_mfma_f32_kernel<3, 64, 16, 16>,
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, maxlds));
-  SHF_HIP_OK(hipFuncSetAttribute((const void*)conv_mfma_f32_kernel<1, 128, 8, 16>,
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, maxlds));
-  SHF_HIP_OK(hipFuncSetAttribute((const void*)conv_mfma_f32_kernel<1, 64, 16, 16>,
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, maxlds));
+  if (set_attr_t<3, 1, 128, 8, 16>() || set_attr_t<3, 2, 128, 8, 16>() || set_attr_t<3, 4, 128, 8, 16>() ||
+      set_attr_t<3, 1, 64, 16, 16>() || set_attr_t<3, 2, 64, 16, 16>() || set_attr_t<3, 4, 64, 16, 16>() ||
+      set_attr_t<1, 0, 128, 8, 16>() || set_attr_t<1, 0, 64, 16, 16>())
+    return -1;
   return 0;
 }
 
@@ -347,8 +476,13 @@ int launch_conv_mfma_group(const ConvArgs* as, int n, hipStream_t s) {
     if ((as[i].in.cstride % 4) || (as[i].in.coff % 4)) { set_error("conv: input view not 16-byte aligned"); return -1; }
   const ConvArgs& a = as[0];
   const bool bn128 = (a.out.C % 128 == 0);
-  if (a.k == 3) return bn128 ? launch_mfma_t<3, 128, 8, 16>(as, n, s) : launch_mfma_t<3, 64, 16, 16>(as, n, s);
-  return bn128 ? launch_mfma_t<1, 128, 8, 16>(as, n, s) : launch_mfma_t<1, 64, 16, 16>(as, n, s);
+  if (a.k == 1) return bn128 ? launch_mfma_t<1, 0, 128, 8, 16>(as, n, s) : launch_mfma_t<1, 0, 64, 16, 16>(as, n, s);
+  switch (a.dil) {
+    case 1: return bn128 ? launch_mfma_t<3, 1, 128, 8, 16>(as, n, s) : launch_mfma_t<3, 1, 64, 16, 16>(as, n, s);
+    case 2: return bn128 ? launch_mfma_t<3, 2, 128, 8, 16>(as, n, s) : launch_mfma_t<3, 2, 64, 16, 16>(as, n, s);
+    case 4: return bn128 ? launch_mfma_t<3, 4, 128, 8, 16>(as, n, s) : launch_mfma_t<3, 4, 64, 16, 16>(as, n, s);
+    default: set_error("conv: the MFMA kernel is instantiated for dilation 1, 2 and 4"); return -1;
+  }
 }
 
 int launch_conv_mfma(const ConvArgs& a, hipStream_t s) { return launch_conv_mfma_group(&a, 1, s); }
