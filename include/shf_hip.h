@@ -127,6 +127,12 @@ int shf_generate_anchors(int base_size, const double* ratios, int n_ratios, cons
                          int n_scales, const double* shifts, int n_shifts, const double* strides,
                          double* out, int cap_rows);
 
+/* Read parameter blob `idx` of layer `layer` from a binary .caffemodel (the reader behind
+ * shf_net_create's weight loading; caffe.proto NetParameter.layer=100 / BlobProto data=5).
+ * Returns the element count (out may be NULL to query), fills dims/ndim.  Needs no GPU. */
+int shf_caffemodel_read_blob(const char* path, const char* layer, int idx, float* out, int cap,
+                             int* dims, int* ndim);
+
 /* ---- diagnostics (tests) ------------------------------------------------------ */
 /* runs the merge pipeline on host dets and returns its intermediates: the IoU bit matrix
  * (n x ceil(n/64) words, upper triangle), cluster head per box, kept heads, sorted dets, perm */

@@ -93,6 +93,7 @@ def _declare(lib):
         "shf_detect_export": (ci, [vp, vp, ci, ip]),
         "shf_detect_import": (ci, [vp, vp, ci]),
         "shf_debug_merge": (ci, [vp, ci, cf, ci, vp, vp, vp, ip, vp, vp]),
+        "shf_caffemodel_read_blob": (ci, [C.c_char_p, C.c_char_p, ci, fp, ci, ip, ip]),
         "shf_nms": (ci, [fp, ci, cf, ci, C.POINTER(C.c_int32), ip]),
         "shf_bbox_vote": (ci, [fp, ci, cf, dp, ci, ip]),
         "shf_generate_anchors": (ci, [ci, dp, ci, dp, ci, dp, ci, dp, dp, ci]),

@@ -128,9 +128,13 @@ struct Layer {
   int kclass = 0;
 };
 
-enum ProfClass { PC_CONV_MFMA, PC_CONV_MFMA_3x3_BN64, PC_CONV_MFMA_1x1_BN128, PC_CONV_MFMA_1x1_BN64, PC_CONV_FIRST, PC_CONV_DIRECT, PC_POOL, PC_DECONV, PC_TAIL, PC_MERGE, PC_LAYOUT, PC_COUNT };
-static const char* kProfNames[PC_COUNT] = {"conv_mfma_f32<3,128,8,16>", "conv_mfma_f32<3,64,16,16>",
-                                           "conv_mfma_f32<1,128,8,16>", "conv_mfma_f32<1,64,16,16>", "conv_first", "conv_direct", "maxpool",
+// the first 8 classes are the instantiations of conv_mfma_f32_kernel, named like rocprofv3 prints them
+enum ProfClass { PC_CONV_MFMA, PC_CONV_MFMA_1 = 1, PC_CONV_MFMA_7 = 7, PC_CONV_FIRST, PC_CONV_DIRECT, PC_POOL, PC_DECONV, PC_TAIL, PC_MERGE, PC_LAYOUT, PC_COUNT };
+static const char* kProfNames[PC_COUNT] = {"conv_mfma_f32_kernel<3, 1, 128, 8, 16>", "conv_mfma_f32_kernel<3, 2, 128, 8, 16>",
+                                           "conv_mfma_f32_kernel<3, 4, 128, 8, 16>", "conv_mfma_f32_kernel<3, 1, 64, 16, 16>",
+                                           "conv_mfma_f32_kernel<3, 2, 64, 16, 16>", "conv_mfma_f32_kernel<3, 4, 64, 16, 16>",
+                                           "conv_mfma_f32_kernel<1, 0, 128, 8, 16>", "conv_mfma_f32_kernel<1, 0, 64, 16, 16>",
+                                           "conv_first_kernel", "conv_direct_kernel", "maxpool_kernel",
                                            "deconv_depthwise", "detect_tail", "box_merge", "layout"};
 
 struct Prof {
@@ -169,6 +173,13 @@ struct Prof {
     for (auto e : pool) (void)hipEventDestroy(e);
   }
 };
+
+static int conv_prof_class(int k, int dil, int nout) {
+  const int bn64 = (nout % 128 == 0) ? 0 : 1;
+  if (k == 1) return 6 + bn64;
+  const int d = dil == 1 ? 0 : dil == 2 ? 1 : 2;
+  return bn64 * 3 + d;
+}
 
 struct ProfScope {
   Prof& p;
@@ -908,8 +919,7 @@ void shf_net::forward_ops(bool fused_path, float im_h, float im_w, float im_scal
           if (L.kclass == 0 && collect) {
             *collect = a;  // grouped launch: the caller batches this layer over several units
           } else if (L.kclass == 0) {
-            const int pc = (L.k == 3) ? (L.nout % 128 == 0 ? PC_CONV_MFMA : PC_CONV_MFMA_3x3_BN64)
-                                      : (L.nout % 128 == 0 ? PC_CONV_MFMA_1x1_BN128 : PC_CONV_MFMA_1x1_BN64);
+            const int pc = conv_prof_class(L.k, L.dil, L.nout);
             ProfScope ps(pf, st, pc, fl, by);
             CHECK_RC(launch_conv_mfma(a, st));
           } else {
@@ -1280,8 +1290,7 @@ int shf_detect_add_levels(shf_net* net, int n, shf_net** members, const float* c
                          mb->blobs[mb->layers[li].tops[0]].shape);
         by += 4.0 * (mb->blobs[mb->layers[li].bottoms[0]].count() + mb->blobs[mb->layers[li].tops[0]].count());
       }
-      const int pc = (L.k == 3) ? (L.nout % 128 == 0 ? PC_CONV_MFMA : PC_CONV_MFMA_3x3_BN64)
-                                : (L.nout % 128 == 0 ? PC_CONV_MFMA_1x1_BN128 : PC_CONV_MFMA_1x1_BN64);
+      const int pc = conv_prof_class(L.k, L.dil, L.nout);
       ProfScope ps(net->prof, net->stream, pc, fl, by);
       CHECK_RC(launch_conv_mfma_group(group.data(), n, net->stream));
     } else {
@@ -1408,6 +1417,23 @@ int shf_bbox_vote(const float* dets5, int n, float thresh, double* out5, int cap
   g_box_in->ensure((size_t)n * 5 * 4);
   HIP_THROW(hipMemcpyAsync(g_box_in->p, dets5, (size_t)n * 5 * 4, hipMemcpyHostToDevice, g_box_stream));
   return g_box_ctx->run((const float*)g_box_in->p, n, 0, thresh, out5, cap, n_out, nullptr, g_box_stream);
+  API_END(-1)
+}
+
+int shf_caffemodel_read_blob(const char* path, const char* layer, int idx, float* out, int cap, int* dims,
+                             int* ndim) {
+  API_BEGIN
+  auto src = read_caffemodel(path);
+  for (auto& L : src) {
+    if (L.name != layer) continue;
+    if (idx < 0 || idx >= (int)L.blobs.size()) throw std::runtime_error("caffemodel: blob index out of range");
+    const WireBlob& b = L.blobs[idx];
+    *ndim = (int)std::min<size_t>(b.shape.size(), 8);
+    for (int i = 0; i < *ndim; ++i) dims[i] = (int)b.shape[i];
+    if (out) std::copy(b.data.begin(), b.data.begin() + std::min<size_t>(b.data.size(), (size_t)cap), out);
+    return (int)b.data.size();
+  }
+  throw std::runtime_error(std::string("caffemodel: no layer named '") + layer + "'");
   API_END(-1)
 }
 
