@@ -95,6 +95,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-events", action="store_true", help="do not record per-launch HIP events")
     ap.add_argument("--method", default=None, help="BBOX_VOTE (default, the reference's) or NMS")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for "
+                    "validating the N>1 code path with several ranks on ONE GPU: SHF_BENCH_ONE_GPU=1)")
     ap.add_argument("--lanes", type=int, default=5, help="execution lanes (HIP streams) per GPU in --mode streams")
     ap.add_argument("--mode", default="group", choices=["group", "streams"],
                     help="group: one grid per conv layer over all units of the image; streams: units on HIP streams")
@@ -107,12 +109,17 @@ def main():
         raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world))
 
     import torch
+    if os.environ.get("SHF_BENCH_ONE_GPU") == "1":
+        local_rank = 0  # validation only: every rank on device 0 (needs --backend gloo)
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
     dev = torch.device("cuda", local_rank)
 
     from smallhardface_amd import caffe, prototxt as P, pyramid, weights
@@ -145,7 +152,8 @@ def main():
     del cache
     flops_per_image = sum(pyramid.level_flops(v[1], v[2]) for v in units.values()) * (1.0 if world == 1 else 0.0)
     exp_cap = n_units * cfg.TEST.N_DETS_PER_MODULE
-    export = [torch.empty((exp_cap, 5), dtype=torch.float32, device=dev) for _ in range(world)] if world > 1 else None
+    export = [torch.empty((cfg.TEST.N_DETS_PER_MODULE, 5), dtype=torch.float32, device=dev)
+              for _ in range(len(mine))] if world > 1 else None
     thresh = 0.05
     last = {}
 
@@ -154,34 +162,27 @@ def main():
     lanes = fd.lanes
     if world == 1:
         unit_list = [(units[(0, u)][0].data_ptr(),) + units[(0, u)][1:] for u in range(n_units)]
+    else:
+        while len(lanes) < len(mine):
+            lanes.append(net.clone())
+        mine_units = [(units[k][0].data_ptr(),) + units[k][1:] for k in mine]
 
     def step():
         if world == 1:
             last[0] = fd.detect(unit_list, thresh, on_device=True)[0]
             return
-        local = {}
-        pending = {}  # lane index -> window image whose units are in flight on it
-
-        def flush(k):
-            j = pending.pop(k)
-            n = lanes[k].detect_export(export[j].data_ptr(), exp_cap)
-            local[j] = export[j][:min(n, exp_cap)]
-
-        # heaviest images first; up to len(lanes) images in flight
-        cost = lambda i: sum(v[1] * v[2] for (ii, _), v in units.items() if ii == i)
-        for i in sorted(range(world), key=lambda i: -cost(i)):
-            k = min(range(len(lanes)), key=lambda q: (q in pending, q))
-            if k in pending:
-                k = next(iter(pending))
-                flush(k)
-            lanes[k].detect_begin()
-            for u in range(n_units):
-                if (i, u) in units:
-                    t, H, W, im_h, im_w, s, flip = units[(i, u)]
-                    lanes[k].detect_add_level(t.data_ptr(), H, W, im_h, im_w, s, flip, thresh, on_device=True)
-            pending[k] = i
-        for k in list(pending):
-            flush(k)
+        # this rank's 10 units (one of each kind, from different images) as ONE grouped pass;
+        # every lane keeps the detections of its unit, which are then routed to the unit's image
+        head = lanes[0]
+        head.detect_add_levels(lanes[:len(mine)], mine_units, thresh, on_device=True, per_member_lists=True)
+        head.sync()
+        parts = {i: [] for i in range(world)}
+        for m, (i, u) in enumerate(mine):
+            n = lanes[m].detect_export(export[m].data_ptr(), cfg.TEST.N_DETS_PER_MODULE)
+            if n:
+                parts[i].append(export[m][:n])
+        empty = torch.zeros((0, 5), dtype=torch.float32, device=dev)
+        local = {i: (torch.cat(p, 0) if p else empty) for i, p in parts.items()}
         got = pyramid.gather_window(local, world, rank, world, device=dev)
         torch.cuda.synchronize()
         for i, t in got.items():

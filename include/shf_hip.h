@@ -94,10 +94,12 @@ int shf_detect_add_level(shf_net* net, const float* data, int data_on_device,
  * size), so the small levels do not serialise latency-bound launches.  members[i] supplies
  * the activation buffers of unit i: `net` itself and/or lanes made with shf_net_clone, all
  * distinct; the work is enqueued on `net`'s stream and the detections land in `net`'s image
- * list in unit order. */
+ * list in unit order -- or, with per_member_lists != 0 (units of DIFFERENT images, the multi-GPU
+ * window), in each member's own list (reset first); synchronise `net` before exporting them. */
 int shf_detect_add_levels(shf_net* net, int n, shf_net** members, const float* const* data,
                           int data_on_device, const int* H, const int* W, const int* im_h,
-                          const int* im_w, const float* im_scale, const int* flip, float thresh);
+                          const int* im_w, const float* im_scale, const int* flip, float thresh,
+                          int per_member_lists);
 /* Box merging for the image (test.py:168-175): method 0 = BBOX_VOTE (test.py:181),
  * 1 = NMS (lib/nms).  out5 rows are (x1,y1,x2,y2,score) as double (bbox_vote
  * returns float64).  *n_out = number of rows (may exceed cap; only cap written). */

@@ -87,7 +87,7 @@ def _declare(lib):
         "shf_net_set_proposal_cfg": (ci, [vp, ci, cf, cf]),
         "shf_detect_begin": (ci, [vp]),
         "shf_detect_add_level": (ci, [vp, vp, ci, ci, ci, ci, ci, cf, ci, cf]),
-        "shf_detect_add_levels": (ci, [vp, ci, C.POINTER(vp), C.POINTER(vp), ci, ip, ip, ip, ip, fp, ip, cf]),
+        "shf_detect_add_levels": (ci, [vp, ci, C.POINTER(vp), C.POINTER(vp), ci, ip, ip, ip, ip, fp, ip, cf, ci]),
         "shf_detect_finish": (ci, [vp, ci, cf, dp, ci, ip]),
         "shf_detect_count": (ci, [vp]),
         "shf_detect_export": (ci, [vp, vp, ci, ip]),

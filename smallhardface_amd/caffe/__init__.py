@@ -254,7 +254,7 @@ class Net(object):
                                                   int(im_w), float(im_scale), 1 if flip else 0, float(thresh)),
                    "detect_add_level")
 
-    def detect_add_levels(self, members, units, thresh, on_device=False):
+    def detect_add_levels(self, members, units, thresh, on_device=False, per_member_lists=False):
         """One grouped pass over several units (C ABI shf_detect_add_levels).  ``members``: distinct
         nets (self and/or lanes) lending their activation buffers, one per unit."""
         n = len(units)
@@ -272,7 +272,8 @@ class Net(object):
         sc = (C.c_float * n)(*[float(u[5]) for u in units])
         fl = (C.c_int * n)(*[1 if u[6] else 0 for u in units])
         _lib.check(self._lib.shf_detect_add_levels(self._h, n, mem, ptrs, 1 if on_device else 0, ia(1), ia(2),
-                                                   ia(3), ia(4), sc, fl, float(thresh)), "detect_add_levels")
+                                                   ia(3), ia(4), sc, fl, float(thresh),
+                                                   1 if per_member_lists else 0), "detect_add_levels")
 
     def detect_count(self):
         n = self._lib.shf_detect_count(self._h)

@@ -1241,15 +1241,17 @@ void shf_net::ensure_img_cap(int units_after) {
 }
 
 // append one finished unit (whose proposals sit in `src`'s output blobs) to `net`'s image list
-static void append_unit(shf_net* net, shf_net* src, int im_w, float im_scale, int flip, float thresh) {
+static void append_unit(shf_net* net, shf_net* src, int im_w, float im_scale, int flip, float thresh,
+                        hipStream_t st = nullptr, Prof* pf = nullptr) {
   net->ensure_img_cap(net->img_units + 1);
   const int rmax = src->pre_nms_topN > 0 ? src->pre_nms_topN : (int)src->tw.cap_anchors;
-  ProfScope ps(net->prof, net->stream, PC_TAIL, 0, 0);
+  if (!st) st = net->stream;
+  ProfScope ps(pf ? *pf : net->prof, st, PC_TAIL, 0, 0);
   CHECK_RC(launch_append_dets((float*)src->blobs[src->boxes_blob].dev.p,
                               src->prob_blob >= 0 ? (float*)src->blobs[src->prob_blob].dev.p : (float*)src->tw_rec.p,
                               src->tw.counters + 2, rmax, (float)im_w, im_scale, flip, thresh, net->img_units,
                               (float*)net->img_dets.p, (unsigned long long*)net->img_keys.p,
-                              (int*)net->img_count.p, net->img_cap, net->stream));
+                              (int*)net->img_count.p, net->img_cap, st));
   net->img_units++;
 }
 
@@ -1266,7 +1268,7 @@ int shf_detect_add_level(shf_net* net, const float* data, int data_on_device, in
 
 int shf_detect_add_levels(shf_net* net, int n, shf_net** members, const float* const* data, int data_on_device,
                           const int* H, const int* W, const int* im_h, const int* im_w, const float* im_scale,
-                          const int* flip, float thresh) {
+                          const int* flip, float thresh, int per_member_lists) {
   API_BEGIN
   if (n < 1 || n > 16) throw std::runtime_error("detect_add_levels: 1..16 units per group");
   for (int m = 0; m < n; ++m) {
@@ -1300,8 +1302,17 @@ int shf_detect_add_levels(shf_net* net, int n, shf_net** members, const float* c
     }
   }
   for (int m = 0; m < n; ++m) {
-    members[m]->blobs[members[m]->data_blob].ext_dev = nullptr;
-    append_unit(net, members[m], im_w[m], im_scale[m], flip[m], thresh);
+    shf_net* mb = members[m];
+    mb->blobs[mb->data_blob].ext_dev = nullptr;
+    if (per_member_lists) {
+      // units of different images: each member keeps its own list (reset + append on net's stream)
+      mb->img_count.ensure(64);
+      HIP_THROW(hipMemsetAsync(mb->img_count.p, 0, 64, net->stream));
+      mb->img_units = 0;
+      append_unit(mb, mb, im_w[m], im_scale[m], flip[m], thresh, net->stream, &net->prof);
+    } else {
+      append_unit(net, mb, im_w[m], im_scale[m], flip[m], thresh);
+    }
   }
   return 0;
   API_END(-1)

@@ -47,6 +47,11 @@ def gather_window(local, n_images, rank, world, device=None, group=None):
         return {i: local[i] for i in range(n_images)}
     import torch.distributed as dist
     dev = device if device is not None else local[0].device
+    out_dev = dev
+    if dist.get_backend(group) == "gloo" and torch.device(dev).type != "cpu":
+        # gloo (CPU tests / one-GPU validation) gathers host tensors; RCCL gathers device tensors
+        local = {i: t.cpu() for i, t in local.items()}
+        dev = torch.device("cpu")
     counts = torch.tensor([int(local[i].shape[0]) for i in range(n_images)], dtype=torch.int64, device=dev)
     all_counts = [torch.empty_like(counts) for _ in range(world)]
     dist.all_gather(all_counts, counts, group=group)
@@ -64,7 +69,7 @@ def gather_window(local, n_images, rank, world, device=None, group=None):
         if image_owner(i, world) != rank:
             continue
         parts = [bufs[r][i, :int(all_counts[r][i])] for r in range(world) if all_counts[r][i] > 0]
-        out[i] = torch.cat(parts, 0) if parts else torch.zeros((0, 5), dtype=torch.float32, device=dev)
+        out[i] = (torch.cat(parts, 0) if parts else torch.zeros((0, 5), dtype=torch.float32, device=dev)).to(out_dev)
     return out
 
 

@@ -270,6 +270,20 @@ def test_detect_driver_vs_fused_vs_oracle():
         # ... and as one grouped pass (one grid per conv layer over all units)
         grouped = T.FusedDetector(gnet, n_lanes=1, mode="group").detect(list(T.pyramid_units(im)), thresh=0.05)
         np.testing.assert_array_equal(grouped[0], fused[0])
+    # multi-GPU window form: one grouped pass, each lane keeps ITS unit's detections for the gather
+    import torch
+    units = list(T.pyramid_units(im))
+    fdm = T.FusedDetector(gnet, n_lanes=len(units), mode="group")
+    fdm.lanes[0].detect_add_levels(fdm.lanes[:len(units)], units, 0.05, per_member_lists=True)
+    fdm.lanes[0].sync()
+    buf = torch.empty((10000, 5), dtype=torch.float32, device="cuda")
+    for m, u in enumerate(units):
+        n = fdm.lanes[m].detect_export(buf.data_ptr(), 10000)
+        got = buf[:n].cpu().numpy()
+        gnet.detect_begin()
+        gnet.detect_add_level(*u[:7], 0.05)
+        n2 = gnet.detect_export(buf.data_ptr(), 10000)
+        np.testing.assert_array_equal(got, buf[:n2].cpu().numpy())
     # the same driver over the oracle net (CPU checker) agrees within tolerance
     cfg.TEST.NMS_METHOD = "NMS"
     gd, _ = T.detect(gnet, None, thresh=0.05, pyramid=True, im=im)
