@@ -31,7 +31,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 2.4 GHz
+# /opt/skills/guides/MI355X_MICROARCH.md: dense matrix-core peaks (256 CU x 2.4 GHz)
+PEAK_F32_MFMA_TFLOPS = 157.3   # v_mfma_f32_32x32x2_f32
+PEAK_F16_MFMA_TFLOPS = 2500.0  # v_mfma_f32_32x32x16_f16 (dense; the 5 PF marketing figure is 2:1 sparse)
 SRC_H = SRC_W = 1024
 
 
@@ -95,6 +97,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-events", action="store_true", help="do not record per-launch HIP events")
     ap.add_argument("--method", default=None, help="BBOX_VOTE (default, the reference's) or NMS")
+    ap.add_argument("--conv-mode", default="f16x3", choices=["f16x3", "fp32"],
+                    help="f16x3: split-fp16 MFMA (3 fp16 products per fp32 product, fp32 accumulate; fp32-class "
+                         "accuracy, same parity bars); fp32: exact v_mfma_f32_32x32x2_f32 everywhere")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for "
                     "validating the N>1 code path with several ranks on ONE GPU: SHF_BENCH_ONE_GPU=1)")
     ap.add_argument("--lanes", type=int, default=5, help="execution lanes (HIP streams) per GPU in --mode streams")
@@ -137,6 +142,7 @@ def main():
         for i, arr in enumerate(blobs):
             net.params[name][i].data[...] = arr
     net.commit_params()
+    net.set_conv_mode(args.conv_mode)
 
     # ---- the window: `world` images, this rank's share of their units resident in HBM
     n_units = len(cfg.TEST.SCALES) * (2 if cfg.TEST.FLIP else 1)
@@ -231,12 +237,15 @@ def main():
             "metric": "images_per_sec_full_multiscale_pyramid", "value": value, "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None,
+            "dtype": "f32 via split-f16 MFMA (3x fp16 products, f32 accumulate)" if args.conv_mode == "f16x3" else "f32",
+            "data": "synthetic",
             "config": {
                 "workload": "C5: full smallhardface.toml test pyramid of a 1024x1024 source: scales "
                             "[100,300,600,1000,1400] -> padded 112/304/608/1008/1408, x flip = 10 units/image "
                             "(5021.6 GFLOP), VGG-16 + shared-weight dilated heads (different_dilation + dim_red), "
-                            "fp32, proposal tail + >0.05 cut + %s on device" % cfg.TEST.NMS_METHOD,
+                            "fp32 activations, conv mode %s, proposal tail + >0.05 cut + %s on device"
+                            % (args.conv_mode, cfg.TEST.NMS_METHOD),
                 "images_per_step": world, "units_per_image": n_units, "lanes_per_gpu": len(lanes), "unit_execution": args.mode, "parallelism":
                     "pyramid units sharded 1-of-each-kind per GPU per window; RCCL all_gather of detections to the "
                     "image's owner rank" if world > 1 else "single GPU",
@@ -250,9 +259,14 @@ def main():
             name, dom = max(convs.items(), key=lambda kv: kv[1]["ms"])
             ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
             all_ms = sum(v["ms"] for v in prof.values())
+            split = "f16x3" in name
+            peak = PEAK_F16_MFMA_TFLOPS if split else PEAK_F32_MFMA_TFLOPS
             out["roofline"] = {
-                "bound": "mfma", "kernel": name, "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": hbm_traffic_per_launch(name),
+                "bound": "mfma", "kernel": name, "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+                "frac": ach / peak, "traffic": hbm_traffic_per_launch(name),
+                "mfma_dtype": "fp16 x3 (split-fp16: 3 MFMA FLOPs issued per algorithmic FLOP)" if split else "fp32",
+                "issued_mfma_achieved": ach * (3.0 if split else 1.0),
+                "issued_mfma_frac": ach * (3.0 if split else 1.0) / peak,
                 "traffic_source": "profiles/r01_pmc_hbm_bytes.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate "
                                   "passes of this command, bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 per launch "
                                   "(gfx950 FETCH_SIZE counts 128-B requests as 64 B, MI355X_MICROARCH.md HBM section)",

@@ -79,6 +79,13 @@ int shf_net_forward(shf_net* net);
  * the native proposal stage takes them here. */
 int shf_net_set_proposal_cfg(shf_net* net, int pre_nms_topN, float score_thresh, float min_size);
 
+/* Arithmetic of the 3x3 / dilation-1 convolutions: 0 = exact fp32 matrix cores
+ * (v_mfma_f32_32x32x2_f32, bit-for-bit an fmaf chain); 1 = split-fp16: x = hi + lo*2^-11 with
+ * three fp16 MFMAs per product, fp32 accumulate (2^-22 relative per product: fp32-class, 5.3x
+ * the fp32 MFMA rate).  Default 0, or the SHF_CONV_MODE environment variable at creation.
+ * Set it before cloning lanes. */
+int shf_net_set_conv_mode(shf_net* net, int mode);
+
 /* ---- fused per-image path (device-resident pyramid; lib/test.py:109-178) ---- */
 /* detect(): begin an image */
 int shf_detect_begin(shf_net* net);

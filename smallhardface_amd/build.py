@@ -19,12 +19,13 @@ ARCH = "gfx950"
 
 SOURCES = [
     ("conv.hip", []),
+    ("conv_f16x3.hip", []),
     ("misc.hip", []),
     ("tail.hip", ["-ffp-contract=off"]),
     ("merge.hip", ["-ffp-contract=off"]),
     ("net.cpp", []),
 ]
-HEADERS = ["shf_internal.h", "proto_text.h", os.path.join("..", "..", "include", "shf_hip.h")]
+HEADERS = ["shf_internal.h", "conv_common.h", "proto_text.h", os.path.join("..", "..", "include", "shf_hip.h")]
 
 
 def _newer(target, deps):

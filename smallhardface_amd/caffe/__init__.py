@@ -162,6 +162,12 @@ class Net(object):
         _lib.check(self._lib.shf_net_set_proposal_cfg(self._h, int(pre_nms_topN), float(score_thresh),
                                                       float(min_size)), "set_proposal_cfg")
 
+    def set_conv_mode(self, mode):
+        """"fp32" (exact fp32 MFMA) or "f16x3" (split-fp16 MFMA, fp32-class accuracy) for the 3x3 convs."""
+        m = {"fp32": 0, "f16x3": 1, 0: 0, 1: 1}[mode]
+        self.commit_params()
+        _lib.check(self._lib.shf_net_set_conv_mode(self._h, m), "set_conv_mode")
+
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
         if h:

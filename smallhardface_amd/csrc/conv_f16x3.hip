@@ -1,0 +1,336 @@
+// Split-fp16 implicit-GEMM convolution for gfx950 (MI355X): fp32-class accuracy at the
+// fp16 matrix-core rate.
+//
+// Every fp32 operand x is split as  x = hi + lo * 2^-11,  hi = fp16(x),  lo = fp16((x - hi) * 2^11)
+// (relative representation error 2^-24, i.e. fp32-grade), and a product is formed from three
+// fp16 MFMAs accumulating in fp32:
+//      main += a_hi * b_hi
+//      corr += a_hi * b_lo + a_lo * b_hi            (both carry the 2^11 scale)
+//      out   = main + corr * 2^-11                   (a_lo*b_lo ~ 2^-22 relative is dropped)
+// v_mfma_f32_32x32x16_f16 retires 16 k per 32 cycles against 2 k per 64 cycles for the exact
+// v_mfma_f32_32x32x2_f32, so three of them are 16/3 = 5.3x the fp32 MFMA rate.  Activations
+// stay fp32 in HBM (the split happens while the halo tile is staged into LDS); weights are
+// split once at load time.  Used for the 3x3 / dilation-1 layers (97 % of the FLOPs); the
+// dilated heads and the 1x1 convs stay on the exact fp32 kernel (conv.hip).
+//
+// Structure: block = 512 threads (8 waves), tile 256 px (16x16) x BN couts; a STAGE is one
+// kernel row (3 taps) of one 32-channel chunk: its three BNx32 weight slabs are double-
+// buffered in LDS (fetched two stages ahead into registers, parked at the top of the stage);
+// the 18x18x32 halo tile is staged once per chunk and reused by all 9 taps.  LDS rows are
+// [hi: 32 halfs][lo: 32 halfs][16 B pad] = 144 B (conflict-free ds_read_b128).
+#include <cstdio>
+#include <cstdlib>
+
+#include "conv_common.h"
+
+namespace shf {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace f16x3 {
+constexpr int KC = 32;      // input channels per chunk
+constexpr int ROWB = 144;   // bytes per LDS row (pixel or cout)
+constexpr int TH = 16, TW = 16, HTW = TW + 2, HTH = TH + 2, HP = HTH * HTW;
+constexpr float LO_SCALE = 2048.0f, LO_INV = 1.0f / 2048.0f;
+}  // namespace f16x3
+
+__device__ __forceinline__ void split4(const float4 v, half4& hi, half4& lo) {
+  const float x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const _Float16 h = (_Float16)x[j];
+    hi[j] = h;
+    lo[j] = (_Float16)((x[j] - (float)h) * f16x3::LO_SCALE);
+  }
+}
+
+// BN = 128: waves 4(M) x 2(N), each 64 px x 64 couts (MT = 2 M-tiles); BN = 64: waves 8 x 1, each 32 px x 64 couts.
+template <int BN>
+__global__ __launch_bounds__(512) void conv_mfma_f16x3_kernel(ConvK p) {
+  using namespace f16x3;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int WN = BN / 64;
+  constexpr int WM = 8 / WN;
+  constexpr int MT = TH / (2 * WM);      // 2x16-pixel MFMA row tiles per wave: 2 (BN=128) or 1 (BN=64)
+  constexpr int NBP = 3 * BN * 8 / 512;  // 16-B weight pieces per thread per stage: 6 or 3
+  constexpr int ALD = (HP * 8 + 511) / 512;  // float4 halo pieces per thread: 6
+  unsigned char* As = smem;                  // [HP][ROWB]
+  unsigned char* Bs = smem + HP * ROWB;      // [2][3][BN][ROWB]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave % WN, wm = wave / WN;
+  const int bid = blockIdx.x;
+  const int ct = bid % p.nct;
+  int pt = bid / p.nct;
+  int mi = 0;
+#pragma unroll 1
+  for (int q = 1; q < p.nmem; ++q)
+    if (pt >= p.m[q].tile_start) mi = q;
+  const ConvMember& mem = p.m[mi];
+  pt -= mem.tile_start;
+  const int b = pt / mem.tiles_per_img;
+  pt -= b * mem.tiles_per_img;
+  const int ty0 = (pt / mem.tiles_x) * TH, tx0 = (pt % mem.tiles_x) * TW;
+  const int H = mem.H, W = mem.W;
+  const float* __restrict__ gin = mem.in;
+  float* __restrict__ gout = mem.out;
+
+  const int i = lane & 31, kh = lane >> 5;
+  int dy, px;
+  row_to_pixel(i, dy, px);
+  int a_off[MT], b_off[2];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) a_off[t] = ((wm * 2 * MT + t * 2 + dy) * HTW + px) * ROWB + kh * 16;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) b_off[t] = (wn * 64 + t * 32 + i) * ROWB + kh * 16;
+
+  f32x16 accm[MT][2], accc[MT][2];
+#pragma unroll
+  for (int a = 0; a < MT; ++a)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { accm[a][c][r] = 0.f; accc[a][c][r] = 0.f; }
+
+  const int nchunks = p.Cin / KC;
+  const int NST = nchunks * 3;  // stages
+  const _Float16* wsp = (const _Float16*)p.wp;
+  // weights: [chunk][ky][kx][cout][hi 32 | lo 32] halfs
+  const size_t slab = (size_t)p.Cout * 64;        // halfs per (chunk,ky,kx)
+  const _Float16* wbase = wsp + (size_t)ct * BN * 64;
+
+  // per-thread weight piece geometry (stage-invariant)
+  int wg_off[NBP], wl_off[NBP];
+#pragma unroll
+  for (int j = 0; j < NBP; ++j) {
+    const int idx = tid + 512 * j;
+    const int sl = idx / (BN * 8), r = (idx >> 3) % BN, q = idx & 7;
+    wg_off[j] = sl * (int)slab + r * 64 + q * 8;            // halfs
+    wl_off[j] = (sl * BN + r) * ROWB + q * 16;              // bytes
+  }
+  // per-thread halo piece geometry (chunk-invariant)
+  int a_goff[ALD], a_loff[ALD];
+#pragma unroll
+  for (int j = 0; j < ALD; ++j) {
+    const int idx = tid + 512 * j;
+    const int hp = idx >> 3, q = idx & 7;
+    const int hy = hp / HTW, hx = hp - hy * HTW;
+    const int gy = ty0 - 1 + hy, gx = tx0 - 1 + hx;
+    const bool in = (idx < HP * 8) && ((unsigned)gy < (unsigned)H) && ((unsigned)gx < (unsigned)W);
+    a_goff[j] = in ? ((b * H + gy) * W + gx) * p.in_stride + q * 4 : -1;
+    a_loff[j] = (idx < HP * 8) ? hp * ROWB + q * 8 : -1;
+  }
+  float4 areg[ALD];
+  // staged weights are loop-carried -> named scalars (a local array would live in scratch)
+  uint4 w0, w1, w2, w3 = make_uint4(0, 0, 0, 0), w4 = make_uint4(0, 0, 0, 0), w5 = make_uint4(0, 0, 0, 0);
+
+#define F16X3_LOAD_W(STAGE)                                                   \
+  {                                                                           \
+    const _Float16* ws_ = wbase + (size_t)(STAGE) * 3 * slab;                 \
+    w0 = *(const uint4*)(ws_ + wg_off[0]);                                    \
+    w1 = *(const uint4*)(ws_ + wg_off[1]);                                    \
+    w2 = *(const uint4*)(ws_ + wg_off[2]);                                    \
+    if constexpr (NBP == 6) {                                                 \
+      w3 = *(const uint4*)(ws_ + wg_off[3]);                                  \
+      w4 = *(const uint4*)(ws_ + wg_off[4]);                                  \
+      w5 = *(const uint4*)(ws_ + wg_off[5]);                                  \
+    }                                                                         \
+  }
+#define F16X3_STORE_W(BUF)                                                    \
+  {                                                                           \
+    unsigned char* bd_ = Bs + (BUF) * (3 * BN * ROWB);                        \
+    *(uint4*)(bd_ + wl_off[0]) = w0;                                          \
+    *(uint4*)(bd_ + wl_off[1]) = w1;                                          \
+    *(uint4*)(bd_ + wl_off[2]) = w2;                                          \
+    if constexpr (NBP == 6) {                                                 \
+      *(uint4*)(bd_ + wl_off[3]) = w3;                                        \
+      *(uint4*)(bd_ + wl_off[4]) = w4;                                        \
+      *(uint4*)(bd_ + wl_off[5]) = w5;                                        \
+    }                                                                         \
+  }
+
+  // prologue: halo(0), W(0) into LDS; W(1) in flight
+  {
+    const float* inc_ = gin;
+#pragma unroll
+    for (int j = 0; j < ALD; ++j)
+      areg[j] = (a_goff[j] >= 0) ? *(const float4*)(inc_ + a_goff[j]) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  F16X3_LOAD_W(0);
+#pragma unroll
+  for (int j = 0; j < ALD; ++j)
+    if (a_loff[j] >= 0) {
+      half4 hi, lo;
+      split4(areg[j], hi, lo);
+      *(half4*)(As + a_loff[j]) = hi;
+      *(half4*)(As + a_loff[j] + 64) = lo;
+    }
+  F16X3_STORE_W(0);
+  if (NST > 1) F16X3_LOAD_W(1);
+
+  int c = 0, ky = 0;
+  for (int st = 0; st < NST; ++st) {
+    __syncthreads();
+    if (st + 1 < NST) F16X3_STORE_W((st + 1) & 1);
+    if (st + 2 < NST) F16X3_LOAD_W(st + 2);
+    const bool last_row = (ky == 2);
+    const bool more_chunks = (c + 1 < nchunks);
+    if (last_row && more_chunks) {
+      const float* inc_ = gin + (c + 1) * KC;
+#pragma unroll
+      for (int j = 0; j < ALD; ++j)
+        areg[j] = (a_goff[j] >= 0) ? *(const float4*)(inc_ + a_goff[j]) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const unsigned char* Arow = As + (ky * HTW) * ROWB;
+    const unsigned char* Bst = Bs + (st & 1) * (3 * BN * ROWB);
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const unsigned char* Ap = Arow + kx * ROWB;
+      const unsigned char* Bp = Bst + kx * (BN * ROWB);
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        half8 ah[MT], al[MT], bh[2], bl[2];
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+          ah[t] = *(const half8*)(Ap + a_off[t] + kk * 32);
+          al[t] = *(const half8*)(Ap + a_off[t] + kk * 32 + 64);
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          bh[t] = *(const half8*)(Bp + b_off[t] + kk * 32);
+          bl[t] = *(const half8*)(Bp + b_off[t] + kk * 32 + 64);
+        }
+#pragma unroll
+        for (int tm = 0; tm < MT; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < 2; ++tn) {
+            accm[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tm], bh[tn], accm[tm][tn], 0, 0, 0);
+            accc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tm], bl[tn], accc[tm][tn], 0, 0, 0);
+            accc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[tm], bh[tn], accc[tm][tn], 0, 0, 0);
+          }
+      }
+    }
+    if (last_row) {
+      if (more_chunks) {
+        __syncthreads();  // every wave is done reading the halo tile of chunk c
+#pragma unroll
+        for (int j = 0; j < ALD; ++j)
+          if (a_loff[j] >= 0) {
+            half4 hi, lo;
+            split4(areg[j], hi, lo);
+            *(half4*)(As + a_loff[j]) = hi;
+            *(half4*)(As + a_loff[j] + 64) = lo;
+          }
+      }
+      ky = 0;
+      ++c;
+    } else {
+      ++ky;
+    }
+  }
+#undef F16X3_LOAD_W
+#undef F16X3_STORE_W
+
+  // epilogue: C row = (r&3) + 8*(r>>2) + 4*(lane>>5), C col = lane&31
+#pragma unroll
+  for (int tn = 0; tn < 2; ++tn) {
+    const int cout = ct * BN + wn * 64 + tn * 32 + i;
+    const float bv = p.bias ? p.bias[cout] : 0.f;
+#pragma unroll
+    for (int tm = 0; tm < MT; ++tm) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * kh;
+        int dy2, px2;
+        row_to_pixel(row, dy2, px2);
+        const int gy = ty0 + wm * 2 * MT + tm * 2 + dy2, gx = tx0 + px2;
+        if (gy < H && gx < W) {
+          float v = accm[tm][tn][r] + accc[tm][tn][r] * LO_INV + bv;
+          if (p.relu & 1) v = fmaxf(v, 0.f);
+          gout[((size_t)(b * H + gy) * W + gx) * p.out_stride + cout] = v;
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+size_t split16_conv_weight_halfs(int Cout, int Cin, int k) { return (size_t)Cout * Cin * k * k * 2; }
+
+// (Cout,Cin,3,3) fp32 -> [Cin/32][ky][kx][Cout][hi 32 | lo 32] fp16
+void pack_conv_weights_split16(const float* w, int Cout, int Cin, int k, void* dst_) {
+  _Float16* dst = (_Float16*)dst_;
+  const int taps = k * k;
+  for (int co = 0; co < Cout; ++co)
+    for (int ci = 0; ci < Cin; ++ci)
+      for (int t = 0; t < taps; ++t) {
+        const float x = w[((size_t)co * Cin + ci) * taps + t];
+        const _Float16 h = (_Float16)x;
+        const _Float16 l = (_Float16)((x - (float)h) * f16x3::LO_SCALE);
+        const size_t row = (((size_t)(ci / 32) * taps + t) * Cout + co) * 64;
+        dst[row + (ci % 32)] = h;
+        dst[row + 32 + (ci % 32)] = l;
+      }
+}
+
+bool conv_f16x3_eligible(int Cin, int Cout, int k, int pad, int dil) {
+  return k == 3 && dil == 1 && pad == 1 && Cin % 32 == 0 && Cout % 64 == 0;
+}
+
+template <int BN>
+static int launch_f16x3_t(const ConvArgs* as, int n, hipStream_t s) {
+  using namespace f16x3;
+  const ConvArgs& a = as[0];
+  ConvK p;
+  p.wp = (const float*)a.wsplit16;
+  p.bias = a.bias;
+  p.Cin = a.in.C; p.Cout = a.out.C;
+  p.in_stride = a.in.cstride; p.out_stride = a.out.cstride;
+  p.dil = 1; p.relu = a.relu;
+  p.nct = p.Cout / BN;
+  p.nmem = n;
+  p.dbg = nullptr;
+  long long tiles = 0;
+  for (int i = 0; i < n; ++i) {
+    const ConvArgs& q = as[i];
+    if (q.in.C != p.Cin || q.out.C != p.Cout || q.in.cstride != p.in_stride || q.out.cstride != p.out_stride ||
+        q.wsplit16 != a.wsplit16) {
+      set_error("conv group: members must share the layer");
+      return -1;
+    }
+    ConvMember& m = p.m[i];
+    m.in = q.in.p + q.in.coff;
+    m.out = q.out.p + q.out.coff;
+    m.B = q.in.B; m.H = q.in.H; m.W = q.in.W;
+    m.tiles_x = (m.W + TW - 1) / TW;
+    m.tiles_per_img = m.tiles_x * ((m.H + TH - 1) / TH);
+    m.tile_start = (int)tiles;
+    tiles += (long long)m.tiles_per_img * m.B;
+  }
+  const size_t lds = (size_t)HP * ROWB + 2 * 3 * (size_t)BN * ROWB;
+  hipLaunchKernelGGL((conv_mfma_f16x3_kernel<BN>), dim3((unsigned)(tiles * p.nct)), dim3(512), lds, s, p);
+  SHF_HIP_OK(hipGetLastError());
+  return 0;
+}
+
+int conv_f16x3_init_attributes() {
+  SHF_HIP_OK(hipFuncSetAttribute((const void*)conv_mfma_f16x3_kernel<128>,
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  SHF_HIP_OK(hipFuncSetAttribute((const void*)conv_mfma_f16x3_kernel<64>,
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  return 0;
+}
+
+int launch_conv_f16x3_group(const ConvArgs* as, int n, hipStream_t s) {
+  if (n < 1 || n > MAX_GROUP) { set_error("conv group: 1..16 members"); return -1; }
+  for (int i = 0; i < n; ++i)
+    if ((as[i].in.cstride % 4) || (as[i].in.coff % 4)) { set_error("conv: input view not 16-byte aligned"); return -1; }
+  if (!as[0].wsplit16) { set_error("conv f16x3: split weights not packed"); return -1; }
+  return (as[0].out.C % 128 == 0) ? launch_f16x3_t<128>(as, n, s) : launch_f16x3_t<64>(as, n, s);
+}
+
+}  // namespace shf

@@ -87,7 +87,7 @@ struct HostBuf {
 struct ParamBlob {
   std::vector<int> shape;
   std::vector<float> host;
-  DevBuf raw, packed;
+  DevBuf raw, packed, packed16;
   bool dirty = true;
   size_t count() const {
     size_t c = 1;
@@ -129,11 +129,12 @@ struct Layer {
 };
 
 // the first 8 classes are the instantiations of conv_mfma_f32_kernel, named like rocprofv3 prints them
-enum ProfClass { PC_CONV_MFMA, PC_CONV_MFMA_1 = 1, PC_CONV_MFMA_7 = 7, PC_CONV_FIRST, PC_CONV_DIRECT, PC_POOL, PC_DECONV, PC_TAIL, PC_MERGE, PC_LAYOUT, PC_COUNT };
+enum ProfClass { PC_CONV_MFMA, PC_CONV_MFMA_1 = 1, PC_CONV_MFMA_7 = 7, PC_CONV_F16X3_128, PC_CONV_F16X3_64, PC_CONV_FIRST, PC_CONV_DIRECT, PC_POOL, PC_DECONV, PC_TAIL, PC_MERGE, PC_LAYOUT, PC_COUNT };
 static const char* kProfNames[PC_COUNT] = {"conv_mfma_f32_kernel<3, 1, 128, 8, 16>", "conv_mfma_f32_kernel<3, 2, 128, 8, 16>",
                                            "conv_mfma_f32_kernel<3, 4, 128, 8, 16>", "conv_mfma_f32_kernel<3, 1, 64, 16, 16>",
                                            "conv_mfma_f32_kernel<3, 2, 64, 16, 16>", "conv_mfma_f32_kernel<3, 4, 64, 16, 16>",
                                            "conv_mfma_f32_kernel<1, 0, 128, 8, 16>", "conv_mfma_f32_kernel<1, 0, 64, 16, 16>",
+                                           "conv_mfma_f16x3_kernel<128>", "conv_mfma_f16x3_kernel<64>",
                                            "conv_first_kernel", "conv_direct_kernel", "maxpool_kernel",
                                            "deconv_depthwise", "detect_tail", "box_merge", "layout"};
 
@@ -373,6 +374,7 @@ struct shf_net {
   shf_net* clone_src = nullptr;     // lanes share the parameter tensors of the net they were cloned from
   std::shared_ptr<int> wgen = std::make_shared<int>(0);  // bumped by every param commit
   int tail_gen = -1;
+  int conv_mode = 0;  // 0: exact fp32 MFMA everywhere; 1: split-fp16 MFMA for the 3x3 / dilation-1 layers
   TailWork tw;
   DevBuf tw_logits, tw_rec, tw_keys, tw_counters;
   int pre_nms_topN = 10000;
@@ -434,10 +436,13 @@ static int geti(const PMsg* m, const char* n, int d) { return m ? (int)m->num(n,
 
 void shf_net::build(const std::string& text, const char* caffemodel) {
   proto_text = text;
+  if (clone_src) conv_mode = clone_src->conv_mode;
+  else if (getenv("SHF_CONV_MODE")) conv_mode = atoi(getenv("SHF_CONV_MODE"));
   TextParser tp(proto_text);
   root = tp.parse();
   HIP_THROW(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
   CHECK_RC(conv_init_attributes());
+  CHECK_RC(conv_f16x3_init_attributes());
 
   // ---- inputs: legacy `input:` + input_shape / input_dim (upgrade_proto.cpp:966-1000)
   auto in_names = root->all("input");
@@ -858,6 +863,12 @@ void shf_net::commit_params(int li) {
       pack_conv_weights(p.host.data(), p.shape[0], p.shape[1], p.shape[2], packed.data());
       p.packed.ensure(packed.size() * 4);
       HIP_THROW(hipMemcpy(p.packed.p, packed.data(), packed.size() * 4, hipMemcpyHostToDevice));
+      if (conv_mode == 1 && conv_f16x3_eligible(p.shape[1], p.shape[0], L.k, L.pad, L.dil)) {
+        std::vector<uint16_t> sp(split16_conv_weight_halfs(p.shape[0], p.shape[1], p.shape[2]));
+        pack_conv_weights_split16(p.host.data(), p.shape[0], p.shape[1], p.shape[2], sp.data());
+        p.packed16.ensure(sp.size() * 2);
+        HIP_THROW(hipMemcpy(p.packed16.p, sp.data(), sp.size() * 2, hipMemcpyHostToDevice));
+      }
     }
     p.dirty = false;
   }
@@ -907,6 +918,9 @@ void shf_net::forward_ops(bool fused_path, float im_h, float im_w, float im_scal
         a.bias = L.params.size() > 1 ? (const float*)L.params[1]->raw.p : nullptr;
         a.wraw = (const float*)L.params[0]->raw.p;
         a.wpacked = (const float*)L.params[0]->packed.p;
+        const bool split16 = conv_mode == 1 && L.kclass == 0 && L.params[0]->packed16.p &&
+                             conv_f16x3_eligible(ib.shape[1], L.nout, L.k, L.pad, L.dil);
+        a.wsplit16 = split16 ? L.params[0]->packed16.p : nullptr;
         const double fl = conv_flops(L, ib.shape, blobs[L.tops[0]].shape);
         const double by = 4.0 * (ib.count() + blobs[L.tops[0]].count() + L.params[0]->count());
         if (L.kclass == 1) {
@@ -918,6 +932,9 @@ void shf_net::forward_ops(bool fused_path, float im_h, float im_w, float im_scal
           a.in = view_of(L.bottoms[0]);
           if (L.kclass == 0 && collect) {
             *collect = a;  // grouped launch: the caller batches this layer over several units
+          } else if (L.kclass == 0 && split16) {
+            ProfScope ps(pf, st, L.nout % 128 == 0 ? PC_CONV_F16X3_128 : PC_CONV_F16X3_64, fl, by);
+            CHECK_RC(launch_conv_f16x3_group(&a, 1, st));
           } else if (L.kclass == 0) {
             const int pc = conv_prof_class(L.k, L.dil, L.nout);
             ProfScope ps(pf, st, pc, fl, by);
@@ -1192,6 +1209,17 @@ int shf_net_set_proposal_cfg(shf_net* net, int pre_nms_topN, float score_thresh,
   API_END(-1)
 }
 
+int shf_net_set_conv_mode(shf_net* net, int mode) {
+  API_BEGIN
+  if (mode != 0 && mode != 1) throw std::runtime_error("conv mode must be 0 (fp32) or 1 (split-fp16)");
+  if (net->conv_mode != mode) {
+    net->conv_mode = mode;
+    for (size_t li = 0; li < net->layers.size(); ++li) net->commit_params((int)li);
+  }
+  return 0;
+  API_END(-1)
+}
+
 int shf_detect_begin(shf_net* net) {
   API_BEGIN
   if (net->tail_layer < 0) throw std::runtime_error("net has no proposal layer");
@@ -1292,9 +1320,14 @@ int shf_detect_add_levels(shf_net* net, int n, shf_net** members, const float* c
                          mb->blobs[mb->layers[li].tops[0]].shape);
         by += 4.0 * (mb->blobs[mb->layers[li].bottoms[0]].count() + mb->blobs[mb->layers[li].tops[0]].count());
       }
-      const int pc = conv_prof_class(L.k, L.dil, L.nout);
-      ProfScope ps(net->prof, net->stream, pc, fl, by);
-      CHECK_RC(launch_conv_mfma_group(group.data(), n, net->stream));
+      if (group[0].wsplit16) {
+        ProfScope ps(net->prof, net->stream, L.nout % 128 == 0 ? PC_CONV_F16X3_128 : PC_CONV_F16X3_64, fl, by);
+        CHECK_RC(launch_conv_f16x3_group(group.data(), n, net->stream));
+      } else {
+        const int pc = conv_prof_class(L.k, L.dil, L.nout);
+        ProfScope ps(net->prof, net->stream, pc, fl, by);
+        CHECK_RC(launch_conv_mfma_group(group.data(), n, net->stream));
+      }
     } else {
       for (int m = 0; m < n; ++m)
         members[m]->forward_ops(true, (float)im_h[m], (float)im_w[m], im_scale[m], net->stream, &net->prof, (int)li,

@@ -29,6 +29,7 @@ struct ConvArgs {
   View in, out;
   const float* wpacked = nullptr;  // [Cin/32][k*k][Cout][32] (see pack_conv_weights)
   const float* wraw = nullptr;     // Caffe layout (Cout,Cin,k,k) for the direct kernels
+  const void* wsplit16 = nullptr;  // split-fp16 pack [Cin/32][tap][Cout][hi32|lo32] (conv_f16x3.hip)
   const float* bias = nullptr;     // [Cout] or null
   int k = 3, dil = 1, pad = 1;
   int relu = 0;
@@ -42,6 +43,12 @@ int launch_conv_mfma_group(const ConvArgs* as, int n, hipStream_t s);
 int launch_conv_first(const float* in_nchw, const ConvArgs& a, hipStream_t s);
 int launch_conv_direct(const ConvArgs& a, hipStream_t s);
 int conv_init_attributes();
+// split-fp16 (3 x fp16 MFMA, fp32-class accuracy) variant for 3x3 / dilation 1 layers
+bool conv_f16x3_eligible(int Cin, int Cout, int k, int pad, int dil);
+int conv_f16x3_init_attributes();
+int launch_conv_f16x3_group(const ConvArgs* as, int n, hipStream_t s);
+size_t split16_conv_weight_halfs(int Cout, int Cin, int k);
+void pack_conv_weights_split16(const float* w, int Cout, int Cin, int k, void* dst);
 // host-side weight re-pack for the mfma kernel
 void pack_conv_weights(const float* w, int Cout, int Cin, int k, float* dst);
 size_t packed_conv_weight_floats(int Cout, int Cin, int k);

@@ -15,6 +15,20 @@ from tests import helpers as H
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(autouse=True, params=["fp32", "f16x3"])
+def conv_mode(request):
+    """Every test runs with the exact fp32 MFMA convs and with the split-fp16 MFMA convs
+    (C ABI shf_net_set_conv_mode / SHF_CONV_MODE): both must meet the same parity bars."""
+    import os
+    old = os.environ.get("SHF_CONV_MODE")
+    os.environ["SHF_CONV_MODE"] = "1" if request.param == "f16x3" else "0"
+    yield request.param
+    if old is None:
+        os.environ.pop("SHF_CONV_MODE", None)
+    else:
+        os.environ["SHF_CONV_MODE"] = old
+
 ACT_TOL = 2e-5
 SCORE_TOL = 1e-4
 BOX_TOL = 1e-3
@@ -297,3 +311,46 @@ def test_detect_driver_vs_fused_vs_oracle():
     assert abs(len(gd[0]) - len(od[0])) <= max(2, 0.02 * len(od[0]))
     n = min(len(gd[0]), len(od[0]))
     assert np.abs(gd[0][:n, 4] - od[0][:n, 4]).max() < SCORE_TOL * 5 or n == 0
+
+
+def test_c1_512_level_vs_oracle(conv_mode):
+    """BASELINE config 1 (512x512 level, the reference's CPU-runnable case) against the oracle net:
+    every fg/bg score of the 12 288 anchors within 1e-4, deltas within 1e-3, same proposal count."""
+    msg = H.detector_msg(True)
+    gnet, onet = H.make_pair(msg)
+    data = H.synth_image_blob(512, 512, seed=21)
+    info = np.array([[512, 512, 1.0]], np.float32)
+    go, oo = H.run_both(gnet, onet, data, info)
+    gp, op = gnet.blobs["cls_prob_reshape_output"].data, onet.blobs["cls_prob_reshape_output"].data
+    assert gp.shape == (1, 6, 64, 64)
+    err = float(np.abs(gp - op).max())
+    assert err < SCORE_TOL, (conv_mode, err)
+    assert np.abs(gnet.blobs["bbox_pred_output"].data - onet.blobs["bbox_pred_output"].data).max() < 1e-3
+    assert H.rel_err(gnet.blobs["conv5_3"].data, onet.blobs["conv5_3"].data) < 5e-5
+    assert abs(len(go["boxes"]) - len(oo["boxes"])) <= max(2, 0.01 * len(oo["boxes"]))
+    n = min(len(go["boxes"]), len(oo["boxes"]))
+    assert np.abs(go["cls_prob"][:n, 1] - oo["cls_prob"][:n, 1]).max() < SCORE_TOL
+
+
+def test_split_fp16_vs_fp32_on_the_bench_pyramid_level():
+    """Property at a full-size level (1008x1008, oracle too slow): the two conv arithmetics agree
+    far inside the 1e-4 score bar on every anchor."""
+    import os
+    msg = H.detector_msg(True)
+    data = H.synth_image_blob(1008, 1008, seed=5)
+    info = np.array([[1000, 1000, 0.9765625]], np.float32)
+    res = []
+    from smallhardface_amd import weights
+    params = weights.synth_params(msg)
+    for mode in ("fp32", "f16x3"):
+        from smallhardface_amd import caffe
+        net = caffe.Net(None, prototxt_text=P.dumps(msg))
+        H.load_params(net, params)
+        net.set_conv_mode(mode)
+        net.blobs['data'].reshape(*data.shape)
+        net.blobs['im_info'].reshape(1, 3)
+        out = net.forward(data=data, im_info=info)
+        res.append((net.blobs["cls_prob_reshape_output"].data.copy(), out["boxes"].copy(), out["cls_prob"].copy()))
+    d = float(np.abs(res[0][0] - res[1][0]).max())
+    assert d < 2e-5, d
+    assert abs(len(res[0][1]) - len(res[1][1])) <= 2
