@@ -261,50 +261,65 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_f32_kernel(ConvK p) {
 // ---------------------------------------------------------------------------
 // First layer (tiny Cin, HBM-bound): NCHW input -> NHWC output, direct FMA.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict__ in, const float* __restrict__ w,
+// lane = pixel, wave = group of 16 output channels: the weights of a wave are uniform, so hipcc
+// keeps them in SGPRs (s_load + v_fma with a scalar operand: no LDS traffic at all); the 64x64
+// output tile is transposed through LDS so that every store instruction writes whole 256-B pixels.
+// FAST: the detector's conv1_1 geometry (Cin 3, 3x3, pad 1, dilation 1) as compile-time constants,
+// so the 27 taps are fully unrolled and their scalar weight loads are scheduled ahead.
+template <bool FAST>
+__global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict__ in, const float* __restrict__ wt,
                                                           const float* __restrict__ bias, float* __restrict__ out,
-                                                          int B, int H, int W, int Cin, int Cout, int k, int dil,
-                                                          int pad, int relu, int out_stride) {
-  extern __shared__ __attribute__((aligned(16))) float ws[];  // [Cin*k*k][Cout]
-  const int K = Cin * k * k;
-  for (int idx = threadIdx.x; idx < K * Cout; idx += 256) {
-    const int co = idx / K, r = idx - co * K;  // w is (Cout, Cin*k*k)
-    ws[r * Cout + co] = w[idx];
-  }
-  __syncthreads();
-  const int groups = Cout / 16;
-  const int ppb = 256 / groups;
-  const int cg = threadIdx.x % groups;
-  const long long P = (long long)blockIdx.x * ppb + threadIdx.x / groups;
+                                                          int B, int H, int W, int Cin_, int Cout, int k_, int dil_,
+                                                          int pad_, int relu, int out_stride) {
+  const int Cin = FAST ? 3 : Cin_, k = FAST ? 3 : k_, dil = FAST ? 1 : dil_, pad = FAST ? 1 : pad_;
+  extern __shared__ __attribute__((aligned(16))) float tile[];  // [64][Cout + 4]
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int pitch = Cout + 4;
+  const int ngroups = Cout / 16;
+  const int c4n = Cout / 4;
   const long long total = (long long)B * H * W;
-  if (threadIdx.x / groups >= ppb || P >= total) return;
-  const int x = (int)(P % W);
-  const int y = (int)((P / W) % H);
-  const int b = (int)(P / ((long long)W * H));
-  float acc[16];
+  for (long long P0 = (long long)blockIdx.x * 64; P0 < total; P0 += (long long)gridDim.x * 64) {
+    const long long P = P0 + lane;
+    const bool valid = P < total;
+    const int x = (int)(P % W);
+    const int y = (int)((P / W) % H);
+    const int b = (int)(P / ((long long)W * H));
+    for (int g = wave; g < ngroups; g += 4) {
+      float acc[16];
 #pragma unroll
-  for (int j = 0; j < 16; ++j) acc[j] = bias ? bias[cg * 16 + j] : 0.f;
-  for (int c = 0; c < Cin; ++c)
-    for (int ky = 0; ky < k; ++ky) {
-      const int iy = y - pad + ky * dil;
-      for (int kx = 0; kx < k; ++kx) {
-        const int ix = x - pad + kx * dil;
-        float v = 0.f;
-        if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
-          v = in[((size_t)(b * Cin + c) * H + iy) * W + ix];
-        const float* wr = ws + ((c * k + ky) * k + kx) * Cout + cg * 16;
+      for (int j = 0; j < 16; ++j) acc[j] = bias ? bias[g * 16 + j] : 0.f;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) acc[j] = fmaf(v, wr[j], acc[j]);
+      for (int c = 0; c < Cin; ++c)
+#pragma unroll
+        for (int ky = 0; ky < k; ++ky) {
+          const int iy = y - pad + ky * dil;
+#pragma unroll
+          for (int kx = 0; kx < k; ++kx) {
+            const int ix = x - pad + kx * dil;
+            float v = 0.f;
+            if (valid && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+              v = in[((size_t)(b * Cin + c) * H + iy) * W + ix];
+            const float* wr = wt + (size_t)((c * k + ky) * k + kx) * Cout + g * 16;  // wave-uniform
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[j] = fmaf(v, wr[j], acc[j]);
+          }
+        }
+#pragma unroll
+      for (int j = 0; j < 16; j += 4) {
+        float4 v = make_float4(acc[j], acc[j + 1], acc[j + 2], acc[j + 3]);
+        if (relu) {
+          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        }
+        *(float4*)(tile + lane * pitch + g * 16 + j) = v;
       }
     }
-  float* o = out + (size_t)P * out_stride + cg * 16;
-#pragma unroll
-  for (int j = 0; j < 16; j += 4) {
-    float4 v = make_float4(acc[j], acc[j + 1], acc[j + 2], acc[j + 3]);
-    if (relu) {
-      v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 64 * c4n; idx += 256) {
+      const int pix = idx / c4n, c4 = idx - pix * c4n;
+      if (P0 + pix < total)
+        *(float4*)(out + (size_t)(P0 + pix) * out_stride + c4 * 4) = *(const float4*)(tile + pix * pitch + c4 * 4);
     }
-    *(float4*)(o + j) = v;
+    __syncthreads();
   }
 }
 
@@ -458,13 +473,19 @@ int launch_conv_mfma(const ConvArgs& a, hipStream_t s) { return launch_conv_mfma
 
 int launch_conv_first(const float* in_nchw, const ConvArgs& a, hipStream_t s) {
   const int Cin = a.in.C, Cout = a.out.C;
-  if (Cout % 16 || 256 % (Cout / 16)) { set_error("conv_first: unsupported Cout"); return -1; }
-  const int ppb = 256 / (Cout / 16);
+  if (Cout % 16 || !a.wfirst) { set_error("conv_first: Cout must be a multiple of 16 (transposed weights required)"); return -1; }
   const long long total = (long long)a.in.B * a.in.H * a.in.W;
-  const size_t lds = (size_t)Cin * a.k * a.k * Cout * sizeof(float);
-  hipLaunchKernelGGL(conv_first_kernel, dim3((unsigned)((total + ppb - 1) / ppb)), dim3(256), lds, s, in_nchw,
-                     a.wraw, a.bias, a.out.p + a.out.coff, a.in.B, a.in.H, a.in.W, Cin, Cout, a.k, a.dil, a.pad,
-                     a.relu, a.out.cstride);
+  const size_t lds = (size_t)64 * (Cout + 4) * sizeof(float);
+  long long blocks = (total + 63) / 64;
+  if (blocks > 256 * 8) blocks = 256 * 8;  // persistent blocks, grid-stride over 64-pixel groups
+  if (Cin == 3 && a.k == 3 && a.dil == 1 && a.pad == 1)
+    hipLaunchKernelGGL(conv_first_kernel<true>, dim3((unsigned)blocks), dim3(256), lds, s, in_nchw, a.wfirst, a.bias,
+                       a.out.p + a.out.coff, a.in.B, a.in.H, a.in.W, Cin, Cout, a.k, a.dil, a.pad, a.relu,
+                       a.out.cstride);
+  else
+    hipLaunchKernelGGL(conv_first_kernel<false>, dim3((unsigned)blocks), dim3(256), lds, s, in_nchw, a.wfirst, a.bias,
+                       a.out.p + a.out.coff, a.in.B, a.in.H, a.in.W, Cin, Cout, a.k, a.dil, a.pad, a.relu,
+                       a.out.cstride);
   SHF_HIP_OK(hipGetLastError());
   return 0;
 }

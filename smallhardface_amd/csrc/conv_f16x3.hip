@@ -20,6 +20,7 @@
 // [hi: 32 halfs][lo: 32 halfs][16 B pad] = 144 B (conflict-free ds_read_b128).
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 
 #include "conv_common.h"
 
@@ -28,6 +29,13 @@ namespace shf {
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#ifndef F16X3_DMA_LATE
+#define F16X3_DMA_LATE 1   // 1: the early-finishing waves 0-3 issue the next stage's weight DMA after their MFMAs
+#endif
+#ifndef F16X3_CONV_MID
+#define F16X3_CONV_MID 1   // 1: split the next halo tile to fp16 hi/lo in the middle of the last stage's MFMAs
+#endif
 
 namespace f16x3 {
 constexpr int KC = 32;      // input channels per chunk
@@ -97,19 +105,10 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_kernel(ConvK p) {
   const int nchunks = p.Cin / KC;
   const int NST = nchunks * 3;  // stages
   const _Float16* wsp = (const _Float16*)p.wp;
-  // weights: [chunk][ky][kx][cout][hi 32 | lo 32] halfs
-  const size_t slab = (size_t)p.Cout * 64;        // halfs per (chunk,ky,kx)
-  const _Float16* wbase = wsp + (size_t)ct * BN * 64;
+  // weights: [chunk][ky][kx][cout][hi 32 | lo 32 | 8 pad] halfs = the LDS row image (144 B)
+  const size_t slab = (size_t)p.Cout * 72;        // halfs per (chunk,ky,kx)
+  const _Float16* wbase = wsp + (size_t)ct * BN * 72;
 
-  // per-thread weight piece geometry (stage-invariant)
-  int wg_off[NBP], wl_off[NBP];
-#pragma unroll
-  for (int j = 0; j < NBP; ++j) {
-    const int idx = tid + 512 * j;
-    const int sl = idx / (BN * 8), r = (idx >> 3) % BN, q = idx & 7;
-    wg_off[j] = sl * (int)slab + r * 64 + q * 8;            // halfs
-    wl_off[j] = (sl * BN + r) * ROWB + q * 16;              // bytes
-  }
   // per-thread halo piece geometry (chunk-invariant)
   int a_goff[ALD], a_loff[ALD];
 #pragma unroll
@@ -123,42 +122,38 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_kernel(ConvK p) {
     a_loff[j] = (idx < HP * 8) ? hp * ROWB + q * 8 : -1;
   }
   float4 areg[ALD];
-  // staged weights are loop-carried -> named scalars (a local array would live in scratch)
-  uint4 w0, w1, w2, w3 = make_uint4(0, 0, 0, 0), w4 = make_uint4(0, 0, 0, 0), w5 = make_uint4(0, 0, 0, 0);
-
-#define F16X3_LOAD_W(STAGE)                                                   \
-  {                                                                           \
-    const _Float16* ws_ = wbase + (size_t)(STAGE) * 3 * slab;                 \
-    w0 = *(const uint4*)(ws_ + wg_off[0]);                                    \
-    w1 = *(const uint4*)(ws_ + wg_off[1]);                                    \
-    w2 = *(const uint4*)(ws_ + wg_off[2]);                                    \
-    if constexpr (NBP == 6) {                                                 \
-      w3 = *(const uint4*)(ws_ + wg_off[3]);                                  \
-      w4 = *(const uint4*)(ws_ + wg_off[4]);                                  \
-      w5 = *(const uint4*)(ws_ + wg_off[5]);                                  \
-    }                                                                         \
-  }
-#define F16X3_STORE_W(BUF)                                                    \
-  {                                                                           \
-    unsigned char* bd_ = Bs + (BUF) * (3 * BN * ROWB);                        \
-    *(uint4*)(bd_ + wl_off[0]) = w0;                                          \
-    *(uint4*)(bd_ + wl_off[1]) = w1;                                          \
-    *(uint4*)(bd_ + wl_off[2]) = w2;                                          \
-    if constexpr (NBP == 6) {                                                 \
-      *(uint4*)(bd_ + wl_off[3]) = w3;                                        \
-      *(uint4*)(bd_ + wl_off[4]) = w4;                                        \
-      *(uint4*)(bd_ + wl_off[5]) = w5;                                        \
-    }                                                                         \
+  half4 ahi[ALD], alo[ALD];
+  // Weight slabs go global -> LDS by DMA (global_load_lds_dwordx4: no registers, no ds_write): the
+  // packed global layout already has the padded 144-B rows, so a stage (3 slabs of the block's BN
+  // couts) is 3 contiguous runs copied in 1-KiB pieces, one piece per wave-instruction.
+  constexpr int SLAB_B = BN * ROWB;            // bytes per slab in LDS and in global
+  constexpr int PCS_SLAB = SLAB_B / 1024;      // 18 (BN=128) or 9 (BN=64)
+  constexpr int PCS = 3 * PCS_SLAB;
+  static_assert(SLAB_B % 1024 == 0, "slab must be whole DMA pieces");
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+#define F16X3_DMA_W(STAGE, BUF, NWAVES)                                                              \
+  {                                                                                                  \
+    const unsigned char* ws_ = (const unsigned char*)(wbase + (size_t)(STAGE) * 3 * slab);           \
+    unsigned char* bd_ = Bs + (BUF) * (3 * SLAB_B);                                                  \
+    _Pragma("unroll") for (int j = 0; j < (PCS + (NWAVES) - 1) / (NWAVES); ++j) {                    \
+      const int pc = wave_u + (NWAVES) * j;                                                          \
+      if (pc < PCS) {                                                                                \
+        const int sl = pc / PCS_SLAB, within = pc - sl * PCS_SLAB;                                   \
+        const unsigned char* src = ws_ + (size_t)sl * slab * 2 + within * 1024 + lane * 16;          \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,         \
+                                         (__attribute__((address_space(3))) void*)(bd_ + pc * 1024), 16, 0, 0); \
+      }                                                                                              \
+    }                                                                                                \
   }
 
-  // prologue: halo(0), W(0) into LDS; W(1) in flight
+  // prologue: halo(0) and W(0) into LDS
   {
     const float* inc_ = gin;
 #pragma unroll
     for (int j = 0; j < ALD; ++j)
       areg[j] = (a_goff[j] >= 0) ? *(const float4*)(inc_ + a_goff[j]) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
-  F16X3_LOAD_W(0);
+  F16X3_DMA_W(0, 0, 8);
 #pragma unroll
   for (int j = 0; j < ALD; ++j)
     if (a_loff[j] >= 0) {
@@ -167,14 +162,24 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_kernel(ConvK p) {
       *(half4*)(As + a_loff[j]) = hi;
       *(half4*)(As + a_loff[j] + 64) = lo;
     }
-  F16X3_STORE_W(0);
-  if (NST > 1) F16X3_LOAD_W(1);
 
   int c = 0, ky = 0;
+#ifdef SHF_CONV_TIMING
+  unsigned long long tb = 0, ti = 0, tc = 0, tx = 0, t0, t1, t2, t3;
+#define SHF_T(x) x = __builtin_amdgcn_s_memtime()
+#else
+#define SHF_T(x)
+#endif
   for (int st = 0; st < NST; ++st) {
+    SHF_T(t0);
+    // LDS-DMA is only ordered by the issuing wave's own vmcnt: drain it by hand before the barrier
+    // (hipcc drops this wait when the DMA sits behind the loop back-edge / in a wave-uniform branch)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (st + 1 < NST) F16X3_STORE_W((st + 1) & 1);
-    if (st + 2 < NST) F16X3_LOAD_W(st + 2);
+    SHF_T(t1);
+#if !F16X3_DMA_LATE
+    if (st + 1 < NST) F16X3_DMA_W(st + 1, (st + 1) & 1, 8);
+#endif
     const bool last_row = (ky == 2);
     const bool more_chunks = (c + 1 < nchunks);
     if (last_row && more_chunks) {
@@ -183,6 +188,7 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_kernel(ConvK p) {
       for (int j = 0; j < ALD; ++j)
         areg[j] = (a_goff[j] >= 0) ? *(const float4*)(inc_ + a_goff[j]) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    SHF_T(t2);
     const unsigned char* Arow = As + (ky * HTW) * ROWB;
     const unsigned char* Bst = Bs + (st & 1) * (3 * BN * ROWB);
 #pragma unroll
@@ -211,17 +217,33 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_kernel(ConvK p) {
             accc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[tm], bh[tn], accc[tm][tn], 0, 0, 0);
           }
       }
+      if (F16X3_CONV_MID && kx == 1 && last_row && more_chunks) {
+        // split the next chunk's halo (loaded at the top of this stage) while the matrix pipe drains
+#pragma unroll
+        for (int j = 0; j < ALD; ++j) split4(areg[j], ahi[j], alo[j]);
+      }
     }
+    // The waves of the first half finish their MFMAs early (they win the matrix-pipe arbitration
+    // against their SIMD partners of the second half), so they feed the DMA engine for the next
+    // stage from that slack instead of every wave paying the issue cost before its MFMAs.
+#if F16X3_DMA_LATE
+    if (wave_u < 4 && st + 1 < NST) F16X3_DMA_W(st + 1, (st + 1) & 1, 4);
+#endif
+#ifdef SHF_CONV_TIMING
+    asm volatile("s_nop 0" ::: "memory");
+    SHF_T(t3);
+    tb += t1 - t0; ti += t2 - t1; tc += t3 - t2;
+#endif
     if (last_row) {
       if (more_chunks) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();  // every wave is done reading the halo tile of chunk c
 #pragma unroll
         for (int j = 0; j < ALD; ++j)
           if (a_loff[j] >= 0) {
-            half4 hi, lo;
-            split4(areg[j], hi, lo);
-            *(half4*)(As + a_loff[j]) = hi;
-            *(half4*)(As + a_loff[j] + 64) = lo;
+            if (!F16X3_CONV_MID) split4(areg[j], ahi[j], alo[j]);
+            *(half4*)(As + a_loff[j]) = ahi[j];
+            *(half4*)(As + a_loff[j] + 64) = alo[j];
           }
       }
       ky = 0;
@@ -229,9 +251,18 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_kernel(ConvK p) {
     } else {
       ++ky;
     }
+#ifdef SHF_CONV_TIMING
+    SHF_T(t0);
+    tx += t0 - t3;
+#endif
   }
-#undef F16X3_LOAD_W
-#undef F16X3_STORE_W
+#ifdef SHF_CONV_TIMING
+  if (p.dbg && lane == 0 && (bid == 0 || bid == 100)) {
+    unsigned long long* d = p.dbg + ((bid ? 1 : 0) * 8 + wave) * 5;
+    d[0] = tb; d[1] = ti; d[2] = tc; d[3] = tx; d[4] = NST;
+  }
+#endif
+#undef F16X3_DMA_W
 
   // epilogue: C row = (r&3) + 8*(r>>2) + 4*(lane>>5), C col = lane&31
 #pragma unroll
@@ -259,19 +290,20 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_kernel(ConvK p) {
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
-size_t split16_conv_weight_halfs(int Cout, int Cin, int k) { return (size_t)Cout * Cin * k * k * 2; }
+size_t split16_conv_weight_halfs(int Cout, int Cin, int k) { return (size_t)Cout * (Cin / 32) * k * k * 72; }
 
-// (Cout,Cin,3,3) fp32 -> [Cin/32][ky][kx][Cout][hi 32 | lo 32] fp16
+// (Cout,Cin,3,3) fp32 -> [Cin/32][ky][kx][Cout][hi 32 | lo 32 | 8 pad] fp16 (144-B rows = the LDS image)
 void pack_conv_weights_split16(const float* w, int Cout, int Cin, int k, void* dst_) {
   _Float16* dst = (_Float16*)dst_;
   const int taps = k * k;
+  memset(dst_, 0, split16_conv_weight_halfs(Cout, Cin, k) * 2);
   for (int co = 0; co < Cout; ++co)
     for (int ci = 0; ci < Cin; ++ci)
       for (int t = 0; t < taps; ++t) {
         const float x = w[((size_t)co * Cin + ci) * taps + t];
         const _Float16 h = (_Float16)x;
         const _Float16 l = (_Float16)((x - (float)h) * f16x3::LO_SCALE);
-        const size_t row = (((size_t)(ci / 32) * taps + t) * Cout + co) * 64;
+        const size_t row = (((size_t)(ci / 32) * taps + t) * Cout + co) * 72;
         dst[row + (ci % 32)] = h;
         dst[row + 32 + (ci % 32)] = l;
       }
@@ -312,8 +344,26 @@ static int launch_f16x3_t(const ConvArgs* as, int n, hipStream_t s) {
     tiles += (long long)m.tiles_per_img * m.B;
   }
   const size_t lds = (size_t)HP * ROWB + 2 * 3 * (size_t)BN * ROWB;
+#ifdef SHF_CONV_TIMING
+  static unsigned long long* dbg_dev = nullptr;
+  if (!dbg_dev) hipMalloc((void**)&dbg_dev, 16 * 5 * 8);
+  hipMemset(dbg_dev, 0, 16 * 5 * 8);
+  p.dbg = dbg_dev;
+#endif
   hipLaunchKernelGGL((conv_mfma_f16x3_kernel<BN>), dim3((unsigned)(tiles * p.nct)), dim3(512), lds, s, p);
   SHF_HIP_OK(hipGetLastError());
+#ifdef SHF_CONV_TIMING
+  {
+    unsigned long long h[80];
+    hipStreamSynchronize(s);
+    hipMemcpy(h, dbg_dev, sizeof(h), hipMemcpyDeviceToHost);
+    for (int w = 0; w < 16; w += 3)
+      if (h[w * 5 + 4])
+        fprintf(stderr, "[f16x3 timing] blk%d wave%d stages %llu: per-stage cycles barrier %.0f issue %.0f compute %.0f tail %.0f\n",
+                w / 8 ? 100 : 0, w % 8, h[w * 5 + 4], (double)h[w * 5] / h[w * 5 + 4], (double)h[w * 5 + 1] / h[w * 5 + 4],
+                (double)h[w * 5 + 2] / h[w * 5 + 4], (double)h[w * 5 + 3] / h[w * 5 + 4]);
+  }
+#endif
   return 0;
 }
 

@@ -87,7 +87,7 @@ struct HostBuf {
 struct ParamBlob {
   std::vector<int> shape;
   std::vector<float> host;
-  DevBuf raw, packed, packed16;
+  DevBuf raw, packed, packed16, first_t;
   bool dirty = true;
   size_t count() const {
     size_t c = 1;
@@ -858,6 +858,15 @@ void shf_net::commit_params(int li) {
     ParamBlob& p = *L.params[pi];
     p.raw.ensure(p.count() * 4);
     HIP_THROW(hipMemcpy(p.raw.p, p.host.data(), p.count() * 4, hipMemcpyHostToDevice));
+    if (pi == 0 && L.type == "Convolution" && L.kclass == 1) {
+      // first layer: (Cout, Cin*k*k) -> (Cin*k*k, Cout) so a wave's 16 output channels are one uniform run
+      const int co = p.shape[0], K = (int)(p.count() / p.shape[0]);
+      std::vector<float> t(p.count());
+      for (int o = 0; o < co; ++o)
+        for (int r = 0; r < K; ++r) t[(size_t)r * co + o] = p.host[(size_t)o * K + r];
+      p.first_t.ensure(t.size() * 4);
+      HIP_THROW(hipMemcpy(p.first_t.p, t.data(), t.size() * 4, hipMemcpyHostToDevice));
+    }
     if (pi == 0 && L.type == "Convolution" && L.kclass == 0 && !in_tail) {
       std::vector<float> packed(p.count());
       pack_conv_weights(p.host.data(), p.shape[0], p.shape[1], p.shape[2], packed.data());
@@ -918,6 +927,7 @@ void shf_net::forward_ops(bool fused_path, float im_h, float im_w, float im_scal
         a.bias = L.params.size() > 1 ? (const float*)L.params[1]->raw.p : nullptr;
         a.wraw = (const float*)L.params[0]->raw.p;
         a.wpacked = (const float*)L.params[0]->packed.p;
+        a.wfirst = (const float*)L.params[0]->first_t.p;
         const bool split16 = conv_mode == 1 && L.kclass == 0 && L.params[0]->packed16.p &&
                              conv_f16x3_eligible(ib.shape[1], L.nout, L.k, L.pad, L.dil);
         a.wsplit16 = split16 ? L.params[0]->packed16.p : nullptr;

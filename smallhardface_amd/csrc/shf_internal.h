@@ -29,6 +29,7 @@ struct ConvArgs {
   View in, out;
   const float* wpacked = nullptr;  // [Cin/32][k*k][Cout][32] (see pack_conv_weights)
   const float* wraw = nullptr;     // Caffe layout (Cout,Cin,k,k) for the direct kernels
+  const float* wfirst = nullptr;   // first layer: weights transposed to [Cin*k*k][Cout]
   const void* wsplit16 = nullptr;  // split-fp16 pack [Cin/32][tap][Cout][hi32|lo32] (conv_f16x3.hip)
   const float* bias = nullptr;     // [Cout] or null
   int k = 3, dil = 1, pad = 1;
