@@ -271,18 +271,9 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_kernel(ConvK p) {
     const float bv = p.bias ? p.bias[cout] : 0.f;
 #pragma unroll
     for (int tm = 0; tm < MT; ++tm) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * kh;
-        int dy2, px2;
-        row_to_pixel(row, dy2, px2);
-        const int gy = ty0 + wm * 2 * MT + tm * 2 + dy2, gx = tx0 + px2;
-        if (gy < H && gx < W) {
-          float v = accm[tm][tn][r] + accc[tm][tn][r] * LO_INV + bv;
-          if (p.relu & 1) v = fmaxf(v, 0.f);
-          gout[((size_t)(b * H + gy) * W + gx) * p.out_stride + cout] = v;
-        }
-      }
+      const f32x16 am = accm[tm][tn], ac = accc[tm][tn];
+      conv_store_tile([&](int r) { return am[r] + ac[r] * LO_INV; }, bv, p.relu, ty0 + wm * 2 * MT + tm * 2, tx0, kh,
+                      H, W, b, cout, gout, p.out_stride, mem.pool, p.pool_stride);
     }
   }
 }
@@ -322,7 +313,8 @@ static int launch_f16x3_t(const ConvArgs* as, int n, hipStream_t s) {
   p.bias = a.bias;
   p.Cin = a.in.C; p.Cout = a.out.C;
   p.in_stride = a.in.cstride; p.out_stride = a.out.cstride;
-  p.dil = 1; p.relu = a.relu;
+  p.dil = 1; p.relu = a.relu | (a.pool.p && !a.write_main ? 8 : 0);
+  p.pool_stride = a.pool.p ? a.pool.cstride : 0;
   p.nct = p.Cout / BN;
   p.nmem = n;
   p.dbg = nullptr;
@@ -337,6 +329,7 @@ static int launch_f16x3_t(const ConvArgs* as, int n, hipStream_t s) {
     ConvMember& m = p.m[i];
     m.in = q.in.p + q.in.coff;
     m.out = q.out.p + q.out.coff;
+    m.pool = q.pool.p ? q.pool.p + q.pool.coff : nullptr;
     m.B = q.in.B; m.H = q.in.H; m.W = q.in.W;
     m.tiles_x = (m.W + TW - 1) / TW;
     m.tiles_per_img = m.tiles_x * ((m.H + TH - 1) / TH);

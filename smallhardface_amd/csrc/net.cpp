@@ -126,6 +126,9 @@ struct Layer {
   // conv / deconv / pool hyper-parameters
   int k = 1, pad = 0, stride = 1, dil = 1, group = 1, nout = 0, relu = 0, bias_term = 1;
   int kclass = 0;
+  int fuse_pool = -1;      // conv: index of the 2x2/2 MAX pool folded into its epilogue (fused path only)
+  bool pool_only = false;  // conv: its un-pooled top has no other reader
+  int fused_into = -1;     // pool: index of the conv that produces it in the fused path
 };
 
 // the first 8 classes are the instantiations of conv_mfma_f32_kernel, named like rocprofv3 prints them
@@ -714,6 +717,26 @@ void shf_net::build(const std::string& text, const char* caffemodel) {
     if (L.type == "Convolution")
       L.kclass = conv_kernel_class(cin, L.nout, L.k, L.pad, L.dil, blobs[L.bottoms[0]].kind == BK_INPUT_NCHW);
   }
+  // ---- conv -> MAX 2x2/2 pool pairs that the fused (detect) path runs as one kernel
+  for (size_t li = 0; li < layers.size(); ++li) {
+    Layer& P = layers[li];
+    if (P.op != OP_POOL || P.k != 2 || P.stride != 2 || P.pad != 0) continue;
+    const int x = P.bottoms[0];
+    int prod = -1, others = 0;
+    for (size_t lj = 0; lj < layers.size(); ++lj) {
+      if (lj == li) continue;
+      Layer& Q = layers[lj];
+      if (Q.type == "Convolution" && !Q.tops.empty() && Q.tops[0] == x) prod = (int)lj;
+      if (Q.op == OP_SKIP && Q.type == "ReLU") continue;  // the in-place ReLU is part of the conv
+      for (int bb : Q.bottoms)
+        if (bb == x) ++others;
+    }
+    if (prod < 0 || layers[prod].op != OP_CONV || layers[prod].kclass != 0 || !layers[prod].relu) continue;
+    if (blobs[x].owner >= 0 || blobs[P.tops[0]].owner >= 0) continue;
+    layers[prod].fuse_pool = (int)li;
+    layers[prod].pool_only = (others == 0);
+    P.fused_into = prod;
+  }
   alloc_buffers();
   if (clone_src) {
     wgen = clone_src->wgen;
@@ -928,6 +951,10 @@ void shf_net::forward_ops(bool fused_path, float im_h, float im_w, float im_scal
         a.wraw = (const float*)L.params[0]->raw.p;
         a.wpacked = (const float*)L.params[0]->packed.p;
         a.wfirst = (const float*)L.params[0]->first_t.p;
+        if (fused_path && L.fuse_pool >= 0) {
+          a.pool = view_of(layers[L.fuse_pool].tops[0]);
+          a.write_main = L.pool_only ? 0 : 1;
+        }
         const bool split16 = conv_mode == 1 && L.kclass == 0 && L.params[0]->packed16.p &&
                              conv_f16x3_eligible(ib.shape[1], L.nout, L.k, L.pad, L.dil);
         a.wsplit16 = split16 ? L.params[0]->packed16.p : nullptr;
@@ -957,6 +984,7 @@ void shf_net::forward_ops(bool fused_path, float im_h, float im_w, float im_scal
         break;
       }
       case OP_POOL: {
+        if (fused_path && L.fused_into >= 0) break;  // done by the producing conv's epilogue
         ProfScope ps(pf, st, PC_POOL, 0, 4.0 * (blobs[L.bottoms[0]].count() + blobs[L.tops[0]].count()));
         CHECK_RC(launch_maxpool(view_of(L.bottoms[0]), view_of(L.tops[0]), L.k, L.stride, L.pad, st));
         break;

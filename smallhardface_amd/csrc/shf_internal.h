@@ -34,6 +34,8 @@ struct ConvArgs {
   const float* bias = nullptr;     // [Cout] or null
   int k = 3, dil = 1, pad = 1;
   int relu = 0;
+  View pool;           // optional fused MAX 2x2/2 pool output (p == nullptr: none)
+  int write_main = 1;  // 0: the un-pooled output has no other reader and is not written
 };
 // which kernel class a conv will use: 0 = mfma implicit GEMM, 1 = first-layer direct (NCHW in), 2 = generic direct
 int conv_kernel_class(int Cin, int Cout, int k, int pad, int dil, bool in_nchw);
