@@ -377,6 +377,7 @@ struct shf_net {
   shf_net* clone_src = nullptr;     // lanes share the parameter tensors of the net they were cloned from
   std::shared_ptr<int> wgen = std::make_shared<int>(0);  // bumped by every param commit
   int tail_gen = -1;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   int conv_mode = 0;  // 0: exact fp32 MFMA everywhere; 1: split-fp16 MFMA for the 3x3 / dilation-1 layers
   TailWork tw;
   DevBuf tw_logits, tw_rec, tw_keys, tw_counters;
@@ -392,6 +393,8 @@ struct shf_net {
   bool use_blob_im_info = true;
 
   ~shf_net() {
+    if (ev_fork) (void)hipEventDestroy(ev_fork);
+    if (ev_join) (void)hipEventDestroy(ev_join);
     if (stream) {
       (void)hipStreamSynchronize(stream);
       (void)hipStreamDestroy(stream);
@@ -1365,6 +1368,23 @@ int shf_detect_add_levels(shf_net* net, int n, shf_net** members, const float* c
         const int pc = conv_prof_class(L.k, L.dil, L.nout);
         ProfScope ps(net->prof, net->stream, pc, fl, by);
         CHECK_RC(launch_conv_mfma_group(group.data(), n, net->stream));
+      }
+    } else if (L.op == OP_TAIL && n > 1) {
+      // The detection tail of a unit is a chain of ~8 tiny dependent launches (logits, decode, sort
+      // stages, gather): latency-bound.  Fan the units out over their lanes' own streams so the
+      // chains overlap, and join back on the primary stream.
+      if (!net->ev_fork) HIP_THROW(hipEventCreateWithFlags(&net->ev_fork, hipEventDisableTiming));
+      HIP_THROW(hipEventRecord(net->ev_fork, net->stream));
+      for (int m = 0; m < n; ++m) {
+        shf_net* mb = members[m];
+        if (mb->stream != net->stream) HIP_THROW(hipStreamWaitEvent(mb->stream, net->ev_fork, 0));
+        mb->forward_ops(true, (float)im_h[m], (float)im_w[m], im_scale[m], mb->stream,
+                        mb->stream == net->stream ? &net->prof : &mb->prof, (int)li, nullptr);
+        if (mb->stream != net->stream) {
+          if (!mb->ev_join) HIP_THROW(hipEventCreateWithFlags(&mb->ev_join, hipEventDisableTiming));
+          HIP_THROW(hipEventRecord(mb->ev_join, mb->stream));
+          HIP_THROW(hipStreamWaitEvent(net->stream, mb->ev_join, 0));
+        }
       }
     } else {
       for (int m = 0; m < n; ++m)
