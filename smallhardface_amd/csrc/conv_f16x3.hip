@@ -208,14 +208,34 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_kernel(ConvK p) {
           bh[t] = *(const half8*)(Bp + b_off[t] + kk * 32);
           bl[t] = *(const half8*)(Bp + b_off[t] + kk * 32 + 64);
         }
+        if constexpr (MT == 1) {
+        // three passes over the tiles so that consecutive MFMAs never chain on one accumulator
+  #pragma unroll
+          for (int tm = 0; tm < MT; ++tm)
+  #pragma unroll
+            for (int tn = 0; tn < 2; ++tn)
+              accm[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tm], bh[tn], accm[tm][tn], 0, 0, 0);
+  #pragma unroll
+          for (int tm = 0; tm < MT; ++tm)
+  #pragma unroll
+            for (int tn = 0; tn < 2; ++tn)
+              accc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tm], bl[tn], accc[tm][tn], 0, 0, 0);
+  #pragma unroll
+          for (int tm = 0; tm < MT; ++tm)
+  #pragma unroll
+            for (int tn = 0; tn < 2; ++tn)
+              accc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[tm], bh[tn], accc[tm][tn], 0, 0, 0);
+        } else {
+          // with 4 output tiles per wave hipcc's own interleave of the tile-major order measured faster
 #pragma unroll
-        for (int tm = 0; tm < MT; ++tm)
+          for (int tm = 0; tm < MT; ++tm)
 #pragma unroll
-          for (int tn = 0; tn < 2; ++tn) {
-            accm[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tm], bh[tn], accm[tm][tn], 0, 0, 0);
-            accc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tm], bl[tn], accc[tm][tn], 0, 0, 0);
-            accc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[tm], bh[tn], accc[tm][tn], 0, 0, 0);
-          }
+            for (int tn = 0; tn < 2; ++tn) {
+              accm[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tm], bh[tn], accm[tm][tn], 0, 0, 0);
+              accc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tm], bl[tn], accc[tm][tn], 0, 0, 0);
+              accc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[tm], bh[tn], accc[tm][tn], 0, 0, 0);
+            }
+        }
       }
       if (F16X3_CONV_MID && kx == 1 && last_row && more_chunks) {
         // split the next chunk's halo (loaded at the top of this stage) while the matrix pipe drains
