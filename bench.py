@@ -175,7 +175,10 @@ def main():
 
     def step():
         if world == 1:
-            last[0] = fd.detect(unit_list, thresh, on_device=True)[0]
+            # two images in flight: image k's box merging / read-back overlaps image k+1's convolutions
+            fd.submit(unit_list, thresh, on_device=True)
+            if fd.pending() > 1:
+                last[0] = fd.collect()[0]
             return
         # this rank's 10 units (one of each kind, from different images) as ONE grouped pass;
         # every lane keeps the detections of its unit, which are then routed to the unit's image
@@ -198,7 +201,9 @@ def main():
             last[i] = net.detect_finish(cfg.TEST.NMS_METHOD, cfg.TEST.NMS_THRESH)
 
     def fence():
-        for ln in lanes:
+        while world == 1 and fd.pending() > 0:
+            last[0] = fd.collect()[0]
+        for ln in lanes + getattr(fd, "_heads", []):
             ln.sync()
         torch.cuda.synchronize()
         if dist is not None:
@@ -209,7 +214,7 @@ def main():
         step()
     fence()
     if not args.no_events:
-        for ln in lanes:
+        for ln in lanes + getattr(fd, "_heads", []):
             ln.prof_enable(True)
             ln.prof_reset()
     t0 = time.perf_counter()
@@ -219,7 +224,7 @@ def main():
     elapsed = time.perf_counter() - t0
     prof = {}
     if not args.no_events:
-        for ln in lanes:
+        for ln in lanes + getattr(fd, "_heads", []):
             for k, v in ln.prof_read().items():
                 a = prof.setdefault(k, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
                 for f in a:

@@ -107,6 +107,12 @@ int shf_detect_add_levels(shf_net* net, int n, shf_net** members, const float* c
                           int data_on_device, const int* H, const int* W, const int* im_h,
                           const int* im_w, const float* im_scale, const int* flip, float thresh,
                           int per_member_lists);
+/* Cross-lane ordering for software-pipelining images over two head lanes: record marks the
+ * current end of `net`'s stream; wait makes `net`'s stream wait for `other`'s last mark (e.g. the
+ * next image's convolutions, which reuse the member lanes' buffers, wait for the previous
+ * image's appends while its box merging still runs). */
+int shf_net_record_event(shf_net* net);
+int shf_net_wait_event(shf_net* net, shf_net* other);
 /* Box merging for the image (test.py:168-175): method 0 = BBOX_VOTE (test.py:181),
  * 1 = NMS (lib/nms).  out5 rows are (x1,y1,x2,y2,score) as double (bbox_vote
  * returns float64).  *n_out = number of rows (may exceed cap; only cap written). */

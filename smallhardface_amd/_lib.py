@@ -86,6 +86,8 @@ def _declare(lib):
         "shf_net_forward": (ci, [vp]),
         "shf_net_set_proposal_cfg": (ci, [vp, ci, cf, cf]),
         "shf_net_set_conv_mode": (ci, [vp, ci]),
+        "shf_net_record_event": (ci, [vp]),
+        "shf_net_wait_event": (ci, [vp, vp]),
         "shf_detect_begin": (ci, [vp]),
         "shf_detect_add_level": (ci, [vp, vp, ci, ci, ci, ci, ci, cf, ci, cf]),
         "shf_detect_add_levels": (ci, [vp, ci, C.POINTER(vp), C.POINTER(vp), ci, ip, ip, ip, ip, fp, ip, cf, ci]),

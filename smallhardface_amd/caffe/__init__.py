@@ -281,6 +281,12 @@ class Net(object):
                                                    ia(3), ia(4), sc, fl, float(thresh),
                                                    1 if per_member_lists else 0), "detect_add_levels")
 
+    def record_event(self):
+        _lib.check(self._lib.shf_net_record_event(self._h), "record_event")
+
+    def wait_event(self, other):
+        _lib.check(self._lib.shf_net_wait_event(self._h, other._h), "wait_event")
+
     def detect_count(self):
         n = self._lib.shf_detect_count(self._h)
         if n < 0:

@@ -377,7 +377,7 @@ struct shf_net {
   shf_net* clone_src = nullptr;     // lanes share the parameter tensors of the net they were cloned from
   std::shared_ptr<int> wgen = std::make_shared<int>(0);  // bumped by every param commit
   int tail_gen = -1;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_mark = nullptr;
   int conv_mode = 0;  // 0: exact fp32 MFMA everywhere; 1: split-fp16 MFMA for the 3x3 / dilation-1 layers
   TailWork tw;
   DevBuf tw_logits, tw_rec, tw_keys, tw_counters;
@@ -395,6 +395,7 @@ struct shf_net {
   ~shf_net() {
     if (ev_fork) (void)hipEventDestroy(ev_fork);
     if (ev_join) (void)hipEventDestroy(ev_join);
+    if (ev_mark) (void)hipEventDestroy(ev_mark);
     if (stream) {
       (void)hipStreamSynchronize(stream);
       (void)hipStreamDestroy(stream);
@@ -1257,6 +1258,21 @@ int shf_net_set_conv_mode(shf_net* net, int mode) {
     net->conv_mode = mode;
     for (size_t li = 0; li < net->layers.size(); ++li) net->commit_params((int)li);
   }
+  return 0;
+  API_END(-1)
+}
+
+int shf_net_record_event(shf_net* net) {
+  API_BEGIN
+  if (!net->ev_mark) HIP_THROW(hipEventCreateWithFlags(&net->ev_mark, hipEventDisableTiming));
+  HIP_THROW(hipEventRecord(net->ev_mark, net->stream));
+  return 0;
+  API_END(-1)
+}
+
+int shf_net_wait_event(shf_net* net, shf_net* other) {
+  API_BEGIN
+  if (other->ev_mark) HIP_THROW(hipStreamWaitEvent(net->stream, other->ev_mark, 0));
   return 0;
   API_END(-1)
 }

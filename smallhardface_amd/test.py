@@ -194,6 +194,36 @@ class FusedDetector(object):
         self.lanes = [net] + [net.clone() for _ in range(max(1, n_lanes) - 1)]
         self._xbuf = None
 
+    # -- software pipeline over images (group mode): the box merging + read-back of image k overlaps
+    #    the convolutions of image k+1.  Two head lanes own the image lists and streams; the member
+    #    lanes only lend activation buffers, so image k+1 waits for image k's appends, not its merge.
+    def submit(self, units, thresh=0.05, on_device=False):
+        units = list(units)
+        assert self.mode == "group" and len(units) <= 16
+        if not hasattr(self, "_heads"):
+            self._heads = [self.net.clone(), self.net.clone()]
+            self._turn = 0
+            self._inflight = []
+            while len(self.lanes) < len(units):
+                self.lanes.append(self.net.clone())
+        head = self._heads[self._turn]
+        prev = self._heads[1 - self._turn]
+        head.detect_begin()
+        head.wait_event(prev)  # the previous image has appended: the member buffers are free again
+        head.detect_add_levels(self.lanes[:len(units)], units, thresh, on_device=on_device)
+        head.record_event()
+        self._inflight.append(head)
+        self._turn = 1 - self._turn
+        return head
+
+    def collect(self):
+        """Detections of the oldest submitted image (blocks until its merge is done)."""
+        head = self._inflight.pop(0)
+        return [head.detect_finish(cfg.TEST.NMS_METHOD, cfg.TEST.NMS_THRESH)]
+
+    def pending(self):
+        return len(getattr(self, "_inflight", []))
+
     def detect(self, units, thresh=0.05, on_device=False):
         """``units``: list of (data, H, W, im_h, im_w, scale, flip); data = host array or device pointer."""
         units = list(units)

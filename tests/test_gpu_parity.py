@@ -354,3 +354,24 @@ def test_split_fp16_vs_fp32_on_the_bench_pyramid_level():
     d = float(np.abs(res[0][0] - res[1][0]).max())
     assert d < 2e-5, d
     assert abs(len(res[0][1]) - len(res[1][1])) <= 2
+
+
+def test_image_pipeline_submit_collect():
+    """Two images in flight over two head lanes: same detections as one-at-a-time."""
+    from smallhardface_amd import test as T
+    cfg.MODEL.DIFFERENT_DILATION.ENABLE = True
+    cfg.TEST.SCALES = [100, 300]
+    gnet, _ = H.make_pair(H.detector_msg(True), cls_bias=1.0)
+    ims = [np.random.default_rng(70 + i).integers(0, 256, (96, 128 + 16 * i, 3)).astype(np.uint8) for i in range(3)]
+    fd = T.FusedDetector(gnet, n_lanes=4, mode="group")
+    ref = [fd.detect(list(T.pyramid_units(im)), thresh=0.05)[0] for im in ims]
+    got = []
+    for im in ims:
+        fd.submit(list(T.pyramid_units(im)), thresh=0.05)
+        if fd.pending() > 1:
+            got.append(fd.collect()[0])
+    while fd.pending():
+        got.append(fd.collect()[0])
+    assert len(got) == 3
+    for a, b in zip(got, ref):
+        np.testing.assert_array_equal(a, b)
