@@ -386,6 +386,8 @@ static int launch_mfma_t(const ConvArgs* as, int n, hipStream_t s) {
   p.relu |= dbg_flags;
   p.nct = p.Cout / BN;
   p.nmem = n;
+  p.w1t = nullptr;
+  p.b1 = nullptr;
   long long tiles = 0;
   for (int i = 0; i < n; ++i) {
     const ConvArgs& q = as[i];
@@ -398,6 +400,7 @@ static int launch_mfma_t(const ConvArgs* as, int n, hipStream_t s) {
     m.in = q.in.p + q.in.coff;
     m.out = q.out.p + q.out.coff;
     m.pool = q.pool.p ? q.pool.p + q.pool.coff : nullptr;
+    m.img = nullptr;
     m.B = q.in.B; m.H = q.in.H; m.W = q.in.W;
     m.tiles_x = (m.W + TW - 1) / TW;
     m.tiles_per_img = m.tiles_x * ((m.H + TH - 1) / TH);

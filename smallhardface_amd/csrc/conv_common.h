@@ -13,6 +13,7 @@ constexpr int MAX_GROUP = 16;
 struct ConvMember {
   const float* in;   // already offset to the view's first channel
   float* out;        // already offset to the view's first channel
+  const float* img;  // FUSE1 (conv_f16x3.hip): the raw NCHW image this layer's input is computed from, else null
   float* pool;       // fused 2x2/2 max-pool output (ceil(H/2) x ceil(W/2) x Cout, NHWC) or null
   int B, H, W;
   int tiles_x, tiles_per_img, tile_start;  // tile_start: first pixel-tile index of this member
@@ -26,6 +27,8 @@ struct ConvK {
   int dil, relu;     // relu bit 0: ReLU; bit 3 (8): do NOT write the un-pooled output
   int pool_stride;   // floats per pixel of the pool buffer
   int nct, nmem;
+  const float* w1t;  // FUSE1: first-layer weights transposed to [27][64]
+  const float* b1;   // FUSE1: first-layer bias [64]
   unsigned long long* dbg;  // SHF_CONV_TIMING builds only: per-wave phase cycle sums
   ConvMember m[MAX_GROUP];
 };

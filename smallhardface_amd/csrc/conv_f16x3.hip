@@ -55,7 +55,12 @@ __device__ __forceinline__ void split4(const float4 v, half4& hi, half4& lo) {
 }
 
 // BN = 128: waves 4(M) x 2(N), each 64 px x 64 couts (MT = 2 M-tiles); BN = 64: waves 8 x 1, each 32 px x 64 couts.
-template <int BN>
+// FUSE1: the input of this layer is the first conv of the net (3x3, pad 1, Cin <= 3, + ReLU) applied
+// to the raw image: instead of reading its 64-channel output from HBM, the halo tile is COMPUTED
+// in place from a 20x20x3 image patch staged in LDS (one thread per halo pixel, 27 x 32 FMAs per
+// chunk, under the MFMAs of the previous chunk).  conv1_1 never touches HBM: -1.8 GB written and
+// read per image on the bench pyramid.
+template <int BN, bool FUSE1>
 __global__ __launch_bounds__(512) void conv_mfma_f16x3_kernel(ConvK p) {
   using namespace f16x3;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -66,6 +71,11 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_kernel(ConvK p) {
   constexpr int ALD = (HP * 8 + 511) / 512;  // float4 halo pieces per thread: 6
   unsigned char* As = smem;                  // [HP][ROWB]
   unsigned char* Bs = smem + HP * ROWB;      // [2][3][BN][ROWB]
+  // FUSE1 extras behind the weight buffers
+  constexpr int PW = TW + 4, PH = TH + 4;    // image patch: halo of the halo
+  float* patch = (float*)(Bs + 2 * 3 * BN * ROWB);  // [3][PH][PW]
+  float* w1s = patch + 3 * PH * PW;                 // [27][64]
+  float* b1s = w1s + 27 * 64;                       // [64]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wn = wave % WN, wm = wave / WN;
@@ -147,21 +157,82 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_kernel(ConvK p) {
   }
 
   // prologue: halo(0) and W(0) into LDS
-  {
+  // FUSE1 per-thread state: thread `tid` owns halo pixel hp = tid (tid < HP)
+  half4 fhi[8], flo[8];
+  const int f_hy = tid / HTW, f_hx = tid - (tid / HTW) * HTW;
+  const bool f_own = FUSE1 && tid < HP;
+  const bool f_inside = f_own && ((unsigned)(ty0 - 1 + f_hy) < (unsigned)H) && ((unsigned)(tx0 - 1 + f_hx) < (unsigned)W);
+  auto first_conv = [&](int chunk) {
+    // conv1_1 + ReLU for channels chunk*32 .. +31 at this thread's halo pixel; zero outside the image
+    // (that is conv1_2's zero padding, not conv1_1 evaluated out there)
+    float acc[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) acc[j] = b1s[chunk * 32 + j];
+#pragma unroll
+    for (int ci = 0; ci < 3; ++ci)
+#pragma unroll
+      for (int kyy = 0; kyy < 3; ++kyy)
+#pragma unroll
+        for (int kxx = 0; kxx < 3; ++kxx) {
+          const float v = patch[(ci * PH + f_hy + kyy) * PW + f_hx + kxx];
+          const float4* wv = (const float4*)(w1s + ((ci * 3 + kyy) * 3 + kxx) * 64 + chunk * 32);
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            const float4 w4 = wv[q];
+            acc[4 * q + 0] = fmaf(v, w4.x, acc[4 * q + 0]);
+            acc[4 * q + 1] = fmaf(v, w4.y, acc[4 * q + 1]);
+            acc[4 * q + 2] = fmaf(v, w4.z, acc[4 * q + 2]);
+            acc[4 * q + 3] = fmaf(v, w4.w, acc[4 * q + 3]);
+          }
+        }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      float4 v4 = make_float4(fmaxf(acc[4 * q], 0.f), fmaxf(acc[4 * q + 1], 0.f), fmaxf(acc[4 * q + 2], 0.f),
+                              fmaxf(acc[4 * q + 3], 0.f));
+      if (!f_inside) v4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      split4(v4, fhi[q], flo[q]);
+    }
+  };
+  auto first_store = [&]() {
+    if (f_own) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        *(half4*)(As + tid * ROWB + q * 8) = fhi[q];
+        *(half4*)(As + tid * ROWB + q * 8 + 64) = flo[q];
+      }
+    }
+  };
+  if constexpr (FUSE1) {
+    const float* img = mem.img + (size_t)b * 3 * H * W;
+    for (int idx = tid; idx < 3 * PH * PW; idx += 512) {
+      const int ci = idx / (PH * PW), r = idx - ci * (PH * PW);
+      const int py = r / PW, pxx = r - py * PW;
+      const int gy = ty0 - 2 + py, gx = tx0 - 2 + pxx;
+      patch[idx] = ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) ? img[((size_t)ci * H + gy) * W + gx] : 0.f;
+    }
+    for (int idx = tid; idx < 27 * 64; idx += 512) w1s[idx] = p.w1t[idx];
+    if (tid < 64) b1s[tid] = p.b1 ? p.b1[tid] : 0.f;
+    __syncthreads();
+    if (f_own) first_conv(0);
+  } else {
     const float* inc_ = gin;
 #pragma unroll
     for (int j = 0; j < ALD; ++j)
       areg[j] = (a_goff[j] >= 0) ? *(const float4*)(inc_ + a_goff[j]) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
   F16X3_DMA_W(0, 0, 8);
+  if constexpr (FUSE1) {
+    first_store();
+  } else {
 #pragma unroll
-  for (int j = 0; j < ALD; ++j)
-    if (a_loff[j] >= 0) {
-      half4 hi, lo;
-      split4(areg[j], hi, lo);
-      *(half4*)(As + a_loff[j]) = hi;
-      *(half4*)(As + a_loff[j] + 64) = lo;
-    }
+    for (int j = 0; j < ALD; ++j)
+      if (a_loff[j] >= 0) {
+        half4 hi, lo;
+        split4(areg[j], hi, lo);
+        *(half4*)(As + a_loff[j]) = hi;
+        *(half4*)(As + a_loff[j] + 64) = lo;
+      }
+  }
 
   int c = 0, ky = 0;
 #ifdef SHF_CONV_TIMING
@@ -182,11 +253,13 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_kernel(ConvK p) {
 #endif
     const bool last_row = (ky == 2);
     const bool more_chunks = (c + 1 < nchunks);
-    if (last_row && more_chunks) {
-      const float* inc_ = gin + (c + 1) * KC;
+    if constexpr (!FUSE1) {
+      if (last_row && more_chunks) {
+        const float* inc_ = gin + (c + 1) * KC;
 #pragma unroll
-      for (int j = 0; j < ALD; ++j)
-        areg[j] = (a_goff[j] >= 0) ? *(const float4*)(inc_ + a_goff[j]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j = 0; j < ALD; ++j)
+          areg[j] = (a_goff[j] >= 0) ? *(const float4*)(inc_ + a_goff[j]) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
     }
     SHF_T(t2);
     const unsigned char* Arow = As + (ky * HTW) * ROWB;
@@ -238,9 +311,13 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_kernel(ConvK p) {
         }
       }
       if (F16X3_CONV_MID && kx == 1 && last_row && more_chunks) {
-        // split the next chunk's halo (loaded at the top of this stage) while the matrix pipe drains
+        // prepare the next chunk's halo while the matrix pipe drains
+        if constexpr (FUSE1) {
+          if (f_own) first_conv(c + 1);
+        } else {
 #pragma unroll
-        for (int j = 0; j < ALD; ++j) split4(areg[j], ahi[j], alo[j]);
+          for (int j = 0; j < ALD; ++j) split4(areg[j], ahi[j], alo[j]);
+        }
       }
     }
     // The waves of the first half finish their MFMAs early (they win the matrix-pipe arbitration
@@ -258,13 +335,17 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_kernel(ConvK p) {
       if (more_chunks) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();  // every wave is done reading the halo tile of chunk c
+        if constexpr (FUSE1) {
+          first_store();
+        } else {
 #pragma unroll
-        for (int j = 0; j < ALD; ++j)
-          if (a_loff[j] >= 0) {
-            if (!F16X3_CONV_MID) split4(areg[j], ahi[j], alo[j]);
-            *(half4*)(As + a_loff[j]) = ahi[j];
-            *(half4*)(As + a_loff[j] + 64) = alo[j];
-          }
+          for (int j = 0; j < ALD; ++j)
+            if (a_loff[j] >= 0) {
+              if (!F16X3_CONV_MID) split4(areg[j], ahi[j], alo[j]);
+              *(half4*)(As + a_loff[j]) = ahi[j];
+              *(half4*)(As + a_loff[j] + 64) = alo[j];
+            }
+        }
       }
       ky = 0;
       ++c;
@@ -324,7 +405,7 @@ bool conv_f16x3_eligible(int Cin, int Cout, int k, int pad, int dil) {
   return k == 3 && dil == 1 && pad == 1 && Cin % 32 == 0 && Cout % 64 == 0;
 }
 
-template <int BN>
+template <int BN, bool FUSE1>
 static int launch_f16x3_t(const ConvArgs* as, int n, hipStream_t s) {
   using namespace f16x3;
   const ConvArgs& a = as[0];
@@ -338,9 +419,12 @@ static int launch_f16x3_t(const ConvArgs* as, int n, hipStream_t s) {
   p.nct = p.Cout / BN;
   p.nmem = n;
   p.dbg = nullptr;
+  p.w1t = a.w1t;
+  p.b1 = a.b1;
   long long tiles = 0;
   for (int i = 0; i < n; ++i) {
     const ConvArgs& q = as[i];
+    if (FUSE1 && !q.img) { set_error("conv f16x3: fused first layer needs the image pointer"); return -1; }
     if (q.in.C != p.Cin || q.out.C != p.Cout || q.in.cstride != p.in_stride || q.out.cstride != p.out_stride ||
         q.wsplit16 != a.wsplit16) {
       set_error("conv group: members must share the layer");
@@ -350,20 +434,22 @@ static int launch_f16x3_t(const ConvArgs* as, int n, hipStream_t s) {
     m.in = q.in.p + q.in.coff;
     m.out = q.out.p + q.out.coff;
     m.pool = q.pool.p ? q.pool.p + q.pool.coff : nullptr;
+    m.img = q.img;
     m.B = q.in.B; m.H = q.in.H; m.W = q.in.W;
     m.tiles_x = (m.W + TW - 1) / TW;
     m.tiles_per_img = m.tiles_x * ((m.H + TH - 1) / TH);
     m.tile_start = (int)tiles;
     tiles += (long long)m.tiles_per_img * m.B;
   }
-  const size_t lds = (size_t)HP * ROWB + 2 * 3 * (size_t)BN * ROWB;
+  const size_t lds = (size_t)HP * ROWB + 2 * 3 * (size_t)BN * ROWB +
+                     (FUSE1 ? (3 * (TH + 4) * (TW + 4) + 27 * 64 + 64) * sizeof(float) : 0);
 #ifdef SHF_CONV_TIMING
   static unsigned long long* dbg_dev = nullptr;
   if (!dbg_dev) hipMalloc((void**)&dbg_dev, 16 * 5 * 8);
   hipMemset(dbg_dev, 0, 16 * 5 * 8);
   p.dbg = dbg_dev;
 #endif
-  hipLaunchKernelGGL((conv_mfma_f16x3_kernel<BN>), dim3((unsigned)(tiles * p.nct)), dim3(512), lds, s, p);
+  hipLaunchKernelGGL((conv_mfma_f16x3_kernel<BN, FUSE1>), dim3((unsigned)(tiles * p.nct)), dim3(512), lds, s, p);
   SHF_HIP_OK(hipGetLastError());
 #ifdef SHF_CONV_TIMING
   {
@@ -381,9 +467,11 @@ static int launch_f16x3_t(const ConvArgs* as, int n, hipStream_t s) {
 }
 
 int conv_f16x3_init_attributes() {
-  SHF_HIP_OK(hipFuncSetAttribute((const void*)conv_mfma_f16x3_kernel<128>,
+  SHF_HIP_OK(hipFuncSetAttribute((const void*)conv_mfma_f16x3_kernel<128, false>,
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  SHF_HIP_OK(hipFuncSetAttribute((const void*)conv_mfma_f16x3_kernel<64>,
+  SHF_HIP_OK(hipFuncSetAttribute((const void*)conv_mfma_f16x3_kernel<64, false>,
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  SHF_HIP_OK(hipFuncSetAttribute((const void*)conv_mfma_f16x3_kernel<64, true>,
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   return 0;
 }
@@ -393,7 +481,11 @@ int launch_conv_f16x3_group(const ConvArgs* as, int n, hipStream_t s) {
   for (int i = 0; i < n; ++i)
     if ((as[i].in.cstride % 4) || (as[i].in.coff % 4)) { set_error("conv: input view not 16-byte aligned"); return -1; }
   if (!as[0].wsplit16) { set_error("conv f16x3: split weights not packed"); return -1; }
-  return (as[0].out.C % 128 == 0) ? launch_f16x3_t<128>(as, n, s) : launch_f16x3_t<64>(as, n, s);
+  if (as[0].img) {
+    if (as[0].in.C != 64 || !as[0].w1t) { set_error("conv f16x3: fused first layer needs 64 channels + transposed weights"); return -1; }
+    return launch_f16x3_t<64, true>(as, n, s);  // conv1_1 computed in place (BN=64 tile: Cout 64 or any multiple of 64)
+  }
+  return (as[0].out.C % 128 == 0) ? launch_f16x3_t<128, false>(as, n, s) : launch_f16x3_t<64, false>(as, n, s);
 }
 
 }  // namespace shf

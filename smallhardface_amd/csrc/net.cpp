@@ -129,6 +129,8 @@ struct Layer {
   int fuse_pool = -1;      // conv: index of the 2x2/2 MAX pool folded into its epilogue (fused path only)
   bool pool_only = false;  // conv: its un-pooled top has no other reader
   int fused_into = -1;     // pool: index of the conv that produces it in the fused path
+  int first_src = -1;      // conv: index of the first-layer conv computed inside this conv's halo staging (f16x3)
+  int first_dst = -1;      // first-layer conv: index of the conv that absorbs it
 };
 
 // the first 8 classes are the instantiations of conv_mfma_f32_kernel, named like rocprofv3 prints them
@@ -741,6 +743,25 @@ void shf_net::build(const std::string& text, const char* caffemodel) {
     layers[prod].pool_only = (others == 0);
     P.fused_into = prod;
   }
+  // ---- first-layer conv (on the raw image) that the split-fp16 kernel of the NEXT conv can compute in place
+  for (size_t li = 0; li < layers.size(); ++li) {
+    Layer& F = layers[li];
+    if (F.op != OP_CONV || F.kclass != 1 || !F.relu || F.k != 3 || F.pad != 1 || F.dil != 1 || F.nout != 64) continue;
+    if (blobs[F.bottoms[0]].shape.size() != 4 || blobs[F.bottoms[0]].shape[1] != 3) continue;
+    const int x = F.tops[0];
+    int next = -1, readers = 0;
+    for (size_t lj = 0; lj < layers.size(); ++lj) {
+      Layer& Q = layers[lj];
+      if (lj == li || (Q.op == OP_SKIP && Q.type == "ReLU")) continue;
+      for (int bb : Q.bottoms)
+        if (bb == x) { ++readers; next = (int)lj; }
+    }
+    if (readers != 1 || layers[next].op != OP_CONV || layers[next].kclass != 0) continue;
+    Layer& N = layers[next];
+    if (!conv_f16x3_eligible(64, N.nout, N.k, N.pad, N.dil) || blobs[x].owner >= 0) continue;
+    N.first_src = (int)li;
+    F.first_dst = next;
+  }
   alloc_buffers();
   if (clone_src) {
     wgen = clone_src->wgen;
@@ -955,13 +976,22 @@ void shf_net::forward_ops(bool fused_path, float im_h, float im_w, float im_scal
         a.wraw = (const float*)L.params[0]->raw.p;
         a.wpacked = (const float*)L.params[0]->packed.p;
         a.wfirst = (const float*)L.params[0]->first_t.p;
+        const bool split16 = conv_mode == 1 && L.kclass == 0 && L.params[0]->packed16.p &&
+                             conv_f16x3_eligible(ib.shape[1], L.nout, L.k, L.pad, L.dil);
+        a.wsplit16 = split16 ? L.params[0]->packed16.p : nullptr;
         if (fused_path && L.fuse_pool >= 0) {
           a.pool = view_of(layers[L.fuse_pool].tops[0]);
           a.write_main = L.pool_only ? 0 : 1;
         }
-        const bool split16 = conv_mode == 1 && L.kclass == 0 && L.params[0]->packed16.p &&
-                             conv_f16x3_eligible(ib.shape[1], L.nout, L.k, L.pad, L.dil);
-        a.wsplit16 = split16 ? L.params[0]->packed16.p : nullptr;
+        if (fused_path && split16 && L.first_src >= 0) {
+          Layer& F = layers[L.first_src];
+          Blob& db = blobs[F.bottoms[0]];
+          a.img = db.ext_dev ? db.ext_dev : (const float*)db.dev.p;
+          a.w1t = (const float*)F.params[0]->first_t.p;
+          a.b1 = F.params.size() > 1 ? (const float*)F.params[1]->raw.p : nullptr;
+        }
+        if (fused_path && conv_mode == 1 && L.first_dst >= 0 && layers[L.first_dst].params[0]->packed16.p)
+          break;  // computed inside the next conv's halo staging
         const double fl = conv_flops(L, ib.shape, blobs[L.tops[0]].shape);
         const double by = 4.0 * (ib.count() + blobs[L.tops[0]].count() + L.params[0]->count());
         if (L.kclass == 1) {

@@ -34,6 +34,9 @@ struct ConvArgs {
   const float* bias = nullptr;     // [Cout] or null
   int k = 3, dil = 1, pad = 1;
   int relu = 0;
+  const float* img = nullptr;  // fused first layer (f16x3 only): raw NCHW image, transposed weights, bias
+  const float* w1t = nullptr;
+  const float* b1 = nullptr;
   View pool;           // optional fused MAX 2x2/2 pool output (p == nullptr: none)
   int write_main = 1;  // 0: the un-pooled output has no other reader and is not written
 };
