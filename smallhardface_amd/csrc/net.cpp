@@ -134,12 +134,13 @@ struct Layer {
 };
 
 // the first 8 classes are the instantiations of conv_mfma_f32_kernel, named like rocprofv3 prints them
-enum ProfClass { PC_CONV_MFMA, PC_CONV_MFMA_1 = 1, PC_CONV_MFMA_7 = 7, PC_CONV_F16X3_128, PC_CONV_F16X3_64, PC_CONV_FIRST, PC_CONV_DIRECT, PC_POOL, PC_DECONV, PC_TAIL, PC_MERGE, PC_LAYOUT, PC_COUNT };
+enum ProfClass { PC_CONV_MFMA, PC_CONV_MFMA_1 = 1, PC_CONV_MFMA_7 = 7, PC_CONV_F16X3_128, PC_CONV_F16X3_64, PC_CONV_F16X3_64_FUSE1, PC_CONV_FIRST, PC_CONV_DIRECT, PC_POOL, PC_DECONV, PC_TAIL, PC_MERGE, PC_LAYOUT, PC_COUNT };
 static const char* kProfNames[PC_COUNT] = {"conv_mfma_f32_kernel<3, 1, 128, 8, 16>", "conv_mfma_f32_kernel<3, 2, 128, 8, 16>",
                                            "conv_mfma_f32_kernel<3, 4, 128, 8, 16>", "conv_mfma_f32_kernel<3, 1, 64, 16, 16>",
                                            "conv_mfma_f32_kernel<3, 2, 64, 16, 16>", "conv_mfma_f32_kernel<3, 4, 64, 16, 16>",
                                            "conv_mfma_f32_kernel<1, 0, 128, 8, 16>", "conv_mfma_f32_kernel<1, 0, 64, 16, 16>",
-                                           "conv_mfma_f16x3_kernel<128>", "conv_mfma_f16x3_kernel<64>",
+                                           "conv_mfma_f16x3_kernel<128, false>", "conv_mfma_f16x3_kernel<64, false>",
+                                           "conv_mfma_f16x3_kernel<64, true>",
                                            "conv_first_kernel", "conv_direct_kernel", "maxpool_kernel",
                                            "deconv_depthwise", "detect_tail", "box_merge", "layout"};
 
@@ -1004,7 +1005,8 @@ void shf_net::forward_ops(bool fused_path, float im_h, float im_w, float im_scal
           if (L.kclass == 0 && collect) {
             *collect = a;  // grouped launch: the caller batches this layer over several units
           } else if (L.kclass == 0 && split16) {
-            ProfScope ps(pf, st, L.nout % 128 == 0 ? PC_CONV_F16X3_128 : PC_CONV_F16X3_64, fl, by);
+            ProfScope ps(pf, st, a.img ? PC_CONV_F16X3_64_FUSE1 : L.nout % 128 == 0 ? PC_CONV_F16X3_128 : PC_CONV_F16X3_64,
+                         fl, by);
             CHECK_RC(launch_conv_f16x3_group(&a, 1, st));
           } else if (L.kclass == 0) {
             const int pc = conv_prof_class(L.k, L.dil, L.nout);
@@ -1408,7 +1410,16 @@ int shf_detect_add_levels(shf_net* net, int n, shf_net** members, const float* c
         by += 4.0 * (mb->blobs[mb->layers[li].bottoms[0]].count() + mb->blobs[mb->layers[li].tops[0]].count());
       }
       if (group[0].wsplit16) {
-        ProfScope ps(net->prof, net->stream, L.nout % 128 == 0 ? PC_CONV_F16X3_128 : PC_CONV_F16X3_64, fl, by);
+        if (group[0].img && L.first_src >= 0) {  // conv1_1's work rides in this launch
+          for (int m = 0; m < n; ++m) {
+            shf_net* mb = members[m];
+            const Layer& F = mb->layers[L.first_src];
+            fl += conv_flops(F, mb->blobs[F.bottoms[0]].shape, mb->blobs[F.tops[0]].shape);
+          }
+        }
+        ProfScope ps(net->prof, net->stream,
+                     group[0].img ? PC_CONV_F16X3_64_FUSE1 : L.nout % 128 == 0 ? PC_CONV_F16X3_128 : PC_CONV_F16X3_64, fl,
+                     by);
         CHECK_RC(launch_conv_f16x3_group(group.data(), n, net->stream));
       } else {
         const int pc = conv_prof_class(L.k, L.dil, L.nout);
