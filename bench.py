@@ -100,6 +100,7 @@ def main():
     ap.add_argument("--conv-mode", default="f16x3", choices=["f16x3", "fp32"],
                     help="f16x3: split-fp16 MFMA (3 fp16 products per fp32 product, fp32 accumulate; fp32-class "
                          "accuracy, same parity bars); fp32: exact v_mfma_f32_32x32x2_f32 everywhere")
+    ap.add_argument("--dump-dets", default=None, help="rank 0 writes the detections of window image 0 to this .npy")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for "
                     "validating the N>1 code path with several ranks on ONE GPU: SHF_BENCH_ONE_GPU=1)")
     ap.add_argument("--lanes", type=int, default=5, help="execution lanes (HIP streams) per GPU in --mode streams")
@@ -184,12 +185,11 @@ def main():
         # every lane keeps the detections of its unit, which are then routed to the unit's image
         head = lanes[0]
         head.detect_add_levels(lanes[:len(mine)], mine_units, thresh, on_device=True, per_member_lists=True)
-        head.sync()
+        counts = head.detect_export_many(lanes[:len(mine)], [e.data_ptr() for e in export], cfg.TEST.N_DETS_PER_MODULE)
         parts = {i: [] for i in range(world)}
         for m, (i, u) in enumerate(mine):
-            n = lanes[m].detect_export(export[m].data_ptr(), cfg.TEST.N_DETS_PER_MODULE)
-            if n:
-                parts[i].append(export[m][:n])
+            if counts[m]:
+                parts[i].append(export[m][:min(counts[m], cfg.TEST.N_DETS_PER_MODULE)])
         empty = torch.zeros((0, 5), dtype=torch.float32, device=dev)
         local = {i: (torch.cat(p, 0) if p else empty) for i, p in parts.items()}
         got = pyramid.gather_window(local, world, rank, world, device=dev)
@@ -235,6 +235,8 @@ def main():
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
 
+    if rank == 0 and args.dump_dets and 0 in last:
+        np.save(args.dump_dets, np.asarray(last[0]))
     if rank == 0:
         images = world * args.steps
         value = images / elapsed

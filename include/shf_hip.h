@@ -126,6 +126,9 @@ int shf_detect_count(shf_net* net);
  * pointer) to the current image before shf_detect_finish. */
 int shf_detect_export(shf_net* net, float* dst_dev5, int cap_rows, int* n_rows);
 int shf_detect_import(shf_net* net, const float* src_dev5, int n_rows);
+/* export of all the per-member lists of one shf_detect_add_levels(..., per_member_lists=1) pass */
+int shf_detect_export_many(shf_net* net, int n, shf_net** members, float* const* dst_dev5, int cap_rows,
+                           int* n_rows);
 
 /* ---- stand-alone box ops ----------------------------------------------------- */
 /* nms(dets, thresh)  lib/nms/nms_wrapper.py:13 -> gpu_nms lib/nms/gpu_nms.pyx:16-31

@@ -300,6 +300,15 @@ class Net(object):
                    "detect_export")
         return n.value
 
+    def detect_export_many(self, members, dst_ptrs, cap_rows):
+        """Row counts of the members' lists after a per_member_lists pass; rows land in dst_ptrs[m]."""
+        n = len(members)
+        mem = (C.c_void_p * n)(*[m._h for m in members])
+        dst = (C.c_void_p * n)(*[int(p) for p in dst_ptrs])
+        cnt = (C.c_int * n)()
+        _lib.check(self._lib.shf_detect_export_many(self._h, n, mem, dst, int(cap_rows), cnt), "detect_export_many")
+        return [int(cnt[i]) for i in range(n)]
+
     def detect_import(self, src_ptr, n_rows):
         _lib.check(self._lib.shf_detect_import(self._h, C.c_void_p(int(src_ptr)), int(n_rows)), "detect_import")
 

@@ -1489,6 +1489,29 @@ int shf_detect_export(shf_net* net, float* dst_dev5, int cap_rows, int* n_rows) 
   API_END(-1)
 }
 
+int shf_detect_export_many(shf_net* net, int n, shf_net** members, float* const* dst_dev5, int cap_rows,
+                           int* n_rows) {
+  API_BEGIN
+  // after a per_member_lists pass: everything was enqueued on `net`'s stream -> one sync, then all
+  // counts, then the row copies, then one more sync
+  HIP_THROW(hipStreamSynchronize(net->stream));
+  for (int m = 0; m < n; ++m) {
+    int c[2] = {0, 0};
+    HIP_THROW(hipMemcpyAsync(c, members[m]->img_count.p, 8, hipMemcpyDeviceToHost, net->stream));
+    HIP_THROW(hipStreamSynchronize(net->stream));
+    n_rows[m] = c[members[m]->img_units & 1];
+  }
+  for (int m = 0; m < n; ++m) {
+    const int w = std::min(n_rows[m], cap_rows);
+    if (w > 0)
+      HIP_THROW(hipMemcpyAsync(dst_dev5[m], members[m]->img_dets.p, (size_t)w * 5 * 4, hipMemcpyDeviceToDevice,
+                               net->stream));
+  }
+  HIP_THROW(hipStreamSynchronize(net->stream));
+  return 0;
+  API_END(-1)
+}
+
 int shf_detect_import(shf_net* net, const float* src_dev5, int n_rows) {
   API_BEGIN
   if (n_rows <= 0) return 0;
