@@ -100,6 +100,8 @@ def main():
     ap.add_argument("--conv-mode", default="f16x3", choices=["f16x3", "fp32"],
                     help="f16x3: split-fp16 MFMA (3 fp16 products per fp32 product, fp32 accumulate; fp32-class "
                          "accuracy, same parity bars); fp32: exact v_mfma_f32_32x32x2_f32 everywhere")
+    ap.add_argument("--host-input", action="store_true",
+                    help="N=1 only: hand HOST blobs to the C ABI each step (PCIe-inclusive rate; not the headline value)")
     ap.add_argument("--dump-dets", default=None, help="rank 0 writes the detections of window image 0 to this .npy")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for "
                     "validating the N>1 code path with several ranks on ONE GPU: SHF_BENCH_ONE_GPU=1)")
@@ -169,6 +171,8 @@ def main():
     lanes = fd.lanes
     if world == 1:
         unit_list = [(units[(0, u)][0].data_ptr(),) + units[(0, u)][1:] for u in range(n_units)]
+        if args.host_input:
+            host_list = [(units[(0, u)][0].cpu().numpy(),) + units[(0, u)][1:] for u in range(n_units)]
     else:
         while len(lanes) < len(mine):
             lanes.append(net.clone())
@@ -177,7 +181,10 @@ def main():
     def step():
         if world == 1:
             # two images in flight: image k's box merging / read-back overlaps image k+1's convolutions
-            fd.submit(unit_list, thresh, on_device=True)
+            if args.host_input:
+                fd.submit(host_list, thresh, on_device=False)
+            else:
+                fd.submit(unit_list, thresh, on_device=True)
             if fd.pending() > 1:
                 last[0] = fd.collect()[0]
             return
