@@ -1,0 +1,48 @@
+"""``train_test.py --train false`` end to end on the GPU: TOML config, --amend, manipulate_test,
+synthetic .caffemodel, image list, pyramid + flip, bbox_vote, WIDER-format detection files."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+def test_cli_writes_wider_detections(tmp_path):
+    from PIL import Image
+    from smallhardface_amd import caffemodel, weights
+    from tests import helpers as H
+    data = tmp_path / "data"
+    (data / "images" / "0--Parade").mkdir(parents=True)
+    rng = np.random.default_rng(0)
+    names = []
+    for i, (h, w) in enumerate([(120, 160), (90, 140)]):
+        p = data / "images" / "0--Parade" / ("img%d.jpg" % i)
+        Image.fromarray(rng.integers(0, 256, (h, w, 3)).astype(np.uint8)).save(p)
+        names.append("images/0--Parade/img%d.jpg" % i)
+    (data / "wider_val.txt").write_text("\n".join(names) + "\n")
+    model = str(tmp_path / "synthetic.caffemodel")
+    caffemodel.write_caffemodel(model, weights.synth_params(H.detector_msg(True), cls_bias=1.0))
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "train_test.py"), "--train", "false", "--conf",
+                        os.path.join(ROOT, "configs", "smallhardface.toml"), "--amend", "TEST.MODEL", model,
+                        "DATA_DIR", str(data), "TEST.GPU_ID", "[0]", "TEST.SCALES", "[100, 300]", "EXP_DIR",
+                        str(tmp_path / "exp")], cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    found = []
+    for root, _, files in os.walk(str(tmp_path / "exp")):
+        found += [os.path.join(root, f) for f in files if f.endswith(".txt") and "img" in f]
+    assert len(found) == 2, (found, r.stderr[-1500:])
+    lines = open(sorted(found)[0]).read().splitlines()
+    assert lines[0] == names[0] and int(lines[1]) == len(lines) - 2 and int(lines[1]) >= 1
+    x, y, w, h, s = lines[2].split()
+    assert int(w) >= 0 and int(h) >= 0 and 0.0 < float(s) <= 1.0
+
+
+def test_cli_refuses_training():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "train_test.py"), "--train", "true"],
+                       env=dict(os.environ, PYTHONPATH=ROOT), capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "outside the scope" in (r.stderr + r.stdout)
