@@ -100,8 +100,10 @@ def main():
     ap.add_argument("--conv-mode", default="f16x3", choices=["f16x3", "fp32"],
                     help="f16x3: split-fp16 MFMA (3 fp16 products per fp32 product, fp32 accumulate; fp32-class "
                          "accuracy, same parity bars); fp32: exact v_mfma_f32_32x32x2_f32 everywhere")
-    ap.add_argument("--host-input", action="store_true",
-                    help="N=1 only: hand HOST blobs to the C ABI each step (PCIe-inclusive rate; not the headline value)")
+    ap.add_argument("--host-input", nargs="?", const="blobs", default=None, choices=["blobs", "image"],
+                    help="N=1 only, PCIe-inclusive rates (never the headline value): 'blobs' hands the 10 HOST fp32 "
+                         "blobs to the C ABI each step; 'image' uploads the raw uint8 image and builds the pyramid on "
+                         "the device (shf_make_pyramid_level)")
     ap.add_argument("--dump-dets", default=None, help="rank 0 writes the detections of window image 0 to this .npy")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for "
                     "validating the N>1 code path with several ranks on ONE GPU: SHF_BENCH_ONE_GPU=1)")
@@ -171,8 +173,12 @@ def main():
     lanes = fd.lanes
     if world == 1:
         unit_list = [(units[(0, u)][0].data_ptr(),) + units[(0, u)][1:] for u in range(n_units)]
-        if args.host_input:
+        if args.host_input == "blobs":
             host_list = [(units[(0, u)][0].cpu().numpy(),) + units[(0, u)][1:] for u in range(n_units)]
+        elif args.host_input == "image":
+            from smallhardface_amd.test import DevicePyramid
+            dp = DevicePyramid(net, n_slots=2)
+            host_im = np.random.default_rng(1000).integers(0, 256, (SRC_H, SRC_W, 3)).astype(np.uint8)
     else:
         while len(lanes) < len(mine):
             lanes.append(net.clone())
@@ -181,8 +187,10 @@ def main():
     def step():
         if world == 1:
             # two images in flight: image k's box merging / read-back overlaps image k+1's convolutions
-            if args.host_input:
+            if args.host_input == "blobs":
                 fd.submit(host_list, thresh, on_device=False)
+            elif args.host_input == "image":
+                fd.submit(dp.units(host_im, net=fd.next_head()), thresh, on_device=True)
             else:
                 fd.submit(unit_list, thresh, on_device=True)
             if fd.pending() > 1:

@@ -107,6 +107,20 @@ int shf_detect_add_levels(shf_net* net, int n, shf_net** members, const float* c
                           int data_on_device, const int* H, const int* W, const int* im_h,
                           const int* im_w, const float* im_scale, const int* flip, float thresh,
                           int per_member_lists);
+/* ---- image pre-processing ----------------------------------- */
+/* Geometry of one pyramid unit: the resized level is (lvl_h, lvl_w) = round-half-even(im * scale)
+ * (cv2.resize dsize rule, lib/utils/test_utils.py:40-44) and the net input (H, W) is that rounded
+ * up to a multiple of max_resolution (cfg.MAX_RESOLUTION, lib/test.py:35-38).  Needs no GPU. */
+int shf_pyramid_level_shape(int im_h, int im_w, double scale, int max_resolution, int* lvl_h, int* lvl_w,
+                            int* H, int* W);
+/* _get_image_blob for one (scale, flip) unit on the device (lib/utils/test_utils.py:29-46,
+ * lib/utils/blob.py:16-32, flip lib/test.py:150, pad lib/test.py:35-38): im_bgr_dev is the raw
+ * im_h x im_w x 3 uint8 image (cv2.imread layout) in device memory, pixel_means 3 doubles
+ * (cfg.PIXEL_MEANS), out_dev receives the (1,3,H,W) fp32 blob forward_net would build, H/W/lvl_*
+ * from shf_pyramid_level_shape.  Enqueued on `net`'s stream; pass out_dev to
+ * shf_detect_add_level(s) with data_on_device = 1. */
+int shf_make_pyramid_level(shf_net* net, const uint8_t* im_bgr_dev, int im_h, int im_w, double scale, int flip,
+                           const double* pixel_means, float* out_dev, int H, int W, int lvl_h, int lvl_w);
 /* Cross-lane ordering for software-pipelining images over two head lanes: record marks the
  * current end of `net`'s stream; wait makes `net`'s stream wait for `other`'s last mark (e.g. the
  * next image's convolutions, which reuse the member lanes' buffers, wait for the previous

@@ -4,7 +4,7 @@
     python -m smallhardface_amd.build --force
 
 hipcc cross-compiles without a GPU.  The box-arithmetic kernels (tail.hip, merge.hip)
-are built with -ffp-contract=off so IoU / decode round like numpy and devIoU.
+and the image resize (pre.hip) are built with -ffp-contract=off so IoU / decode round like numpy and devIoU.
 """
 import os
 import subprocess
@@ -23,6 +23,7 @@ SOURCES = [
     ("misc.hip", []),
     ("tail.hip", ["-ffp-contract=off"]),
     ("merge.hip", ["-ffp-contract=off"]),
+    ("pre.hip", ["-ffp-contract=off"]),
     ("net.cpp", []),
 ]
 HEADERS = ["shf_internal.h", "conv_common.h", "proto_text.h", os.path.join("..", "..", "include", "shf_hip.h")]

@@ -281,6 +281,14 @@ class Net(object):
                                                    ia(3), ia(4), sc, fl, float(thresh),
                                                    1 if per_member_lists else 0), "detect_add_levels")
 
+    def make_pyramid_level(self, im_dev, im_h, im_w, scale, flip, pixel_means, out_dev, H, W, lvl_h, lvl_w):
+        """_get_image_blob + flip + pad for one unit on this net's stream (C ABI shf_make_pyramid_level):
+        ``im_dev`` raw BGR uint8 HxWx3 device pointer -> ``out_dev`` (1,3,H,W) fp32 device pointer."""
+        pm = (C.c_double * 3)(*[float(v) for v in np.asarray(pixel_means).reshape(-1)[:3]])
+        _lib.check(self._lib.shf_make_pyramid_level(self._h, int(im_dev), int(im_h), int(im_w), float(scale),
+                                                    1 if flip else 0, pm, int(out_dev), int(H), int(W), int(lvl_h),
+                                                    int(lvl_w)), "make_pyramid_level")
+
     def record_event(self):
         _lib.check(self._lib.shf_net_record_event(self._h), "record_event")
 
@@ -324,3 +332,12 @@ class Net(object):
             if n.value <= cap:
                 return out[:n.value]
             cap = n.value  # rare: more merged boxes than expected -> the merge is re-run
+
+
+def pyramid_level_shape(im_h, im_w, scale, max_resolution):
+    """(lvl_h, lvl_w, H, W) of one pyramid unit (C ABI shf_pyramid_level_shape; needs no GPU)."""
+    lib = _lib.load(require_gpu=False)
+    o = [C.c_int() for _ in range(4)]
+    if lib.shf_pyramid_level_shape(int(im_h), int(im_w), float(scale), int(max_resolution), *[C.byref(v) for v in o]):
+        raise ValueError("pyramid_level_shape: bad geometry %r" % ((im_h, im_w, scale, max_resolution),))
+    return tuple(v.value for v in o)

@@ -1372,6 +1372,32 @@ static void append_unit(shf_net* net, shf_net* src, int im_w, float im_scale, in
   net->img_units++;
 }
 
+int shf_pyramid_level_shape(int im_h, int im_w, double scale, int max_resolution, int* lvl_h, int* lvl_w, int* H,
+                            int* W) {
+  if (im_h < 1 || im_w < 1 || !(scale > 0) || max_resolution < 1) return -1;
+  // np.round / cvRound: round half to even (the default FP environment of nearbyint)
+  const int lh = scale == 1.0 ? im_h : (int)std::nearbyint((double)im_h * scale);
+  const int lw = scale == 1.0 ? im_w : (int)std::nearbyint((double)im_w * scale);
+  if (lh < 1 || lw < 1) return -1;
+  if (lvl_h) *lvl_h = lh;
+  if (lvl_w) *lvl_w = lw;
+  if (H) *H = (lh + max_resolution - 1) / max_resolution * max_resolution;
+  if (W) *W = (lw + max_resolution - 1) / max_resolution * max_resolution;
+  return 0;
+}
+
+int shf_make_pyramid_level(shf_net* net, const uint8_t* im_bgr_dev, int im_h, int im_w, double scale, int flip,
+                           const double* pixel_means, float* out_dev, int H, int W, int lvl_h, int lvl_w) {
+  API_BEGIN
+  if (!im_bgr_dev || !out_dev || !pixel_means) throw std::runtime_error("make_pyramid_level: null pointer");
+  if (lvl_h > H || lvl_w > W || lvl_h < 1 || lvl_w < 1) throw std::runtime_error("make_pyramid_level: bad geometry");
+  ProfScope ps(net->prof, net->stream, PC_LAYOUT, 0, 15.0 * H * W);
+  CHECK_RC(launch_pyramid_level(im_bgr_dev, im_h, im_w, scale, flip, pixel_means, out_dev, H, W, lvl_h, lvl_w,
+                                net->stream));
+  return 0;
+  API_END(-1)
+}
+
 int shf_detect_add_level(shf_net* net, const float* data, int data_on_device, int H, int W, int im_h, int im_w,
                          float im_scale, int flip, float thresh) {
   API_BEGIN

@@ -67,6 +67,9 @@ int launch_deconv_depthwise(const View& in, const View& out, const float* w, con
 int launch_copy_view(const View& in, const View& out, hipStream_t s);       // concat fallback
 int launch_nhwc_to_nchw(const View& in, float* out_nchw, hipStream_t s);    // blob.data read-back
 int launch_nchw_to_nhwc(const float* in_nchw, const View& out, hipStream_t s);
+// pyramid unit from the raw BGR uint8 image (pre.hip)
+int launch_pyramid_level(const uint8_t* im, int im_h, int im_w, double scale, int flip, const double* means,
+                         float* out, int H, int W, int lvl_h, int lvl_w, hipStream_t s);
 
 // ---- detection tail ------------------------------------------------------------
 struct TailArgs {

@@ -26,7 +26,7 @@ import numpy as np
 from . import caffe
 from .config import cfg
 from .nms import bbox_vote, nms
-from .test_utils import _compute_scaling_factor, _get_image_blob
+from .test_utils import _compute_scaling_factor, _get_image_blob, pyramid_scales
 from .timer import Timer
 
 logger = logging.getLogger(__name__)
@@ -162,6 +162,48 @@ def pyramid_units(im, scales=None):
             yield np.ascontiguousarray(d, dtype=np.float32), nh, nw, h, w, s, flip
 
 
+class DevicePyramid(object):
+    """pyramid_units with the pre-processing on the device (C ABI shf_make_pyramid_level): the raw
+    BGR uint8 image goes up once (3 bytes/pixel instead of 4 bytes x 3 channels x every level x
+    flip) and each (scale, flip) unit is resized / flipped / padded into a device blob on
+    ``net``'s stream.  ``units(im)`` returns the same tuples as pyramid_units with a device pointer
+    in place of the host array (use with on_device=True); the blobs stay alive in this object
+    until the slot comes round again (``n_slots`` calls later: collect that image first)."""
+
+    def __init__(self, net, n_slots=2):
+        self.net = net
+        self._slots = [None] * max(1, n_slots)
+        self._k = 0
+
+    def units(self, im, scales=None, im_dev=None, net=None):
+        import torch
+        net = net or self.net
+        if scales is None:
+            scales = pyramid_scales(im.shape)
+        im_h, im_w = im.shape[:2]
+        if im_dev is None:
+            im_dev = torch.from_numpy(np.ascontiguousarray(im, dtype=np.uint8)).to("cuda", non_blocking=False)
+        geo = []
+        for s in scales:
+            lh, lw, H, W = caffe.pyramid_level_shape(im_h, im_w, s, cfg.MAX_RESOLUTION)
+            for flip in ([False, True] if cfg.TEST.FLIP else [False]):
+                geo.append((lh, lw, H, W, s, flip))
+        total = sum(3 * g[2] * g[3] for g in geo)
+        slot = self._slots[self._k]
+        if slot is None or slot[0].numel() < total:
+            slot = [torch.empty(total, dtype=torch.float32, device="cuda"), None]
+        slot[1] = im_dev  # keep the image alive while the kernels are in flight
+        self._slots[self._k] = slot
+        self._k = (self._k + 1) % len(self._slots)
+        out, off = [], 0
+        for lh, lw, H, W, s, flip in geo:
+            ptr = slot[0].data_ptr() + 4 * off
+            net.make_pyramid_level(im_dev.data_ptr(), im_h, im_w, s, flip, cfg.PIXEL_MEANS, ptr, H, W, lh, lw)
+            out.append((ptr, H, W, lh, lw, s, flip))
+            off += 3 * H * W
+        return out
+
+
 def lane_ranges(costs, n_lanes):
     """Split the unit sequence into ``n_lanes`` CONTIGUOUS ranges of roughly equal cost
     (contiguous so that concatenating the lanes' detection lists in lane order is the
@@ -197,16 +239,21 @@ class FusedDetector(object):
     # -- software pipeline over images (group mode): the box merging + read-back of image k overlaps
     #    the convolutions of image k+1.  Two head lanes own the image lists and streams; the member
     #    lanes only lend activation buffers, so image k+1 waits for image k's appends, not its merge.
-    def submit(self, units, thresh=0.05, on_device=False):
-        units = list(units)
-        assert self.mode == "group" and len(units) <= 16
+    def next_head(self):
+        """The head lane the next ``submit`` will enqueue on (e.g. to pre-process its image on the
+        same stream: DevicePyramid.units(im, net=fd.next_head()))."""
         if not hasattr(self, "_heads"):
             self._heads = [self.net.clone(), self.net.clone()]
             self._turn = 0
             self._inflight = []
-            while len(self.lanes) < len(units):
-                self.lanes.append(self.net.clone())
-        head = self._heads[self._turn]
+        return self._heads[self._turn]
+
+    def submit(self, units, thresh=0.05, on_device=False):
+        units = list(units)
+        assert self.mode == "group" and len(units) <= 16
+        head = self.next_head()
+        while len(self.lanes) < len(units):
+            self.lanes.append(self.net.clone())
         prev = self._heads[1 - self._turn]
         head.detect_begin()
         head.wait_event(prev)  # the previous image has appended: the member buffers are free again
@@ -267,7 +314,10 @@ def detect_fused(net, units, thresh=0.05, on_device=False):
     return [net.detect_finish(cfg.TEST.NMS_METHOD, cfg.TEST.NMS_THRESH)]
 
 
-def inference_worker(rank, imdb, target_test, start, end, thresh, result_queue=None):
+def inference_worker(rank, imdb, target_test, start, end, thresh, result_queue=None, fused=None):
+    """lib/test.py:220-253.  ``fused`` (default: env SHF_FUSED_DETECT, on): pyramid images go through
+    the device-resident path (DevicePyramid -> FusedDetector.submit/collect, two images in flight)
+    instead of one Net.forward() per unit; same detections, the blobs never visit the host."""
     cfg.GPU_ID = cfg.TEST.GPU_ID[rank]
     caffe.set_mode_gpu()
     caffe.set_device(cfg.GPU_ID)
@@ -276,16 +326,46 @@ def inference_worker(rank, imdb, target_test, start, end, thresh, result_queue=N
     timers = {'detect': Timer(), 'misc': Timer()}
     pyramid = True if len(cfg.TEST.SCALES) > 1 else False
     dets = [[[] for _ in range(start, end)] for _ in range(imdb.num_classes)]
-    for i in range(start, end):
-        im_path = imdb.image_path_at(i)
-        dets_, _ = detect(net, im_path, thresh, timers=timers, pyramid=pyramid)
-        for c in range(imdb.num_classes - 1):
-            dets[c + 1][i - start] = dets_[c]
+    if fused is None:
+        fused = os.environ.get("SHF_FUSED_DETECT", "1") != "0"
+    n_units = len(cfg.TEST.SCALES) * (2 if cfg.TEST.FLIP else 1)
+    fused = fused and pyramid and n_units <= 16 and len(cfg.TEST.LEVEL) == 0
+
+    def progress(i):
         if rank == 0:
             print('\r{:02d}% detect-time: {:.3f}s, misc-time:{:.3f}s, remain-time: {:.3f}s'.format(
                 int(100 * (i + 1 - start) / (end - start)), timers['detect'].average_time,
                 timers['misc'].average_time,
                 (end - i - 1) * (timers['detect'].average_time + timers['misc'].average_time)), end='')
+
+    if fused:
+        fd = FusedDetector(net, n_lanes=n_units, mode="group")
+        dp = DevicePyramid(net, n_slots=2)
+        queued = []
+        for i in list(range(start, end)) + [None]:
+            if i is not None:
+                timers['misc'].tic()
+                im = _imread(imdb.image_path_at(i))
+                timers['misc'].toc()
+                timers['detect'].tic()
+                fd.submit(dp.units(im, net=fd.next_head()), thresh, on_device=True)
+                queued.append(i)
+            if queued and (i is None or fd.pending() > 1):
+                j = queued.pop(0)
+                dets[1][j - start] = fd.collect()[0]
+                timers['detect'].toc()
+                progress(j)
+        while queued:
+            j = queued.pop(0)
+            dets[1][j - start] = fd.collect()[0]
+            progress(j)
+    else:
+        for i in range(start, end):
+            im_path = imdb.image_path_at(i)
+            dets_, _ = detect(net, im_path, thresh, timers=timers, pyramid=pyramid)
+            for c in range(imdb.num_classes - 1):
+                dets[c + 1][i - start] = dets_[c]
+            progress(i)
     if result_queue:
         result_queue.put((rank, dets))
         return

@@ -375,3 +375,48 @@ def test_image_pipeline_submit_collect():
     assert len(got) == 3
     for a, b in zip(got, ref):
         np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.parametrize("shape,scales,flip", [
+    ((97, 131), [1.0, 0.5, 1.7, 2.25, 0.3125], True),     # identity, down, up, exact-binary factor
+    ((64, 64), [0.25, 3.0], True),                          # already a multiple of MAX_RESOLUTION
+    ((33, 250), [0.0625, 1.0 / 3.0, 1.28], False),          # tiny level (3 rows), non-terminating factor
+])
+def test_device_preprocessing_bit_exact(shape, scales, flip, conv_mode):
+    """shf_make_pyramid_level == _get_image_blob + flip + pad of the host mirror, bit for bit
+    (mean subtraction and interpolation in float64, the blob narrowed to fp32 last)."""
+    if conv_mode != "fp32":
+        pytest.skip("no convolution in this test")
+    import torch
+    from smallhardface_amd import test as T
+    cfg.TEST.FLIP = flip
+    gnet, _ = H.make_pair(H.detector_msg(True), cls_bias=1.0)
+    im = np.random.default_rng(shape[0]).integers(0, 256, shape + (3,)).astype(np.uint8)
+    want = list(T.pyramid_units(im, scales))
+    dp = T.DevicePyramid(gnet)
+    got = dp.units(im, scales)
+    gnet.sync()
+    assert len(got) == len(want)
+    for g, w in zip(got, want):
+        assert tuple(g[1:5]) == tuple(w[1:5]) and g[5] == w[5] and g[6] == w[6]
+        n = 3 * g[1] * g[2]
+        base = dp._slots[0][0]
+        off = (g[0] - base.data_ptr()) // 4
+        dev = base[off:off + n].cpu().numpy().reshape(1, 3, g[1], g[2])
+        np.testing.assert_array_equal(dev.view(np.uint32), w[0].view(np.uint32))
+
+
+def test_device_preprocessing_feeds_the_detector():
+    """uint8 image -> device pyramid -> grouped detector == host pyramid -> grouped detector."""
+    from smallhardface_amd import test as T
+    cfg.MODEL.DIFFERENT_DILATION.ENABLE = True
+    cfg.TEST.SCALES = [100, 300, 500]
+    gnet, _ = H.make_pair(H.detector_msg(True), cls_bias=1.0)
+    fd = T.FusedDetector(gnet, n_lanes=6, mode="group")
+    dp = T.DevicePyramid(gnet)
+    for i in range(2):
+        im = np.random.default_rng(90 + i).integers(0, 256, (120 + 7 * i, 150, 3)).astype(np.uint8)
+        ref = fd.detect(list(T.pyramid_units(im)), thresh=0.05)[0]
+        got = fd.detect(dp.units(im), thresh=0.05, on_device=True)[0]
+        assert len(ref) > 0
+        np.testing.assert_array_equal(got, ref)

@@ -77,3 +77,20 @@ def test_gather_window_single():
     import torch
     local = {0: torch.zeros((3, 5))}
     assert pyramid.gather_window(local, 1, 0, 1)[0] is local[0]
+
+
+def test_pyramid_level_shape_matches_host_rounding():
+    """C ABI shf_pyramid_level_shape == the host mirror's dsize / pad arithmetic (no GPU needed)."""
+    from smallhardface_amd import caffe
+    rng = np.random.default_rng(3)
+    cases = [(600, 800, 0.5), (5, 7, 0.5), (3, 3, 2.5), (101, 203, 1.0), (1000, 1500, 0.8533333)]
+    cases += [(int(h), int(w), float(s)) for h, w, s in
+              zip(rng.integers(8, 2000, 200), rng.integers(8, 2000, 200), rng.uniform(0.05, 3.0, 200))]
+    for h, w, s in cases:
+        lh = h if s == 1.0 else int(np.round(h * s))
+        lw = w if s == 1.0 else int(np.round(w * s))
+        m = 16
+        want = (lh, lw, int(np.ceil(1.0 * lh / m) * m), int(np.ceil(1.0 * lw / m) * m))
+        assert caffe.pyramid_level_shape(h, w, s, m) == want, (h, w, s)
+    with pytest.raises(ValueError):
+        caffe.pyramid_level_shape(0, 5, 1.0, 16)

@@ -26,20 +26,30 @@ def test_cli_writes_wider_detections(tmp_path):
     (data / "wider_val.txt").write_text("\n".join(names) + "\n")
     model = str(tmp_path / "synthetic.caffemodel")
     caffemodel.write_caffemodel(model, weights.synth_params(H.detector_msg(True), cls_bias=1.0))
-    env = dict(os.environ, PYTHONPATH=ROOT)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "train_test.py"), "--train", "false", "--conf",
-                        os.path.join(ROOT, "configs", "smallhardface.toml"), "--amend", "TEST.MODEL", model,
-                        "DATA_DIR", str(data), "TEST.GPU_ID", "[0]", "TEST.SCALES", "[100, 300]", "EXP_DIR",
-                        str(tmp_path / "exp")], cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stderr[-2000:]
-    found = []
-    for root, _, files in os.walk(str(tmp_path / "exp")):
-        found += [os.path.join(root, f) for f in files if f.endswith(".txt") and "img" in f]
-    assert len(found) == 2, (found, r.stderr[-1500:])
-    lines = open(sorted(found)[0]).read().splitlines()
+    runs = {}
+    for fused in ("1", "0"):
+        env = dict(os.environ, PYTHONPATH=ROOT, SHF_FUSED_DETECT=fused)
+        exp = tmp_path / ("exp" + fused)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "train_test.py"), "--train", "false", "--conf",
+                            os.path.join(ROOT, "configs", "smallhardface.toml"), "--amend", "TEST.MODEL", model,
+                            "DATA_DIR", str(data), "TEST.GPU_ID", "[0]", "TEST.SCALES", "[100, 300]", "EXP_DIR",
+                            str(exp)], cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        found = []
+        for root, _, files in os.walk(str(exp)):
+            found += [os.path.join(root, f) for f in files if f.endswith(".txt") and "img" in f]
+        assert len(found) == 2, (found, r.stderr[-1500:])
+        runs[fused] = [open(f).read().splitlines() for f in sorted(found)]
+    lines = runs["1"][0]
     assert lines[0] == names[0] and int(lines[1]) == len(lines) - 2 and int(lines[1]) >= 1
     x, y, w, h, s = lines[2].split()
     assert int(w) >= 0 and int(h) >= 0 and 0.0 < float(s) <= 1.0
+    # device-resident path (default) == one Net.forward() per unit (the reference's call pattern)
+    for a, b in zip(runs["1"], runs["0"]):
+        assert a[:2] == b[:2]
+        for la, lb in zip(a[2:], b[2:]):
+            fa, fb = la.split(), lb.split()
+            assert fa[:4] == fb[:4] and abs(float(fa[4]) - float(fb[4])) <= 1e-4
 
 
 def test_cli_refuses_training():
