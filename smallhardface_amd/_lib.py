@@ -9,7 +9,7 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libshf_hip.so")
+LIB_PATH = os.environ.get("SHF_LIB") or os.path.join(_HERE, "libshf_hip.so")  # SHF_LIB: kernel-variant experiments
 HEADER_PATH = os.path.join(_HERE, "..", "include", "shf_hip.h")
 
 _lib = None

@@ -24,7 +24,8 @@ struct ConvK {
   const float* bias;
   int Cin, Cout;
   int in_stride, out_stride;
-  int dil, relu;     // relu bit 0: ReLU; bit 3 (8): do NOT write the un-pooled output
+  int dil, relu;     // relu bit 0: ReLU; bit 3 (8): do NOT write the un-pooled output; bit 4 (16): views are
+                     // 16-byte aligned -> LDS-transposed float4 epilogue
   int pool_stride;   // floats per pixel of the pool buffer
   int nct, nmem;
   const float* w1t;  // FUSE1: first-layer weights transposed to [27][64]
@@ -67,6 +68,76 @@ __device__ __forceinline__ void conv_store_tile(GetV getv, float bv, int relu_fl
     if (gpool && gy0 < H && gx < W) {
       const int Hp = (H + 1) >> 1, Wp = (W + 1) >> 1;
       gpool[((size_t)(b * Hp + (gy0 >> 1)) * Wp + (gx >> 1)) * pool_stride + cout] = m;
+    }
+  }
+}
+
+// LDS-transposed epilogue for a 16x16-pixel x BN-cout block tile.  An MFMA accumulator lane holds ONE
+// cout for 16 pixels, so storing it directly is 4-byte stores, 128 B per wave-instruction, hundreds of
+// them per thread (measured: ~50 k cycles per tile, a third of a short-K layer).  Instead the tile is
+// parked in LDS as Cs[pixel][BN + 4] (the K-loop buffers are dead by then) and written out along the
+// channel axis: float4 per lane, 512 contiguous bytes per pixel, and the fused 2x2 pool becomes a max
+// over four float4 rows.  Needs 16-byte aligned channel views (the launcher checks and otherwise keeps
+// the scalar conv_store_tile path).
+constexpr int CS_PAD = 4;
+
+// stage the 2x16-pixel x 32-cout MFMA tile of one lane: local rows ly0, ly0+1; `cl` = local cout
+template <int BN, typename GetV>
+__device__ __forceinline__ void conv_stage_tile(float* __restrict__ Cs, GetV getv, float bv, int relu_flags, int ly0,
+                                                int kh, int cl) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int lx = 2 * (2 * q + kh);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      float v = getv(4 * q + s) + bv;
+      if (relu_flags & 1) v = fmaxf(v, 0.f);
+      Cs[((ly0 + (s >> 1)) * 16 + lx + (s & 1)) * (BN + CS_PAD) + cl] = v;
+    }
+  }
+}
+
+// write the staged tile (and its 2x2/2 max-pool) to global memory; all NT threads of the block
+template <int BN, int NT>
+__device__ __forceinline__ void conv_flush_tile(const float* __restrict__ Cs, int tid, int ty0, int tx0, int H, int W,
+                                                int b, int cout0, float* __restrict__ gout, int out_stride,
+                                                float* __restrict__ gpool, int pool_stride, bool write_main) {
+  constexpr int CG = BN / 4;       // float4 groups per pixel
+  constexpr int PPI = NT / CG;     // pixels per block-wide store instruction
+  const int cg = tid % CG, p0 = tid / CG;
+  if (write_main) {
+#pragma unroll 4
+    for (int pp = p0; pp < 256; pp += PPI) {
+      const int y = ty0 + (pp >> 4), x = tx0 + (pp & 15);
+      if (y < H && x < W) {
+        const float4 v = *(const float4*)(Cs + pp * (BN + CS_PAD) + cg * 4);
+        *(float4*)(gout + ((size_t)(b * H + y) * W + x) * out_stride + cout0 + cg * 4) = v;
+      }
+    }
+  }
+  if (gpool) {
+    const int Hp = (H + 1) >> 1, Wp = (W + 1) >> 1;
+#pragma unroll 2
+    for (int pp = p0; pp < 64; pp += PPI) {
+      const int ly = (pp >> 3) * 2, lx = (pp & 7) * 2;
+      const int y = ty0 + ly, x = tx0 + lx;
+      if (y < H && x < W) {
+        // windows on a ragged edge are clipped like Caffe's (pooling_layer.cu:24-27)
+        const float* c0 = Cs + (ly * 16 + lx) * (BN + CS_PAD) + cg * 4;
+        float4 m = make_float4(-3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f);
+        auto mx = [&](const float* q) {
+          const float4 v = *(const float4*)q;
+          m.x = v.x > m.x ? v.x : m.x; m.y = v.y > m.y ? v.y : m.y;
+          m.z = v.z > m.z ? v.z : m.z; m.w = v.w > m.w ? v.w : m.w;
+        };
+        mx(c0);
+        if (x + 1 < W) mx(c0 + (BN + CS_PAD));
+        if (y + 1 < H) {
+          mx(c0 + 16 * (BN + CS_PAD));
+          if (x + 1 < W) mx(c0 + 17 * (BN + CS_PAD));
+        }
+        *(float4*)(gpool + ((size_t)(b * Hp + (y >> 1)) * Wp + (x >> 1)) * pool_stride + cout0 + cg * 4) = m;
+      }
     }
   }
 }

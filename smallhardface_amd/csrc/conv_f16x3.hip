@@ -18,9 +18,11 @@
 // buffered in LDS (fetched two stages ahead into registers, parked at the top of the stage);
 // the 18x18x32 halo tile is staged once per chunk and reused by all 9 taps.  LDS rows are
 // [hi: 32 halfs][lo: 32 halfs][16 B pad] = 144 B (conflict-free ds_read_b128).
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 #include "conv_common.h"
 
@@ -32,6 +34,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #ifndef F16X3_DMA_LATE
 #define F16X3_DMA_LATE 1   // 1: the early-finishing waves 0-3 issue the next stage's weight DMA after their MFMAs
+#endif
+#ifndef F16X3_PIPE
+#define F16X3_PIPE 0       // 1: explicit LDS->register software pipeline in the stages without a halo hand-over
 #endif
 #ifndef F16X3_CONV_MID
 #define F16X3_CONV_MID 1   // 1: split the next halo tile to fp16 hi/lo in the middle of the last stage's MFMAs
@@ -131,8 +136,7 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_kernel(ConvK p) {
     a_goff[j] = in ? ((b * H + gy) * W + gx) * p.in_stride + q * 4 : -1;
     a_loff[j] = (idx < HP * 8) ? hp * ROWB + q * 8 : -1;
   }
-  float4 areg[ALD];
-  half4 ahi[ALD], alo[ALD];
+  float4 areg0[ALD];  // prologue only: the halo registers of the main loop are local to the hand-over stage
   // Weight slabs go global -> LDS by DMA (global_load_lds_dwordx4: no registers, no ds_write): the
   // packed global layout already has the padded 144-B rows, so a stage (3 slabs of the block's BN
   // couts) is 3 contiguous runs copied in 1-KiB pieces, one piece per wave-instruction.
@@ -218,7 +222,7 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_kernel(ConvK p) {
     const float* inc_ = gin;
 #pragma unroll
     for (int j = 0; j < ALD; ++j)
-      areg[j] = (a_goff[j] >= 0) ? *(const float4*)(inc_ + a_goff[j]) : make_float4(0.f, 0.f, 0.f, 0.f);
+      areg0[j] = (a_goff[j] >= 0) ? *(const float4*)(inc_ + a_goff[j]) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
   F16X3_DMA_W(0, 0, 8);
   if constexpr (FUSE1) {
@@ -228,20 +232,24 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_kernel(ConvK p) {
     for (int j = 0; j < ALD; ++j)
       if (a_loff[j] >= 0) {
         half4 hi, lo;
-        split4(areg[j], hi, lo);
+        split4(areg0[j], hi, lo);
         *(half4*)(As + a_loff[j]) = hi;
         *(half4*)(As + a_loff[j] + 64) = lo;
       }
   }
 
-  int c = 0, ky = 0;
 #ifdef SHF_CONV_TIMING
   unsigned long long tb = 0, ti = 0, tc = 0, tx = 0, t0, t1, t2, t3;
 #define SHF_T(x) x = __builtin_amdgcn_s_memtime()
 #else
 #define SHF_T(x)
 #endif
-  for (int st = 0; st < NST; ++st) {
+  for (int c = 0; c < nchunks; ++c) {
+   float4 areg[ALD];
+   half4 ahi[ALD], alo[ALD];
+#pragma unroll
+   for (int ky = 0; ky < 3; ++ky) {
+    const int st = c * 3 + ky;
     SHF_T(t0);
     // LDS-DMA is only ordered by the issuing wave's own vmcnt: drain it by hand before the barrier
     // (hipcc drops this wait when the DMA sits behind the loop back-edge / in a wave-uniform branch)
@@ -264,6 +272,53 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_kernel(ConvK p) {
     SHF_T(t2);
     const unsigned char* Arow = As + (ky * HTW) * ROWB;
     const unsigned char* Bst = Bs + (st & 1) * (3 * BN * ROWB);
+#if F16X3_PIPE
+    bool piped = false;
+    if constexpr (MT == 2) {
+      if (!(last_row && more_chunks)) {
+        // software pipeline over the six k-steps of the stage: the fragments of step s+1 are fetched
+        // from LDS (into the other register set) underneath the 12 MFMAs of step s.  The stage that
+        // also carries the next halo tile in registers has no room for the second set.
+        piped = true;
+        half8 fa[2][4], fb[2][4];
+        auto load_frag = [&](int s_, half8* a, half8* bf) {
+          const unsigned char* Ap = Arow + (s_ >> 1) * ROWB + (s_ & 1) * 32;
+          const unsigned char* Bp = Bst + (s_ >> 1) * (BN * ROWB) + (s_ & 1) * 32;
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            a[2 * t] = *(const half8*)(Ap + a_off[t]);
+            a[2 * t + 1] = *(const half8*)(Ap + a_off[t] + 64);
+            bf[2 * t] = *(const half8*)(Bp + b_off[t]);
+            bf[2 * t + 1] = *(const half8*)(Bp + b_off[t] + 64);
+          }
+        };
+        load_frag(0, fa[0], fb[0]);
+#pragma unroll
+        for (int s_ = 0; s_ < 6; ++s_) {
+          half8* a = fa[s_ & 1];
+          half8* bf = fb[s_ & 1];
+          if (s_ + 1 < 6) load_frag(s_ + 1, fa[(s_ + 1) & 1], fb[(s_ + 1) & 1]);
+#pragma unroll
+          for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn) {
+              accm[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[2 * tm], bf[2 * tn], accm[tm][tn], 0, 0, 0);
+              accc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[2 * tm], bf[2 * tn + 1], accc[tm][tn], 0, 0, 0);
+              accc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[2 * tm + 1], bf[2 * tn], accc[tm][tn], 0, 0, 0);
+            }
+          if (s_ + 1 < 6) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);  // 3 MFMA
+              __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // 2 LDS reads of the next step
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);  // keep the scheduler from piling later steps' reads up here
+        }
+      }
+    }
+    if (!piped)
+#endif
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) {
       const unsigned char* Ap = Arow + kx * ROWB;
@@ -331,31 +386,26 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_kernel(ConvK p) {
     SHF_T(t3);
     tb += t1 - t0; ti += t2 - t1; tc += t3 - t2;
 #endif
-    if (last_row) {
-      if (more_chunks) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();  // every wave is done reading the halo tile of chunk c
-        if constexpr (FUSE1) {
-          first_store();
-        } else {
+    if (last_row && more_chunks) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();  // every wave is done reading the halo tile of chunk c
+      if constexpr (FUSE1) {
+        first_store();
+      } else {
 #pragma unroll
-          for (int j = 0; j < ALD; ++j)
-            if (a_loff[j] >= 0) {
-              if (!F16X3_CONV_MID) split4(areg[j], ahi[j], alo[j]);
-              *(half4*)(As + a_loff[j]) = ahi[j];
-              *(half4*)(As + a_loff[j] + 64) = alo[j];
-            }
-        }
+        for (int j = 0; j < ALD; ++j)
+          if (a_loff[j] >= 0) {
+            if (!F16X3_CONV_MID) split4(areg[j], ahi[j], alo[j]);
+            *(half4*)(As + a_loff[j]) = ahi[j];
+            *(half4*)(As + a_loff[j] + 64) = alo[j];
+          }
       }
-      ky = 0;
-      ++c;
-    } else {
-      ++ky;
     }
 #ifdef SHF_CONV_TIMING
     SHF_T(t0);
     tx += t0 - t3;
 #endif
+   }
   }
 #ifdef SHF_CONV_TIMING
   if (p.dbg && lane == 0 && (bid == 0 || bid == 100)) {
@@ -366,6 +416,24 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_kernel(ConvK p) {
 #undef F16X3_DMA_W
 
   // epilogue: C row = (r&3) + 8*(r>>2) + 4*(lane>>5), C col = lane&31
+  if (p.relu & 16) {
+    __syncthreads();  // the K loop's LDS buffers are dead: the output tile is transposed through them
+    float* Cs = (float*)smem;
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) {
+      const int cl = wn * 64 + tn * 32 + i;
+      const float bv = p.bias ? p.bias[ct * BN + cl] : 0.f;
+#pragma unroll
+      for (int tm = 0; tm < MT; ++tm) {
+        const f32x16 am = accm[tm][tn], ac = accc[tm][tn];
+        conv_stage_tile<BN>(Cs, [&](int r) { return am[r] + ac[r] * LO_INV; }, bv, p.relu, wm * 2 * MT + tm * 2, kh, cl);
+      }
+    }
+    __syncthreads();
+    conv_flush_tile<BN, 512>(Cs, tid, ty0, tx0, H, W, b, ct * BN, gout, p.out_stride, mem.pool, p.pool_stride,
+                             !(p.relu & 8));
+    return;
+  }
 #pragma unroll
   for (int tn = 0; tn < 2; ++tn) {
     const int cout = ct * BN + wn * 64 + tn * 32 + i;
@@ -377,6 +445,287 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_kernel(ConvK p) {
                       H, W, b, cout, gout, p.out_stride, mem.pool, p.pool_stride);
     }
   }
+}
+
+// One-wave-per-SIMD variant for Cout % 128 == 0: block = 256 threads = 4 waves (2 M x 2 N), each wave
+// 128 px x 64 couts = 16 accumulator tiles (main + corr: 256 registers, the AGPR half of the 512 a lone
+// wave owns).  Against the 8-wave kernel: 12 LDS fragment reads per 24 MFMAs instead of 8 per 12, and
+// room for a second fragment set, so the six k-steps of a stage run as an explicit software pipeline
+// (step s+1's ds_reads interleaved 1:2 with step s's MFMAs) -- the matrix pipe only idles at the stage
+// barriers.  The weight DMA for stage st+1 is issued right after the barrier of stage st (a full stage
+// of slack), the next chunk's halo tile is fetched, split and parked in registers under the last stage.
+__global__ __launch_bounds__(256) void conv_mfma_f16x3_w4_kernel(ConvK p) {
+  using namespace f16x3;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+#ifdef SHF_CONV_TIMING
+  const unsigned long long t_entry = __builtin_amdgcn_s_memtime(), r_entry = __builtin_amdgcn_s_memrealtime();
+#endif
+  constexpr int BN = 128, MT = 4, NT = 256;
+  constexpr int ALD = (HP * 8 + NT - 1) / NT;  // float4 halo pieces per thread: 11
+  unsigned char* As = smem;                    // [HP][ROWB]
+  unsigned char* Bs = smem + HP * ROWB;        // [2][3][BN][ROWB]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave & 1, wm = wave >> 1;
+  const int bid = blockIdx.x;
+  const int ct = bid % p.nct;
+  int pt = bid / p.nct;
+  int mi = 0;
+#pragma unroll 1
+  for (int q = 1; q < p.nmem; ++q)
+    if (pt >= p.m[q].tile_start) mi = q;
+  const ConvMember& mem = p.m[mi];
+  pt -= mem.tile_start;
+  const int b = pt / mem.tiles_per_img;
+  pt -= b * mem.tiles_per_img;
+  const int ty0 = (pt / mem.tiles_x) * TH, tx0 = (pt % mem.tiles_x) * TW;
+  const int H = mem.H, W = mem.W;
+  const float* __restrict__ gin = mem.in;
+  float* __restrict__ gout = mem.out;
+
+  const int i = lane & 31, kh = lane >> 5;
+  int dy, px;
+  row_to_pixel(i, dy, px);
+  int a_off[MT], b_off[2];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) a_off[t] = ((wm * 2 * MT + t * 2 + dy) * HTW + px) * ROWB + kh * 16;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) b_off[t] = (wn * 64 + t * 32 + i) * ROWB + kh * 16;
+
+  f32x16 accm[MT][2], accc[MT][2];
+#pragma unroll
+  for (int a = 0; a < MT; ++a)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { accm[a][c][r] = 0.f; accc[a][c][r] = 0.f; }
+
+  const int nchunks = p.Cin / KC;
+  const int NST = nchunks * 3;
+  const _Float16* wsp = (const _Float16*)p.wp;
+  const size_t slab = (size_t)p.Cout * 72;
+  const _Float16* wbase = wsp + (size_t)ct * BN * 72;
+
+  // halo piece j of this thread: float4 q of halo pixel hp0 + 32 j (LDS offset = a_loff0 + j * 32 rows).
+  // Pieces are fetched unconditionally -- out-of-image lanes read the member's first pixel and are
+  // zeroed afterwards (bit j of a_valid) -- because predicated loads would split the MFMA
+  // scheduling region into basic blocks.
+  int a_gsafe[ALD];
+  unsigned a_valid = 0;
+  const int a_loff0 = (tid >> 3) * ROWB + (tid & 7) * 8;
+  const bool a_last = tid + NT * (ALD - 1) < HP * 8;  // the ragged last piece exists for this thread
+#pragma unroll
+  for (int j = 0; j < ALD; ++j) {
+    const int idx = tid + NT * j;
+    const int hp = idx >> 3, q = idx & 7;
+    const int hy = hp / HTW, hx = hp - hy * HTW;
+    const int gy = ty0 - 1 + hy, gx = tx0 - 1 + hx;
+    const bool in = (idx < HP * 8) && ((unsigned)gy < (unsigned)H) && ((unsigned)gx < (unsigned)W);
+    a_gsafe[j] = in ? ((b * H + gy) * W + gx) * p.in_stride + q * 4 : 0;
+    a_valid |= in ? (1u << j) : 0u;
+  }
+  // fp32 piece -> [hi half4 | lo half4] in the same four registers
+  auto split_inplace = [&](float4& v, bool valid) {
+    half4 hi, lo;
+    split4(valid ? v : make_float4(0.f, 0.f, 0.f, 0.f), hi, lo);
+    const float2 h2 = __builtin_bit_cast(float2, hi), l2 = __builtin_bit_cast(float2, lo);
+    v = make_float4(h2.x, h2.y, l2.x, l2.y);
+  };
+  auto store_piece = [&](const float4& v, int j) {
+    *(float2*)(As + a_loff0 + j * 32 * ROWB) = make_float2(v.x, v.y);
+    *(float2*)(As + a_loff0 + j * 32 * ROWB + 64) = make_float2(v.z, v.w);
+  };
+  constexpr int SLAB_B = BN * ROWB;
+  constexpr int PCS_SLAB = SLAB_B / 1024;
+  constexpr int PCS = 3 * PCS_SLAB;          // 54 one-KiB DMA pieces per stage
+  constexpr int DMA_ROUNDS = (PCS + 3) / 4;  // 14 per wave; waves 2,3 repeat piece 53 in the last round
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  // rounds [j0, j0+n) of the weight DMA for `stage` into buffer `buf`; branch-free so that it can sit
+  // inside the MFMA scheduling region
+  auto dma_w = [&](int stage, int buf, int j0, int n) {
+    const unsigned char* ws_ = (const unsigned char*)(wbase + (size_t)stage * 3 * slab);
+    unsigned char* bd_ = Bs + buf * (3 * SLAB_B);
+#pragma unroll
+    for (int j = j0; j < j0 + n; ++j) {
+      int pc = wave_u + 4 * j;
+      if (4 * j + 3 >= PCS) pc = pc < PCS ? pc : PCS - 1;
+      const int sl = pc / PCS_SLAB, within = pc - sl * PCS_SLAB;
+      const unsigned char* src = ws_ + (size_t)sl * slab * 2 + within * 1024 + lane * 16;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(bd_ + pc * 1024), 16, 0, 0);
+    }
+  };
+  {  // prologue: halo(0) and W(0) into LDS
+    float4 areg0[ALD];
+#pragma unroll
+    for (int j = 0; j < ALD; ++j) areg0[j] = *(const float4*)(gin + a_gsafe[j]);
+    dma_w(0, 0, 0, DMA_ROUNDS);
+#pragma unroll
+    for (int j = 0; j < ALD; ++j) {
+      split_inplace(areg0[j], (a_valid >> j) & 1);
+      if (j + 1 < ALD || a_last) store_piece(areg0[j], j);
+    }
+  }
+
+#ifdef SHF_CONV_TIMING
+  unsigned long long tb = 0, tc = 0, tx = 0, t0, t1, t3;
+  const unsigned long long t_loop = __builtin_amdgcn_s_memtime();
+#endif
+  // one stage = kernel row KY of chunk c; HANDOVER: also fetch / split / park the halo tile of chunk c+1
+  auto stage = [&](int c, auto KY_, auto HANDOVER_) {
+    constexpr int ky = decltype(KY_)::value;
+    constexpr bool HANDOVER = decltype(HANDOVER_)::value;
+    const int st = c * 3 + ky;
+    SHF_T(t0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of W(st) has landed
+    __syncthreads();
+    SHF_T(t1);
+    const int st_next = st + 1 < NST ? st + 1 : st;  // the last stage re-fetches itself (unused) instead of branching
+    const int buf_next = (st + 1) & 1;
+    float4 areg[ALD];
+    const float* inc_ = gin + (c + 1) * KC;
+    const unsigned char* Arow = As + (ky * HTW) * ROWB;
+    const unsigned char* Bst = Bs + (st & 1) * (3 * BN * ROWB);
+    half8 fa[2][2 * MT], fb[2][4];
+    auto load_frag = [&](int s_, half8* a, half8* bf) {
+      const unsigned char* Ap = Arow + (s_ >> 1) * ROWB + (s_ & 1) * 32;
+      const unsigned char* Bp = Bst + (s_ >> 1) * (BN * ROWB) + (s_ & 1) * 32;
+#pragma unroll
+      for (int t = 0; t < MT; ++t) {
+        a[2 * t] = *(const half8*)(Ap + a_off[t]);
+        a[2 * t + 1] = *(const half8*)(Ap + a_off[t] + 64);
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        bf[2 * t] = *(const half8*)(Bp + b_off[t]);
+        bf[2 * t + 1] = *(const half8*)(Bp + b_off[t] + 64);
+      }
+    };
+    load_frag(0, fa[0], fb[0]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s_ = 0; s_ < 6; ++s_) {
+      half8* a = fa[s_ & 1];
+      half8* bf = fb[s_ & 1];
+      if (s_ + 1 < 6) load_frag(s_ + 1, fa[(s_ + 1) & 1], fb[(s_ + 1) & 1]);
+      // the stage's side jobs ride under the MFMAs, a few per k-step so that no queue ever fills
+      constexpr int DMA_J0[6] = {0, 3, 6, 9, 12, 14}, DMA_N[6] = {3, 3, 3, 3, 2, 0};
+      if (DMA_N[s_]) dma_w(st_next, buf_next, DMA_J0[s_], DMA_N[s_]);
+      int n_vmem = DMA_N[s_];
+      if constexpr (HANDOVER) {
+        if (s_ < 2) {
+#pragma unroll
+          for (int j = s_ * 6; j < (s_ ? ALD : 6); ++j) areg[j] = *(const float4*)(inc_ + a_gsafe[j]);
+          n_vmem += s_ ? ALD - 6 : 6;
+        } else {
+#pragma unroll
+          for (int j = (s_ - 2) * 3; j < (s_ == 5 ? ALD : (s_ - 1) * 3); ++j)
+            split_inplace(areg[j], (a_valid >> j) & 1);
+        }
+      }
+      // three sweeps over the 8 output tiles: consecutive MFMAs never chain on one accumulator
+#pragma unroll
+      for (int tm = 0; tm < MT; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+          accm[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[2 * tm], bf[2 * tn], accm[tm][tn], 0, 0, 0);
+#pragma unroll
+      for (int tm = 0; tm < MT; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+          accc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[2 * tm], bf[2 * tn + 1], accc[tm][tn], 0, 0, 0);
+#pragma unroll
+      for (int tm = 0; tm < MT; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+          accc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[2 * tm + 1], bf[2 * tn], accc[tm][tn], 0, 0, 0);
+      if (s_ + 1 < 6) {
+        // next step's 12 fragment reads go out under the first 12 MFMAs (12 more to land), the VMEM
+        // issues are spread over the second half
+#pragma unroll
+        for (int g = 0; g < 12; ++g) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+#pragma unroll
+        for (int g = 0; g < 9; ++g) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          if (g < n_vmem) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#ifdef SHF_CONV_TIMING
+    asm volatile("s_nop 0" ::: "memory");
+    SHF_T(t3);
+    tb += t1 - t0; tc += t3 - t1;
+#endif
+    if constexpr (HANDOVER) {
+      __syncthreads();  // every wave is done reading the halo tile of chunk c
+#pragma unroll
+      for (int j = 0; j < ALD; ++j)
+        if (j + 1 < ALD || a_last) store_piece(areg[j], j);
+    }
+#ifdef SHF_CONV_TIMING
+    SHF_T(t0);
+    tx += t0 - t3;
+#endif
+  };
+  using std::integral_constant;
+  // the last chunk is peeled so that the loop body is one straight path (a hand-over / no-hand-over
+  // branch inside it makes the two arms disagree on accumulator registers and pay for it every turn)
+#pragma unroll 1
+  for (int c = 0; c + 1 < nchunks; ++c) {
+    stage(c, integral_constant<int, 0>{}, integral_constant<bool, false>{});
+    stage(c, integral_constant<int, 1>{}, integral_constant<bool, false>{});
+    stage(c, integral_constant<int, 2>{}, integral_constant<bool, true>{});
+  }
+  stage(nchunks - 1, integral_constant<int, 0>{}, integral_constant<bool, false>{});
+  stage(nchunks - 1, integral_constant<int, 1>{}, integral_constant<bool, false>{});
+  stage(nchunks - 1, integral_constant<int, 2>{}, integral_constant<bool, false>{});
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last stage's (unused) self re-fetch
+#ifdef SHF_CONV_TIMING
+  const unsigned long long t_loop_end = __builtin_amdgcn_s_memtime();
+#endif
+
+  if (p.relu & 16) {
+    __syncthreads();  // the K loop's LDS buffers are dead: the output tile is transposed through them
+    float* Cs = (float*)smem;
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) {
+      const int cl = wn * 64 + tn * 32 + i;
+      const float bv = p.bias ? p.bias[ct * BN + cl] : 0.f;
+#pragma unroll
+      for (int tm = 0; tm < MT; ++tm) {
+        const f32x16 am = accm[tm][tn], ac = accc[tm][tn];
+        conv_stage_tile<BN>(Cs, [&](int r) { return am[r] + ac[r] * LO_INV; }, bv, p.relu, wm * 2 * MT + tm * 2, kh, cl);
+      }
+    }
+    __syncthreads();
+    conv_flush_tile<BN, NT>(Cs, tid, ty0, tx0, H, W, b, ct * BN, gout, p.out_stride, mem.pool, p.pool_stride,
+                            !(p.relu & 8));
+  } else {
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) {
+      const int cout = ct * BN + wn * 64 + tn * 32 + i;
+      const float bv = p.bias ? p.bias[cout] : 0.f;
+#pragma unroll
+      for (int tm = 0; tm < MT; ++tm) {
+        const f32x16 am = accm[tm][tn], ac = accc[tm][tn];
+        conv_store_tile([&](int r) { return am[r] + ac[r] * LO_INV; }, bv, p.relu, ty0 + wm * 2 * MT + tm * 2, tx0,
+                        kh, H, W, b, cout, gout, p.out_stride, mem.pool, p.pool_stride);
+      }
+    }
+  }
+#ifdef SHF_CONV_TIMING
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const unsigned long long t_exit = __builtin_amdgcn_s_memtime(), r_exit = __builtin_amdgcn_s_memrealtime();
+  if (p.dbg && lane == 0 && (bid == 0 || bid == 100)) {
+    unsigned long long* d = p.dbg + ((bid ? 1 : 0) * 8 + wave) * 5;
+    d[0] = tb; d[1] = ((t_loop - t_entry) << 32) | (t_exit - t_loop_end); d[2] = tc; d[3] = tx;
+    d[4] = NST | ((t_exit - t_entry) << 16) | ((r_exit - r_entry) << 40);
+  }
+#endif
 }
 
 // ---------------------------------------------------------------------------
@@ -401,6 +750,11 @@ void pack_conv_weights_split16(const float* w, int Cout, int Cin, int k, void* d
       }
 }
 
+bool conv_f16x3_uses_w4(int Cin) {
+  static const int w4_mode = getenv("SHF_F16X3_W4") ? atoi(getenv("SHF_F16X3_W4")) : -1;
+  return w4_mode < 0 ? Cin >= 256 : w4_mode != 0;
+}
+
 bool conv_f16x3_eligible(int Cin, int Cout, int k, int pad, int dil) {
   return k == 3 && dil == 1 && pad == 1 && Cin % 32 == 0 && Cout % 64 == 0;
 }
@@ -422,8 +776,11 @@ static int launch_f16x3_t(const ConvArgs* as, int n, hipStream_t s) {
   p.w1t = a.w1t;
   p.b1 = a.b1;
   long long tiles = 0;
+  bool vec_ok = !(getenv("SHF_CONV_SCALAR_EPILOGUE") && atoi(getenv("SHF_CONV_SCALAR_EPILOGUE")));
   for (int i = 0; i < n; ++i) {
     const ConvArgs& q = as[i];
+    vec_ok = vec_ok && (q.out.cstride % 4 == 0) && (q.out.coff % 4 == 0) && (((uintptr_t)q.out.p & 15) == 0) &&
+             (!q.pool.p || ((q.pool.cstride % 4 == 0) && (q.pool.coff % 4 == 0) && (((uintptr_t)q.pool.p & 15) == 0)));
     if (FUSE1 && !q.img) { set_error("conv f16x3: fused first layer needs the image pointer"); return -1; }
     if (q.in.C != p.Cin || q.out.C != p.Cout || q.in.cstride != p.in_stride || q.out.cstride != p.out_stride ||
         q.wsplit16 != a.wsplit16) {
@@ -441,6 +798,7 @@ static int launch_f16x3_t(const ConvArgs* as, int n, hipStream_t s) {
     m.tile_start = (int)tiles;
     tiles += (long long)m.tiles_per_img * m.B;
   }
+  if (vec_ok) p.relu |= 16;
   const size_t lds = (size_t)HP * ROWB + 2 * 3 * (size_t)BN * ROWB +
                      (FUSE1 ? (3 * (TH + 4) * (TW + 4) + 27 * 64 + 64) * sizeof(float) : 0);
 #ifdef SHF_CONV_TIMING
@@ -449,7 +807,13 @@ static int launch_f16x3_t(const ConvArgs* as, int n, hipStream_t s) {
   hipMemset(dbg_dev, 0, 16 * 5 * 8);
   p.dbg = dbg_dev;
 #endif
-  hipLaunchKernelGGL((conv_mfma_f16x3_kernel<BN, FUSE1>), dim3((unsigned)(tiles * p.nct)), dim3(512), lds, s, p);
+  // the 4-wave kernel has the faster K loop (~6.2 k cycles per stage against ~7 k) but the dearer
+  // prologue / epilogue (half the waves to fetch the first tiles and to write the result): it wins from
+  // 8 input-channel chunks up.  SHF_F16X3_W4 = 0 / 1 forces never / always (experiments).
+  if (BN == 128 && !FUSE1 && conv_f16x3_uses_w4(p.Cin))
+    hipLaunchKernelGGL(conv_mfma_f16x3_w4_kernel, dim3((unsigned)(tiles * p.nct)), dim3(256), lds, s, p);
+  else
+    hipLaunchKernelGGL((conv_mfma_f16x3_kernel<BN, FUSE1>), dim3((unsigned)(tiles * p.nct)), dim3(512), lds, s, p);
   SHF_HIP_OK(hipGetLastError());
 #ifdef SHF_CONV_TIMING
   {
@@ -457,10 +821,18 @@ static int launch_f16x3_t(const ConvArgs* as, int n, hipStream_t s) {
     hipStreamSynchronize(s);
     hipMemcpy(h, dbg_dev, sizeof(h), hipMemcpyDeviceToHost);
     for (int w = 0; w < 16; w += 3)
-      if (h[w * 5 + 4])
-        fprintf(stderr, "[f16x3 timing] blk%d wave%d stages %llu: per-stage cycles barrier %.0f issue %.0f compute %.0f tail %.0f\n",
-                w / 8 ? 100 : 0, w % 8, h[w * 5 + 4], (double)h[w * 5] / h[w * 5 + 4], (double)h[w * 5 + 1] / h[w * 5 + 4],
-                (double)h[w * 5 + 2] / h[w * 5 + 4], (double)h[w * 5 + 3] / h[w * 5 + 4]);
+      if (h[w * 5 + 4]) {
+        const unsigned long long nst = h[w * 5 + 4] & 0xffff, tot = (h[w * 5 + 4] >> 16) & 0xffffff, rt = h[w * 5 + 4] >> 40;
+        if (tot)
+          fprintf(stderr, "[f16x3 timing] blk%d wave%d stages %llu: per-stage cycles barrier %.0f compute %.0f tail %.0f | "
+                  "prologue %llu epilogue %llu total %llu cycles, %.2f GHz\n", w / 8 ? 100 : 0, w % 8, nst,
+                  (double)h[w * 5] / nst, (double)h[w * 5 + 2] / nst, (double)h[w * 5 + 3] / nst, h[w * 5 + 1] >> 32,
+                  h[w * 5 + 1] & 0xffffffffull, tot, rt ? tot / (rt * 10.0) : 0.0);
+        else
+          fprintf(stderr, "[f16x3 timing] blk%d wave%d stages %llu: per-stage cycles barrier %.0f issue %.0f compute %.0f tail %.0f\n",
+                  w / 8 ? 100 : 0, w % 8, nst, (double)h[w * 5] / nst, (double)h[w * 5 + 1] / nst,
+                  (double)h[w * 5 + 2] / nst, (double)h[w * 5 + 3] / nst);
+      }
   }
 #endif
   return 0;
@@ -469,6 +841,8 @@ static int launch_f16x3_t(const ConvArgs* as, int n, hipStream_t s) {
 int conv_f16x3_init_attributes() {
   SHF_HIP_OK(hipFuncSetAttribute((const void*)conv_mfma_f16x3_kernel<128, false>,
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  SHF_HIP_OK(hipFuncSetAttribute((const void*)conv_mfma_f16x3_w4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 160 * 1024));
   SHF_HIP_OK(hipFuncSetAttribute((const void*)conv_mfma_f16x3_kernel<64, false>,
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   SHF_HIP_OK(hipFuncSetAttribute((const void*)conv_mfma_f16x3_kernel<64, true>,

@@ -28,7 +28,10 @@ SHAPES = [  # name, cin, cout, k, dil, h, w
 
 def main():
     reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+    only = sys.argv[2].split(",") if len(sys.argv) > 2 else None
     for name, cin, cout, k, dil, h, w in SHAPES:
+        if only and name not in only:
+            continue
         pad = dil if k == 3 else 0
         txt = H.single_layer_net(conv_layer("c0", "data", cin, 3, 1) + conv_layer("c1", "c0", cout, k, pad, dil), 3, h, w)
         msg = P.parse(txt)
