@@ -97,31 +97,45 @@ __device__ __forceinline__ void conv_stage_tile(float* __restrict__ Cs, GetV get
   }
 }
 
-// write the staged tile (and its 2x2/2 max-pool) to global memory; all NT threads of the block
+// write the staged tile (and its 2x2/2 max-pool) to global memory; all NT threads of the block.
+// A block-wide store covers PPI = NT / (BN/4) pixels; the walk over the 256 pixels is fully unrolled
+// with compile-time (row, column) steps so that an iteration is one LDS read, one predicate and one
+// float4 store off a running pointer.
 template <int BN, int NT>
 __device__ __forceinline__ void conv_flush_tile(const float* __restrict__ Cs, int tid, int ty0, int tx0, int H, int W,
                                                 int b, int cout0, float* __restrict__ gout, int out_stride,
                                                 float* __restrict__ gpool, int pool_stride, bool write_main) {
   constexpr int CG = BN / 4;       // float4 groups per pixel
-  constexpr int PPI = NT / CG;     // pixels per block-wide store instruction
+  constexpr int PPI = NT / CG;     // pixels per block-wide store instruction: 8 (4 waves x BN 128), 16 or 32
+  static_assert(PPI == 8 || PPI == 16 || PPI == 32, "tile walk assumes 8, 16 or 32 pixels per store round");
   const int cg = tid % CG, p0 = tid / CG;
   if (write_main) {
-#pragma unroll 4
-    for (int pp = p0; pp < 256; pp += PPI) {
-      const int y = ty0 + (pp >> 4), x = tx0 + (pp & 15);
-      if (y < H && x < W) {
-        const float4 v = *(const float4*)(Cs + pp * (BN + CS_PAD) + cg * 4);
-        *(float4*)(gout + ((size_t)(b * H + y) * W + x) * out_stride + cout0 + cg * 4) = v;
+    constexpr int XS = PPI < 16 ? 16 / PPI : 1;   // store rounds per tile row
+    constexpr int YS = PPI < 16 ? 1 : PPI / 16;   // tile rows per store round
+    const int y0 = ty0 + (p0 >> 4), x0 = tx0 + (p0 & 15);
+    const float* cs = Cs + p0 * (BN + CS_PAD) + cg * 4;
+    float* g = gout + ((size_t)(b * H + y0) * W + x0) * out_stride + cout0 + cg * 4;
+    const size_t row_pitch = (size_t)W * out_stride;
+#pragma unroll
+    for (int r = 0; r < 16 / YS; ++r) {
+#pragma unroll
+      for (int c = 0; c < XS; ++c) {
+        const int y = y0 + r * YS, x = x0 + c * PPI;
+        if (y < H && x < W) {
+          const float4 v = *(const float4*)(cs + (r * YS * 16 + c * PPI) * (BN + CS_PAD));
+          *(float4*)(g + r * YS * row_pitch + (size_t)(c * PPI) * out_stride) = v;
+        }
       }
     }
   }
   if (gpool) {
     const int Hp = (H + 1) >> 1, Wp = (W + 1) >> 1;
-#pragma unroll 2
-    for (int pp = p0; pp < 64; pp += PPI) {
+#pragma unroll
+    for (int k = 0; k < (64 + PPI - 1) / PPI; ++k) {
+      const int pp = p0 + k * PPI;
       const int ly = (pp >> 3) * 2, lx = (pp & 7) * 2;
       const int y = ty0 + ly, x = tx0 + lx;
-      if (y < H && x < W) {
+      if (pp < 64 && y < H && x < W) {
         // windows on a ragged edge are clipped like Caffe's (pooling_layer.cu:24-27)
         const float* c0 = Cs + (ly * 16 + lx) * (BN + CS_PAD) + cg * 4;
         float4 m = make_float4(-3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f);

@@ -109,14 +109,6 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_kernel(ConvK p) {
 #pragma unroll
   for (int t = 0; t < 2; ++t) b_off[t] = (wn * 64 + t * 32 + i) * ROWB + kh * 16;
 
-  f32x16 accm[MT][2], accc[MT][2];
-#pragma unroll
-  for (int a = 0; a < MT; ++a)
-#pragma unroll
-    for (int c = 0; c < 2; ++c)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { accm[a][c][r] = 0.f; accc[a][c][r] = 0.f; }
-
   const int nchunks = p.Cin / KC;
   const int NST = nchunks * 3;  // stages
   const _Float16* wsp = (const _Float16*)p.wp;
@@ -206,6 +198,8 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_kernel(ConvK p) {
       }
     }
   };
+  // W(0) is requested before anything else; the accumulator clearing fills part of the wait
+  F16X3_DMA_W(0, 0, 8);
   if constexpr (FUSE1) {
     const float* img = mem.img + (size_t)b * 3 * H * W;
     for (int idx = tid; idx < 3 * PH * PW; idx += 512) {
@@ -224,7 +218,13 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_kernel(ConvK p) {
     for (int j = 0; j < ALD; ++j)
       areg0[j] = (a_goff[j] >= 0) ? *(const float4*)(inc_ + a_goff[j]) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
-  F16X3_DMA_W(0, 0, 8);
+  f32x16 accm[MT][2], accc[MT][2];
+#pragma unroll
+  for (int a = 0; a < MT; ++a)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { accm[a][c][r] = 0.f; accc[a][c][r] = 0.f; }
   if constexpr (FUSE1) {
     first_store();
   } else {
@@ -483,23 +483,6 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4_kernel(ConvK p) {
   const float* __restrict__ gin = mem.in;
   float* __restrict__ gout = mem.out;
 
-  const int i = lane & 31, kh = lane >> 5;
-  int dy, px;
-  row_to_pixel(i, dy, px);
-  int a_off[MT], b_off[2];
-#pragma unroll
-  for (int t = 0; t < MT; ++t) a_off[t] = ((wm * 2 * MT + t * 2 + dy) * HTW + px) * ROWB + kh * 16;
-#pragma unroll
-  for (int t = 0; t < 2; ++t) b_off[t] = (wn * 64 + t * 32 + i) * ROWB + kh * 16;
-
-  f32x16 accm[MT][2], accc[MT][2];
-#pragma unroll
-  for (int a = 0; a < MT; ++a)
-#pragma unroll
-    for (int c = 0; c < 2; ++c)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { accm[a][c][r] = 0.f; accc[a][c][r] = 0.f; }
-
   const int nchunks = p.Cin / KC;
   const int NST = nchunks * 3;
   const _Float16* wsp = (const _Float16*)p.wp;
@@ -555,20 +538,40 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4_kernel(ConvK p) {
                                        (__attribute__((address_space(3))) void*)(bd_ + pc * 1024), 16, 0, 0);
     }
   };
-  {  // prologue: halo(0) and W(0) into LDS
-    float4 areg0[ALD];
+  // prologue: W(0) by DMA and the halo tile of chunk 0 are requested first; the accumulator clearing and
+  // the fragment geometry fill the wait
+  float4 areg0[ALD];
+  dma_w(0, 0, 0, DMA_ROUNDS);
 #pragma unroll
-    for (int j = 0; j < ALD; ++j) areg0[j] = *(const float4*)(gin + a_gsafe[j]);
-    dma_w(0, 0, 0, DMA_ROUNDS);
+  for (int j = 0; j < ALD; ++j) areg0[j] = *(const float4*)(gin + a_gsafe[j]);
+
+  const int i = lane & 31, kh = lane >> 5;
+  int dy, px;
+  row_to_pixel(i, dy, px);
+  int a_off[MT], b_off[2];
 #pragma unroll
-    for (int j = 0; j < ALD; ++j) {
-      split_inplace(areg0[j], (a_valid >> j) & 1);
-      if (j + 1 < ALD || a_last) store_piece(areg0[j], j);
-    }
+  for (int t = 0; t < MT; ++t) a_off[t] = ((wm * 2 * MT + t * 2 + dy) * HTW + px) * ROWB + kh * 16;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) b_off[t] = (wn * 64 + t * 32 + i) * ROWB + kh * 16;
+  f32x16 accm[MT][2], accc[MT][2];
+#pragma unroll
+  for (int a = 0; a < MT; ++a)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { accm[a][c][r] = 0.f; accc[a][c][r] = 0.f; }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int j = 0; j < ALD; ++j) {
+    split_inplace(areg0[j], (a_valid >> j) & 1);
+    if (j + 1 < ALD || a_last) store_piece(areg0[j], j);
   }
 
 #ifdef SHF_CONV_TIMING
   unsigned long long tb = 0, tc = 0, tx = 0, t0, t1, t3;
+#ifdef SHF_CONV_TIMING_STEPS
+  unsigned long long tstep[6] = {0, 0, 0, 0, 0, 0};
+#endif
   const unsigned long long t_loop = __builtin_amdgcn_s_memtime();
 #endif
   // one stage = kernel row KY of chunk c; HANDOVER: also fetch / split / park the halo tile of chunk c+1
@@ -603,6 +606,9 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4_kernel(ConvK p) {
     };
     load_frag(0, fa[0], fb[0]);
     __builtin_amdgcn_sched_barrier(0);
+#ifdef SHF_CONV_TIMING_STEPS
+    unsigned long long ts0 = __builtin_amdgcn_s_memtime(), ts1;
+#endif
 #pragma unroll
     for (int s_ = 0; s_ < 6; ++s_) {
       half8* a = fa[s_ & 1];
@@ -617,10 +623,9 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4_kernel(ConvK p) {
 #pragma unroll
           for (int j = s_ * 6; j < (s_ ? ALD : 6); ++j) areg[j] = *(const float4*)(inc_ + a_gsafe[j]);
           n_vmem += s_ ? ALD - 6 : 6;
-        } else {
+        } else if (s_ >= 4) {  // as late as possible: the loads get three k-steps to come back
 #pragma unroll
-          for (int j = (s_ - 2) * 3; j < (s_ == 5 ? ALD : (s_ - 1) * 3); ++j)
-            split_inplace(areg[j], (a_valid >> j) & 1);
+          for (int j = (s_ - 4) * 6; j < (s_ == 5 ? ALD : 6); ++j) split_inplace(areg[j], (a_valid >> j) & 1);
         }
       }
       // three sweeps over the 8 output tiles: consecutive MFMAs never chain on one accumulator
@@ -654,6 +659,12 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4_kernel(ConvK p) {
         }
       }
       __builtin_amdgcn_sched_barrier(0);
+#ifdef SHF_CONV_TIMING_STEPS
+      ts1 = __builtin_amdgcn_s_memtime();
+      tstep[s_] += ts1 - ts0;
+      ts0 = ts1;
+      __builtin_amdgcn_sched_barrier(0);
+#endif
     }
 #ifdef SHF_CONV_TIMING
     asm volatile("s_nop 0" ::: "memory");
@@ -701,9 +712,20 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4_kernel(ConvK p) {
         conv_stage_tile<BN>(Cs, [&](int r) { return am[r] + ac[r] * LO_INV; }, bv, p.relu, wm * 2 * MT + tm * 2, kh, cl);
       }
     }
+#ifdef SHF_CONV_TIMING_STEPS
+    const unsigned long long te1 = __builtin_amdgcn_s_memtime();
+#endif
     __syncthreads();
+#ifdef SHF_CONV_TIMING_STEPS
+    const unsigned long long te2 = __builtin_amdgcn_s_memtime();
+#endif
     conv_flush_tile<BN, NT>(Cs, tid, ty0, tx0, H, W, b, ct * BN, gout, p.out_stride, mem.pool, p.pool_stride,
                             !(p.relu & 8));
+#ifdef SHF_CONV_TIMING_STEPS
+    const unsigned long long te3 = __builtin_amdgcn_s_memtime();
+    if (wave == 0 && bid == 0 && lane == 0)
+      printf("[w4 epilogue] stage %llu barrier %llu flush-issue %llu\n", te1 - t_loop_end, te2 - te1, te3 - te2);
+#endif
   } else {
 #pragma unroll
     for (int tn = 0; tn < 2; ++tn) {
@@ -724,6 +746,11 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4_kernel(ConvK p) {
     unsigned long long* d = p.dbg + ((bid ? 1 : 0) * 8 + wave) * 5;
     d[0] = tb; d[1] = ((t_loop - t_entry) << 32) | (t_exit - t_loop_end); d[2] = tc; d[3] = tx;
     d[4] = NST | ((t_exit - t_entry) << 16) | ((r_exit - r_entry) << 40);
+#ifdef SHF_CONV_TIMING_STEPS
+    if (wave == 0 && bid == 0)
+      printf("[w4 steps] per-stage cycles by k-step: %llu %llu %llu %llu %llu %llu\n", tstep[0] / NST, tstep[1] / NST,
+             tstep[2] / NST, tstep[3] / NST, tstep[4] / NST, tstep[5] / NST);
+#endif
   }
 #endif
 }
@@ -752,7 +779,7 @@ void pack_conv_weights_split16(const float* w, int Cout, int Cin, int k, void* d
 
 bool conv_f16x3_uses_w4(int Cin) {
   static const int w4_mode = getenv("SHF_F16X3_W4") ? atoi(getenv("SHF_F16X3_W4")) : -1;
-  return w4_mode < 0 ? Cin >= 256 : w4_mode != 0;
+  return w4_mode < 0 ? Cin >= 128 : w4_mode != 0;
 }
 
 bool conv_f16x3_eligible(int Cin, int Cout, int k, int pad, int dil) {
@@ -809,7 +836,7 @@ static int launch_f16x3_t(const ConvArgs* as, int n, hipStream_t s) {
 #endif
   // the 4-wave kernel has the faster K loop (~6.2 k cycles per stage against ~7 k) but the dearer
   // prologue / epilogue (half the waves to fetch the first tiles and to write the result): it wins from
-  // 8 input-channel chunks up.  SHF_F16X3_W4 = 0 / 1 forces never / always (experiments).
+  // 4 input-channel chunks (Cin 128) up.  SHF_F16X3_W4 = 0 / 1 forces never / always (experiments).
   if (BN == 128 && !FUSE1 && conv_f16x3_uses_w4(p.Cin))
     hipLaunchKernelGGL(conv_mfma_f16x3_w4_kernel, dim3((unsigned)(tiles * p.nct)), dim3(256), lds, s, p);
   else
