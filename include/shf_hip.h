@@ -127,6 +127,12 @@ int shf_make_pyramid_level(shf_net* net, const uint8_t* im_bgr_dev, int im_h, in
  * image's appends while its box merging still runs). */
 int shf_net_record_event(shf_net* net);
 int shf_net_wait_event(shf_net* net, shf_net* other);
+/* Finer hand-over for the same pipeline: with `prev` set as `net`'s predecessor head,
+ * shf_detect_add_levels on `net` starts its convolutions as soon as the member lanes' previous tails
+ * have consumed the head feature maps (their logits kernels), and waits for `prev`'s last
+ * shf_net_record_event mark only before its own tails, which reuse the members' tail buffers.
+ * prev = NULL clears it. */
+int shf_net_set_predecessor(shf_net* net, shf_net* prev);
 /* Box merging for the image (test.py:168-175): method 0 = BBOX_VOTE (test.py:181),
  * 1 = NMS (lib/nms).  out5 rows are (x1,y1,x2,y2,score) as double (bbox_vote
  * returns float64).  *n_out = number of rows (may exceed cap; only cap written). */

@@ -93,6 +93,7 @@ def _declare(lib):
         "shf_detect_add_levels": (ci, [vp, ci, C.POINTER(vp), C.POINTER(vp), ci, ip, ip, ip, ip, fp, ip, cf, ci]),
         "shf_pyramid_level_shape": (ci, [ci, ci, C.c_double, ci, ip, ip, ip, ip]),
         "shf_make_pyramid_level": (ci, [vp, vp, ci, ci, C.c_double, ci, dp, vp, ci, ci, ci, ci]),
+        "shf_net_set_predecessor": (ci, [vp, vp]),
         "shf_detect_finish": (ci, [vp, ci, cf, dp, ci, ip]),
         "shf_detect_count": (ci, [vp]),
         "shf_detect_export": (ci, [vp, vp, ci, ip]),

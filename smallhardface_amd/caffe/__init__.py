@@ -289,6 +289,10 @@ class Net(object):
                                                     1 if flip else 0, pm, int(out_dev), int(H), int(W), int(lvl_h),
                                                     int(lvl_w)), "make_pyramid_level")
 
+    def set_predecessor(self, prev):
+        """Pipeline hand-over at logits granularity (C ABI shf_net_set_predecessor)."""
+        _lib.check(self._lib.shf_net_set_predecessor(self._h, prev._h if prev is not None else None), "set_predecessor")
+
     def record_event(self):
         _lib.check(self._lib.shf_net_record_event(self._h), "record_event")
 

@@ -382,6 +382,11 @@ struct shf_net {
   std::shared_ptr<int> wgen = std::make_shared<int>(0);  // bumped by every param commit
   int tail_gen = -1;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_mark = nullptr;
+  hipEvent_t ev_logits = nullptr;  // recorded by every fused tail pass right after its logits kernel
+  int tail_phase = 0;  // group pass: 1 = logits kernels only, 2 = the rest of the tail (launch_tail)
+  std::vector<hipStream_t> tail_pool;  // head-owned streams the detection tails of a group pass fan out over
+  std::vector<hipEvent_t> tail_pool_ev;
+  shf_net* pred = nullptr;         // shf_net_set_predecessor: the head lane whose image precedes this one's
   int conv_mode = 0;  // 0: exact fp32 MFMA everywhere; 1: split-fp16 MFMA for the 3x3 / dilation-1 layers
   TailWork tw;
   DevBuf tw_logits, tw_rec, tw_keys, tw_counters;
@@ -399,6 +404,9 @@ struct shf_net {
   ~shf_net() {
     if (ev_fork) (void)hipEventDestroy(ev_fork);
     if (ev_join) (void)hipEventDestroy(ev_join);
+    if (ev_logits) (void)hipEventDestroy(ev_logits);
+    for (auto e : tail_pool_ev) (void)hipEventDestroy(e);
+    for (auto t : tail_pool) (void)hipStreamDestroy(t);
     if (ev_mark) (void)hipEventDestroy(ev_mark);
     if (stream) {
       (void)hipStreamSynchronize(stream);
@@ -1054,8 +1062,10 @@ void shf_net::forward_ops(bool fused_path, float im_h, float im_w, float im_scal
         const double K = (double)t.h * t.w;
         ProfScope ps(pf, st, PC_TAIL, 2.0 * K * tail_A * 6 * tail_Cf,
                      4.0 * K * (tail_heads * tail_Cf + tail_A * 18));
+        if (fused_path && !ev_logits) HIP_THROW(hipEventCreateWithFlags(&ev_logits, hipEventDisableTiming));
         CHECK_RC(launch_tail(t, tw, (float*)blobs[boxes_blob].dev.p,
-                             prob_blob >= 0 ? (float*)blobs[prob_blob].dev.p : (float*)tw_rec.p, st));
+                             prob_blob >= 0 ? (float*)blobs[prob_blob].dev.p : (float*)tw_rec.p, st,
+                             fused_path ? ev_logits : nullptr, tail_phase));
         break;
       }
     }
@@ -1310,6 +1320,13 @@ int shf_net_wait_event(shf_net* net, shf_net* other) {
   API_END(-1)
 }
 
+int shf_net_set_predecessor(shf_net* net, shf_net* prev) {
+  API_BEGIN
+  net->pred = prev;
+  return 0;
+  API_END(-1)
+}
+
 int shf_detect_begin(shf_net* net) {
   API_BEGIN
   if (net->tail_layer < 0) throw std::runtime_error("net has no proposal layer");
@@ -1420,6 +1437,13 @@ int shf_detect_add_levels(shf_net* net, int n, shf_net** members, const float* c
       if (members[q] == members[m]) throw std::runtime_error("detect_add_levels: members must be distinct nets");
     if (members[m]->layers.size() != net->layers.size())
       throw std::runtime_error("detect_add_levels: members must be lanes of the same net");
+  }
+  // The member lanes' activations are free as soon as the previous pass over them has run its logits
+  // kernels (the rest of a tail works on its own buffers), so with a predecessor head set this pass's
+  // convolutions overlap the predecessor's sorts / gathers / appends; the full hand-over is only
+  // awaited before this pass's own tail (below).
+  for (int m = 0; m < n; ++m) {
+    if (members[m]->ev_logits) HIP_THROW(hipStreamWaitEvent(net->stream, members[m]->ev_logits, 0));
     members[m]->prepare_unit(data[m], data_on_device, H[m], W[m], net->stream);
   }
   std::vector<ConvArgs> group(n);
@@ -1454,11 +1478,61 @@ int shf_detect_add_levels(shf_net* net, int n, shf_net** members, const float* c
         CHECK_RC(launch_conv_mfma_group(group.data(), n, net->stream));
       }
     } else if (L.op == OP_TAIL && n > 1) {
+      if (net->pred && net->pred->ev_mark) HIP_THROW(hipStreamWaitEvent(net->stream, net->pred->ev_mark, 0));
       // The detection tail of a unit is a chain of ~8 tiny dependent launches (logits, decode, sort
       // stages, gather): latency-bound.  Fan the units out over their lanes' own streams so the
       // chains overlap, and join back on the primary stream.
+      // Where the tails run (SHF_TAIL_STREAMS overrides): 0 = on this head's stream, logits kernels of all
+      // units first -- the default when the head has a predecessor, i.e. images are pipelined over two heads:
+      // the serial chain then hides under the next image's convolutions, and only the two head streams are
+      // ever active (the runtime multiplexes HIP streams onto ~4 hardware queues; a tail stream that lands on
+      // the OTHER head's queue serialises the pipeline).  N > 0 = fan out over N streams owned by this head
+      // (default 3 without a predecessor: shortest latency for one image); -1 = the member lanes' own streams.
+      static const int tail_env = getenv("SHF_TAIL_STREAMS") ? atoi(getenv("SHF_TAIL_STREAMS")) : -2;
+      const int tail_streams = tail_env != -2 ? tail_env : (net->pred ? 0 : 3);
+      if (tail_streams == 0) {
+        for (int phase = 1; phase <= 2; ++phase)
+          for (int m = 0; m < n; ++m) {
+            members[m]->tail_phase = phase;
+            members[m]->forward_ops(true, (float)im_h[m], (float)im_w[m], im_scale[m], net->stream, &net->prof, (int)li,
+                                    nullptr);
+            members[m]->tail_phase = 0;
+          }
+        continue;
+      }
       if (!net->ev_fork) HIP_THROW(hipEventCreateWithFlags(&net->ev_fork, hipEventDisableTiming));
       HIP_THROW(hipEventRecord(net->ev_fork, net->stream));
+      if (tail_streams > 0) {
+        while ((int)net->tail_pool.size() < tail_streams) {
+          hipStream_t ts;
+          hipEvent_t te;
+          HIP_THROW(hipStreamCreateWithFlags(&ts, hipStreamNonBlocking));
+          HIP_THROW(hipEventCreateWithFlags(&te, hipEventDisableTiming));
+          net->tail_pool.push_back(ts);
+          net->tail_pool_ev.push_back(te);
+        }
+        // longest chains first, round-robin: the big levels' sorts dominate
+        std::vector<int> order(n);
+        for (int m = 0; m < n; ++m) order[m] = m;
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return (long long)H[a] * W[a] > (long long)H[b] * W[b]; });
+        for (int t = 0; t < tail_streams; ++t) HIP_THROW(hipStreamWaitEvent(net->tail_pool[t], net->ev_fork, 0));
+        // every unit's logits kernel goes first: once they have run, the member lanes' feature maps are
+        // free and the next image's convolutions start under the sorts / gathers of this one
+        for (int phase = 1; phase <= 2; ++phase)
+          for (int q = 0; q < n; ++q) {
+            const int m = order[q];
+            shf_net* mb = members[m];
+            mb->tail_phase = phase;
+            mb->forward_ops(true, (float)im_h[m], (float)im_w[m], im_scale[m], net->tail_pool[q % tail_streams],
+                            &mb->prof, (int)li, nullptr);
+            mb->tail_phase = 0;
+          }
+        for (int t = 0; t < tail_streams; ++t) {
+          HIP_THROW(hipEventRecord(net->tail_pool_ev[t], net->tail_pool[t]));
+          HIP_THROW(hipStreamWaitEvent(net->stream, net->tail_pool_ev[t], 0));
+        }
+        continue;
+      }
       for (int m = 0; m < n; ++m) {
         shf_net* mb = members[m];
         if (mb->stream != net->stream) HIP_THROW(hipStreamWaitEvent(mb->stream, net->ev_fork, 0));

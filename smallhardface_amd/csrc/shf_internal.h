@@ -102,7 +102,9 @@ struct TailWork {  // device workspace owned by the net, sized for the largest l
   size_t cap_anchors = 0, cap_keys = 0;
 };
 // runs logits -> decode -> select -> sort; leaves R (device counters[2]) rows in out_boxes/out_probs
-int launch_tail(const TailArgs& a, TailWork& ws, float* out_boxes5, float* out_probs2, hipStream_t s);
+int launch_tail(const TailArgs& a, TailWork& ws, float* out_boxes5, float* out_probs2, hipStream_t s,
+                hipEvent_t after_logits = nullptr, int phase = 0);
+// after_logits: recorded once the feature maps are consumed; phase 1 = only up to there, 2 = only the rest
 
 // generic device sort of u64 keys, descending; n_dev points at the element count on the device,
 // n_max is a host-known upper bound (sizes the launch sequence)

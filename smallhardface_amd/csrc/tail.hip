@@ -316,26 +316,32 @@ int launch_sort_desc_u64(unsigned long long* keys, const int* n_dev, size_t n_ma
 }
 
 // ---------------------------------------------------------------------------
-int launch_tail(const TailArgs& a, TailWork& ws, float* out_boxes5, float* out_probs2, hipStream_t s) {
+int launch_tail(const TailArgs& a, TailWork& ws, float* out_boxes5, float* out_probs2, hipStream_t s,
+                hipEvent_t after_logits, int phase) {
   const int K = a.h * a.w;
   const long long total = (long long)K * a.A;
   if ((size_t)total > ws.cap_anchors) { set_error("tail: workspace too small"); return -1; }
   if (a.Cf % 128) { set_error("tail: head feature width must be a multiple of 128"); return -1; }
-  SHF_HIP_OK(hipMemsetAsync(ws.counters, 0, 8 * sizeof(int), s));
-  TailK lk;
-  for (int i = 0; i < a.A; ++i) {
-    const View& f = a.feat[a.heads == 1 ? 0 : i];
-    lk.feat[i] = f.p + f.coff;
-    lk.fstride[i] = f.cstride;
-    lk.aw[i] = a.anchors[i * 4 + 2] - a.anchors[i * 4 + 0] + 1.0f;
-    lk.ah[i] = a.anchors[i * 4 + 3] - a.anchors[i * 4 + 1] + 1.0f;
+  if (phase != 2) {
+    SHF_HIP_OK(hipMemsetAsync(ws.counters, 0, 8 * sizeof(int), s));
+    TailK lk;
+    for (int i = 0; i < a.A; ++i) {
+      const View& f = a.feat[a.heads == 1 ? 0 : i];
+      lk.feat[i] = f.p + f.coff;
+      lk.fstride[i] = f.cstride;
+      lk.aw[i] = a.anchors[i * 4 + 2] - a.anchors[i * 4 + 0] + 1.0f;
+      lk.ah[i] = a.anchors[i * 4 + 3] - a.anchors[i * 4 + 1] + 1.0f;
+    }
+    lk.Wt = a.wcls[0];  // combined [A][6][Cf] matrix prepared by the net (see net.cpp: build_tail_weights)
+    lk.bt = a.bcls[0];
+    lk.logits = ws.logits;
+    lk.K = K; lk.A = a.A; lk.Cf = a.Cf; lk.w = a.w;
+    lk.counters = ws.counters;
+    hipLaunchKernelGGL(tail_logits_kernel, dim3(grid_for(((long long)K + 1) / 2 * 64)), dim3(256), 0, s, lk);
+    // from here on the tail only touches its own workspace: the head feature maps may be overwritten
+    if (after_logits) SHF_HIP_OK(hipEventRecord(after_logits, s));
   }
-  lk.Wt = a.wcls[0];  // combined [A][6][Cf] matrix prepared by the net (see net.cpp: build_tail_weights)
-  lk.bt = a.bcls[0];
-  lk.logits = ws.logits;
-  lk.K = K; lk.A = a.A; lk.Cf = a.Cf; lk.w = a.w;
-  lk.counters = ws.counters;
-  hipLaunchKernelGGL(tail_logits_kernel, dim3(grid_for(((long long)K + 1) / 2 * 64)), dim3(256), 0, s, lk);
+  if (phase == 1) return 0;
 
   DecodeK dk;
   dk.logits = ws.logits; dk.rec = ws.rec; dk.keys = ws.keys; dk.counters = ws.counters;

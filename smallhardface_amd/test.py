@@ -244,6 +244,8 @@ class FusedDetector(object):
         same stream: DevicePyramid.units(im, net=fd.next_head()))."""
         if not hasattr(self, "_heads"):
             self._heads = [self.net.clone(), self.net.clone()]
+            self._heads[0].set_predecessor(self._heads[1])
+            self._heads[1].set_predecessor(self._heads[0])
             self._turn = 0
             self._inflight = []
         return self._heads[self._turn]
@@ -254,9 +256,9 @@ class FusedDetector(object):
         head = self.next_head()
         while len(self.lanes) < len(units):
             self.lanes.append(self.net.clone())
-        prev = self._heads[1 - self._turn]
         head.detect_begin()
-        head.wait_event(prev)  # the previous image has appended: the member buffers are free again
+        # no wait here: add_levels starts as soon as the previous image's logits kernels have consumed
+        # the member lanes' feature maps and only awaits its appends before this image's own tails
         head.detect_add_levels(self.lanes[:len(units)], units, thresh, on_device=on_device)
         head.record_event()
         self._inflight.append(head)
