@@ -383,6 +383,7 @@ struct shf_net {
   int tail_gen = -1;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_mark = nullptr;
   hipEvent_t ev_logits = nullptr;  // recorded by every fused tail pass right after its logits kernel
+  hipEvent_t ev_convs = nullptr;   // group pass: recorded on the head's stream after the last layer before the tails
   int tail_phase = 0;  // group pass: 1 = logits kernels only, 2 = the rest of the tail (launch_tail)
   std::vector<hipStream_t> tail_pool;  // head-owned streams the detection tails of a group pass fan out over
   std::vector<hipEvent_t> tail_pool_ev;
@@ -405,6 +406,7 @@ struct shf_net {
     if (ev_fork) (void)hipEventDestroy(ev_fork);
     if (ev_join) (void)hipEventDestroy(ev_join);
     if (ev_logits) (void)hipEventDestroy(ev_logits);
+    if (ev_convs) (void)hipEventDestroy(ev_convs);
     for (auto e : tail_pool_ev) (void)hipEventDestroy(e);
     for (auto t : tail_pool) (void)hipStreamDestroy(t);
     if (ev_mark) (void)hipEventDestroy(ev_mark);
@@ -1442,13 +1444,25 @@ int shf_detect_add_levels(shf_net* net, int n, shf_net** members, const float* c
   // kernels (the rest of a tail works on its own buffers), so with a predecessor head set this pass's
   // convolutions overlap the predecessor's sorts / gathers / appends; the full hand-over is only
   // awaited before this pass's own tail (below).
+  // (With a predecessor head the start only awaits its last convolution; the logits events are awaited
+  // right before the first layer that writes a feature map the tails read: every blob owns its buffer.)
+  int first_feat_writer = (int)net->layers.size();
+  for (size_t li = 0; li < net->layers.size(); ++li)
+    for (int t : net->layers[li].tops)
+      for (int f : net->tail_feat_blobs)
+        if (t == f && (int)li < first_feat_writer) first_feat_writer = (int)li;
+  const bool early_start = net->pred && net->pred->ev_convs && first_feat_writer < (int)net->layers.size();
+  if (early_start) HIP_THROW(hipStreamWaitEvent(net->stream, net->pred->ev_convs, 0));
   for (int m = 0; m < n; ++m) {
-    if (members[m]->ev_logits) HIP_THROW(hipStreamWaitEvent(net->stream, members[m]->ev_logits, 0));
+    if (!early_start && members[m]->ev_logits) HIP_THROW(hipStreamWaitEvent(net->stream, members[m]->ev_logits, 0));
     members[m]->prepare_unit(data[m], data_on_device, H[m], W[m], net->stream);
   }
   std::vector<ConvArgs> group(n);
   for (size_t li = 0; li < net->layers.size(); ++li) {
     Layer& L = net->layers[li];
+    if (early_start && (int)li == first_feat_writer)
+      for (int m = 0; m < n; ++m)
+        if (members[m]->ev_logits) HIP_THROW(hipStreamWaitEvent(net->stream, members[m]->ev_logits, 0));
     if (L.op == OP_SKIP) continue;
     if (L.op == OP_CONV && L.kclass == 0) {
       double fl = 0, by = 4.0 * L.params[0]->count();
@@ -1478,6 +1492,8 @@ int shf_detect_add_levels(shf_net* net, int n, shf_net** members, const float* c
         CHECK_RC(launch_conv_mfma_group(group.data(), n, net->stream));
       }
     } else if (L.op == OP_TAIL && n > 1) {
+      if (!net->ev_convs) HIP_THROW(hipEventCreateWithFlags(&net->ev_convs, hipEventDisableTiming));
+      HIP_THROW(hipEventRecord(net->ev_convs, net->stream));
       if (net->pred && net->pred->ev_mark) HIP_THROW(hipStreamWaitEvent(net->stream, net->pred->ev_mark, 0));
       // The detection tail of a unit is a chain of ~8 tiny dependent launches (logits, decode, sort
       // stages, gather): latency-bound.  Fan the units out over their lanes' own streams so the
