@@ -38,6 +38,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef F16X3_PIPE
 #define F16X3_PIPE 0       // 1: explicit LDS->register software pipeline in the stages without a halo hand-over
 #endif
+#ifndef F16X3_W4_PREFETCH
+#define F16X3_W4_PREFETCH 0  // 4-wave kernel: request the next halo tile a stage early (1) or in the hand-over stage (0)
+#endif
+#ifndef F16X3_W4_PIN
+#define F16X3_W4_PIN 0       // 1: pin the fp16 split inside its k-step (fewer cycles, but measured SLOWER end to end: see below)
+#endif
 #ifndef F16X3_CONV_MID
 #define F16X3_CONV_MID 1   // 1: split the next halo tile to fp16 hi/lo in the middle of the last stage's MFMAs
 #endif
@@ -512,7 +518,16 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4_kernel(ConvK p) {
     half4 hi, lo;
     split4(valid ? v : make_float4(0.f, 0.f, 0.f, 0.f), hi, lo);
     const float2 h2 = __builtin_bit_cast(float2, hi), l2 = __builtin_bit_cast(float2, lo);
-    v = make_float4(h2.x, h2.y, l2.x, l2.y);
+    // Left alone the compiler sinks the conversion to its single use after the stage (the hand-over
+    // bubble, ~1 k cycles per chunk).  Pinning it here (F16X3_W4_PIN) puts the VALU work under the MFMAs
+    // and saves those cycles -- and measured 3 % SLOWER end to end on the same box: the chip is
+    // power-limited under this kernel (1.75-1.9 GHz sustained), VALU issued alongside the matrix pipe
+    // costs clock.  Same story for requesting the tile a stage early (F16X3_W4_PREFETCH).
+    float x0 = h2.x, x1 = h2.y, x2 = l2.x, x3 = l2.y;
+#if F16X3_W4_PIN
+    asm volatile("" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3));
+#endif
+    v = make_float4(x0, x1, x2, x3);
   };
   auto store_piece = [&](const float4& v, int j) {
     *(float2*)(As + a_loff0 + j * 32 * ROWB) = make_float2(v.x, v.y);
@@ -575,9 +590,13 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4_kernel(ConvK p) {
   const unsigned long long t_loop = __builtin_amdgcn_s_memtime();
 #endif
   // one stage = kernel row KY of chunk c; HANDOVER: also fetch / split / park the halo tile of chunk c+1
-  auto stage = [&](int c, auto KY_, auto HANDOVER_) {
+  // MODE 0: plain; 1 (middle kernel row): also request the halo tile of chunk c+1 into registers;
+  // 2 (last kernel row): split it to fp16 hi/lo under the MFMAs and park it in LDS after the stage
+  float4 areg[ALD];
+  auto stage = [&](int c, auto KY_, auto MODE_) {
     constexpr int ky = decltype(KY_)::value;
-    constexpr bool HANDOVER = decltype(HANDOVER_)::value;
+    constexpr bool PREFETCH = decltype(MODE_)::value == 1;
+    constexpr bool HANDOVER = decltype(MODE_)::value == 2;
     const int st = c * 3 + ky;
     SHF_T(t0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of W(st) has landed
@@ -585,7 +604,6 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4_kernel(ConvK p) {
     SHF_T(t1);
     const int st_next = st + 1 < NST ? st + 1 : st;  // the last stage re-fetches itself (unused) instead of branching
     const int buf_next = (st + 1) & 1;
-    float4 areg[ALD];
     const float* inc_ = gin + (c + 1) * KC;
     const unsigned char* Arow = As + (ky * HTW) * ROWB;
     const unsigned char* Bst = Bs + (st & 1) * (3 * BN * ROWB);
@@ -618,6 +636,19 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4_kernel(ConvK p) {
       constexpr int DMA_J0[6] = {0, 3, 6, 9, 12, 14}, DMA_N[6] = {3, 3, 3, 3, 2, 0};
       if (DMA_N[s_]) dma_w(st_next, buf_next, DMA_J0[s_], DMA_N[s_]);
       int n_vmem = DMA_N[s_];
+#if F16X3_W4_PREFETCH
+      if constexpr (PREFETCH) {  // a whole stage of slack before the first use
+        if (s_ >= 3 && s_ < 5) {
+#pragma unroll
+          for (int j = (s_ - 3) * 6; j < (s_ == 4 ? ALD : 6); ++j) areg[j] = *(const float4*)(inc_ + a_gsafe[j]);
+          n_vmem += s_ == 4 ? ALD - 6 : 6;
+        }
+      }
+      if constexpr (HANDOVER) {  // two pieces per k-step: a trickle of VALU work under the MFMAs
+#pragma unroll
+        for (int j = s_ * 2; j < (s_ == 5 ? ALD : s_ * 2 + 2); ++j) split_inplace(areg[j], (a_valid >> j) & 1);
+      }
+#else
       if constexpr (HANDOVER) {
         if (s_ < 2) {
 #pragma unroll
@@ -628,6 +659,7 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4_kernel(ConvK p) {
           for (int j = (s_ - 4) * 6; j < (s_ == 5 ? ALD : 6); ++j) split_inplace(areg[j], (a_valid >> j) & 1);
         }
       }
+#endif
       // three sweeps over the 8 output tiles: consecutive MFMAs never chain on one accumulator
 #pragma unroll
       for (int tm = 0; tm < MT; ++tm)
@@ -687,13 +719,13 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4_kernel(ConvK p) {
   // branch inside it makes the two arms disagree on accumulator registers and pay for it every turn)
 #pragma unroll 1
   for (int c = 0; c + 1 < nchunks; ++c) {
-    stage(c, integral_constant<int, 0>{}, integral_constant<bool, false>{});
-    stage(c, integral_constant<int, 1>{}, integral_constant<bool, false>{});
-    stage(c, integral_constant<int, 2>{}, integral_constant<bool, true>{});
+    stage(c, integral_constant<int, 0>{}, integral_constant<int, 0>{});
+    stage(c, integral_constant<int, 1>{}, integral_constant<int, 1>{});
+    stage(c, integral_constant<int, 2>{}, integral_constant<int, 2>{});
   }
-  stage(nchunks - 1, integral_constant<int, 0>{}, integral_constant<bool, false>{});
-  stage(nchunks - 1, integral_constant<int, 1>{}, integral_constant<bool, false>{});
-  stage(nchunks - 1, integral_constant<int, 2>{}, integral_constant<bool, false>{});
+  stage(nchunks - 1, integral_constant<int, 0>{}, integral_constant<int, 0>{});
+  stage(nchunks - 1, integral_constant<int, 1>{}, integral_constant<int, 0>{});
+  stage(nchunks - 1, integral_constant<int, 2>{}, integral_constant<int, 0>{});
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last stage's (unused) self re-fetch
 #ifdef SHF_CONV_TIMING
   const unsigned long long t_loop_end = __builtin_amdgcn_s_memtime();

@@ -8,7 +8,8 @@ mkdir -p variants
 obj=variants/$name.$src.o
 extra=""
 case $src in tail.hip|merge.hip|pre.hip) extra="-ffp-contract=off";; esac
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $extra "$@" -c smallhardface_amd/csrc/$src -o $obj
+# SRC_OVERRIDE=/path/to/other/version.hip builds that file in place of csrc/$src (A/B against an older revision)
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $extra -Ismallhardface_amd/csrc "$@" -c ${SRC_OVERRIDE:-smallhardface_amd/csrc/$src} -o $obj
 objs=""
 for o in smallhardface_amd/csrc/_obj/*.o; do
   if [ "$(basename $o)" != "$src.o" ]; then objs="$objs $o"; fi
