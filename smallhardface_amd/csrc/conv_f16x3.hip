@@ -71,9 +71,13 @@ __device__ __forceinline__ void split4(const float4 v, half4& hi, half4& lo) {
 // in place from a 20x20x3 image patch staged in LDS (one thread per halo pixel, 27 x 32 FMAs per
 // chunk, under the MFMAs of the previous chunk).  conv1_1 never touches HBM: -1.8 GB written and
 // read per image on the bench pyramid.
-template <int BN, bool FUSE1>
+template <int BN, bool FUSE1, int DIL>
 __global__ __launch_bounds__(512) void conv_mfma_f16x3_kernel(ConvK p) {
   using namespace f16x3;
+  // halo tile for dilation DIL (the dilated heads: 2 and 4, BN = 64 only -- a 24x24 tile plus 128-cout weight
+  // buffers would not fit the 160 KiB of LDS)
+  constexpr int HTW = TW + 2 * DIL, HTH = TH + 2 * DIL, HP = HTH * HTW;
+  static_assert(!FUSE1 || DIL == 1, "the fused first layer is a dilation-1 path");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int WN = BN / 64;
   constexpr int WM = 8 / WN;
@@ -129,7 +133,7 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_kernel(ConvK p) {
     const int idx = tid + 512 * j;
     const int hp = idx >> 3, q = idx & 7;
     const int hy = hp / HTW, hx = hp - hy * HTW;
-    const int gy = ty0 - 1 + hy, gx = tx0 - 1 + hx;
+    const int gy = ty0 - DIL + hy, gx = tx0 - DIL + hx;
     const bool in = (idx < HP * 8) && ((unsigned)gy < (unsigned)H) && ((unsigned)gx < (unsigned)W);
     a_goff[j] = in ? ((b * H + gy) * W + gx) * p.in_stride + q * 4 : -1;
     a_loff[j] = (idx < HP * 8) ? hp * ROWB + q * 8 : -1;
@@ -276,7 +280,7 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_kernel(ConvK p) {
       }
     }
     SHF_T(t2);
-    const unsigned char* Arow = As + (ky * HTW) * ROWB;
+    const unsigned char* Arow = As + (ky * DIL * HTW) * ROWB;
     const unsigned char* Bst = Bs + (st & 1) * (3 * BN * ROWB);
 #if F16X3_PIPE
     bool piped = false;
@@ -288,7 +292,7 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_kernel(ConvK p) {
         piped = true;
         half8 fa[2][4], fb[2][4];
         auto load_frag = [&](int s_, half8* a, half8* bf) {
-          const unsigned char* Ap = Arow + (s_ >> 1) * ROWB + (s_ & 1) * 32;
+          const unsigned char* Ap = Arow + (s_ >> 1) * DIL * ROWB + (s_ & 1) * 32;
           const unsigned char* Bp = Bst + (s_ >> 1) * (BN * ROWB) + (s_ & 1) * 32;
 #pragma unroll
           for (int t = 0; t < 2; ++t) {
@@ -327,7 +331,7 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_kernel(ConvK p) {
 #endif
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) {
-      const unsigned char* Ap = Arow + kx * ROWB;
+      const unsigned char* Ap = Arow + kx * DIL * ROWB;
       const unsigned char* Bp = Bst + kx * (BN * ROWB);
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
@@ -815,19 +819,22 @@ bool conv_f16x3_uses_w4(int Cin) {
 }
 
 bool conv_f16x3_eligible(int Cin, int Cout, int k, int pad, int dil) {
-  return k == 3 && dil == 1 && pad == 1 && Cin % 32 == 0 && Cout % 64 == 0;
+  static const bool heads = !(getenv("SHF_F16X3_DILATED") && atoi(getenv("SHF_F16X3_DILATED")) == 0);
+  const bool dil_ok = dil == 1 || (heads && (dil == 2 || dil == 4));
+  return k == 3 && dil_ok && pad == dil && Cin % 32 == 0 && Cout % 64 == 0;
 }
 
-template <int BN, bool FUSE1>
+template <int BN, bool FUSE1, int DIL = 1>
 static int launch_f16x3_t(const ConvArgs* as, int n, hipStream_t s) {
   using namespace f16x3;
+  constexpr int HP = (TH + 2 * DIL) * (TW + 2 * DIL);
   const ConvArgs& a = as[0];
   ConvK p;
   p.wp = (const float*)a.wsplit16;
   p.bias = a.bias;
   p.Cin = a.in.C; p.Cout = a.out.C;
   p.in_stride = a.in.cstride; p.out_stride = a.out.cstride;
-  p.dil = 1; p.relu = a.relu | (a.pool.p && !a.write_main ? 8 : 0);
+  p.dil = DIL; p.relu = a.relu | (a.pool.p && !a.write_main ? 8 : 0);
   p.pool_stride = a.pool.p ? a.pool.cstride : 0;
   p.nct = p.Cout / BN;
   p.nmem = n;
@@ -869,10 +876,10 @@ static int launch_f16x3_t(const ConvArgs* as, int n, hipStream_t s) {
   // the 4-wave kernel has the faster K loop (~6.2 k cycles per stage against ~7 k) but the dearer
   // prologue / epilogue (half the waves to fetch the first tiles and to write the result): it wins from
   // 4 input-channel chunks (Cin 128) up.  SHF_F16X3_W4 = 0 / 1 forces never / always (experiments).
-  if (BN == 128 && !FUSE1 && conv_f16x3_uses_w4(p.Cin))
+  if (BN == 128 && !FUSE1 && DIL == 1 && conv_f16x3_uses_w4(p.Cin))
     hipLaunchKernelGGL(conv_mfma_f16x3_w4_kernel, dim3((unsigned)(tiles * p.nct)), dim3(256), lds, s, p);
   else
-    hipLaunchKernelGGL((conv_mfma_f16x3_kernel<BN, FUSE1>), dim3((unsigned)(tiles * p.nct)), dim3(512), lds, s, p);
+    hipLaunchKernelGGL((conv_mfma_f16x3_kernel<BN, FUSE1, DIL>), dim3((unsigned)(tiles * p.nct)), dim3(512), lds, s, p);
   SHF_HIP_OK(hipGetLastError());
 #ifdef SHF_CONV_TIMING
   {
@@ -898,13 +905,17 @@ static int launch_f16x3_t(const ConvArgs* as, int n, hipStream_t s) {
 }
 
 int conv_f16x3_init_attributes() {
-  SHF_HIP_OK(hipFuncSetAttribute((const void*)conv_mfma_f16x3_kernel<128, false>,
+  SHF_HIP_OK(hipFuncSetAttribute((const void*)conv_mfma_f16x3_kernel<128, false, 1>,
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  SHF_HIP_OK(hipFuncSetAttribute((const void*)conv_mfma_f16x3_kernel<64, false, 2>,
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  SHF_HIP_OK(hipFuncSetAttribute((const void*)conv_mfma_f16x3_kernel<64, false, 4>,
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   SHF_HIP_OK(hipFuncSetAttribute((const void*)conv_mfma_f16x3_w4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                  160 * 1024));
-  SHF_HIP_OK(hipFuncSetAttribute((const void*)conv_mfma_f16x3_kernel<64, false>,
+  SHF_HIP_OK(hipFuncSetAttribute((const void*)conv_mfma_f16x3_kernel<64, false, 1>,
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  SHF_HIP_OK(hipFuncSetAttribute((const void*)conv_mfma_f16x3_kernel<64, true>,
+  SHF_HIP_OK(hipFuncSetAttribute((const void*)conv_mfma_f16x3_kernel<64, true, 1>,
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   return 0;
 }
@@ -918,6 +929,8 @@ int launch_conv_f16x3_group(const ConvArgs* as, int n, hipStream_t s) {
     if (as[0].in.C != 64 || !as[0].w1t) { set_error("conv f16x3: fused first layer needs 64 channels + transposed weights"); return -1; }
     return launch_f16x3_t<64, true>(as, n, s);  // conv1_1 computed in place (BN=64 tile: Cout 64 or any multiple of 64)
   }
+  if (as[0].dil == 2) return launch_f16x3_t<64, false, 2>(as, n, s);
+  if (as[0].dil == 4) return launch_f16x3_t<64, false, 4>(as, n, s);
   return (as[0].out.C % 128 == 0) ? launch_f16x3_t<128, false>(as, n, s) : launch_f16x3_t<64, false>(as, n, s);
 }
 

@@ -134,14 +134,15 @@ struct Layer {
 };
 
 // the first 8 classes are the instantiations of conv_mfma_f32_kernel, named like rocprofv3 prints them
-enum ProfClass { PC_CONV_MFMA, PC_CONV_MFMA_1 = 1, PC_CONV_MFMA_7 = 7, PC_CONV_F16X3_128, PC_CONV_F16X3_W4, PC_CONV_F16X3_64, PC_CONV_F16X3_64_FUSE1, PC_CONV_FIRST, PC_CONV_DIRECT, PC_POOL, PC_DECONV, PC_TAIL, PC_MERGE, PC_LAYOUT, PC_COUNT };
+enum ProfClass { PC_CONV_MFMA, PC_CONV_MFMA_1 = 1, PC_CONV_MFMA_7 = 7, PC_CONV_F16X3_128, PC_CONV_F16X3_W4, PC_CONV_F16X3_64, PC_CONV_F16X3_64_FUSE1, PC_CONV_F16X3_64_D2, PC_CONV_F16X3_64_D4, PC_CONV_FIRST, PC_CONV_DIRECT, PC_POOL, PC_DECONV, PC_TAIL, PC_MERGE, PC_LAYOUT, PC_COUNT };
 static const char* kProfNames[PC_COUNT] = {"conv_mfma_f32_kernel<3, 1, 128, 8, 16>", "conv_mfma_f32_kernel<3, 2, 128, 8, 16>",
                                            "conv_mfma_f32_kernel<3, 4, 128, 8, 16>", "conv_mfma_f32_kernel<3, 1, 64, 16, 16>",
                                            "conv_mfma_f32_kernel<3, 2, 64, 16, 16>", "conv_mfma_f32_kernel<3, 4, 64, 16, 16>",
                                            "conv_mfma_f32_kernel<1, 0, 128, 8, 16>", "conv_mfma_f32_kernel<1, 0, 64, 16, 16>",
-                                           "conv_mfma_f16x3_kernel<128, false>", "conv_mfma_f16x3_w4_kernel",
-                                           "conv_mfma_f16x3_kernel<64, false>",
-                                           "conv_mfma_f16x3_kernel<64, true>",
+                                           "conv_mfma_f16x3_kernel<128, false, 1>", "conv_mfma_f16x3_w4_kernel",
+                                           "conv_mfma_f16x3_kernel<64, false, 1>",
+                                           "conv_mfma_f16x3_kernel<64, true, 1>", "conv_mfma_f16x3_kernel<64, false, 2>",
+                                           "conv_mfma_f16x3_kernel<64, false, 4>",
                                            "conv_first_kernel", "conv_direct_kernel", "maxpool_kernel",
                                            "deconv_depthwise", "detect_tail", "box_merge", "layout"};
 
@@ -181,6 +182,14 @@ struct Prof {
     for (auto e : pool) (void)hipEventDestroy(e);
   }
 };
+
+static int f16x3_prof_class(const ConvArgs& a, int nout) {  // which split-fp16 kernel launch_conv_f16x3_group picks
+  if (a.img) return PC_CONV_F16X3_64_FUSE1;
+  if (a.dil == 2) return PC_CONV_F16X3_64_D2;
+  if (a.dil == 4) return PC_CONV_F16X3_64_D4;
+  if (nout % 128) return PC_CONV_F16X3_64;
+  return conv_f16x3_uses_w4(a.in.C) ? PC_CONV_F16X3_W4 : PC_CONV_F16X3_128;
+}
 
 static int conv_prof_class(int k, int dil, int nout) {
   const int bn64 = (nout % 128 == 0) ? 0 : 1;
@@ -1016,7 +1025,7 @@ void shf_net::forward_ops(bool fused_path, float im_h, float im_w, float im_scal
           if (L.kclass == 0 && collect) {
             *collect = a;  // grouped launch: the caller batches this layer over several units
           } else if (L.kclass == 0 && split16) {
-            ProfScope ps(pf, st, a.img ? PC_CONV_F16X3_64_FUSE1 : L.nout % 128 ? PC_CONV_F16X3_64 : conv_f16x3_uses_w4(a.in.C) ? PC_CONV_F16X3_W4 : PC_CONV_F16X3_128,
+            ProfScope ps(pf, st, f16x3_prof_class(a, L.nout),
                          fl, by);
             CHECK_RC(launch_conv_f16x3_group(&a, 1, st));
           } else if (L.kclass == 0) {
@@ -1483,7 +1492,7 @@ int shf_detect_add_levels(shf_net* net, int n, shf_net** members, const float* c
           }
         }
         ProfScope ps(net->prof, net->stream,
-                     group[0].img ? PC_CONV_F16X3_64_FUSE1 : L.nout % 128 ? PC_CONV_F16X3_64 : conv_f16x3_uses_w4(group[0].in.C) ? PC_CONV_F16X3_W4 : PC_CONV_F16X3_128, fl,
+                     f16x3_prof_class(group[0], L.nout), fl,
                      by);
         CHECK_RC(launch_conv_f16x3_group(group.data(), n, net->stream));
       } else {
