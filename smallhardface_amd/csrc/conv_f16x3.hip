@@ -18,6 +18,7 @@
 // buffered in LDS (fetched two stages ahead into registers, parked at the top of the stage);
 // the 18x18x32 halo tile is staged once per chunk and reused by all 9 taps.  LDS rows are
 // [hi: 32 halfs][lo: 32 halfs][16 B pad] = 144 B (conflict-free ds_read_b128).
+#include <algorithm>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -71,24 +72,27 @@ __device__ __forceinline__ void split4(const float4 v, half4& hi, half4& lo) {
 // in place from a 20x20x3 image patch staged in LDS (one thread per halo pixel, 27 x 32 FMAs per
 // chunk, under the MFMAs of the previous chunk).  conv1_1 never touches HBM: -1.8 GB written and
 // read per image on the bench pyramid.
-template <int BN, bool FUSE1, int DIL>
+template <int BN, bool FUSE1, int DIL, int KS>
 __global__ __launch_bounds__(512) void conv_mfma_f16x3_kernel(ConvK p) {
   using namespace f16x3;
   // halo tile for dilation DIL (the dilated heads: 2 and 4, BN = 64 only -- a 24x24 tile plus 128-cout weight
   // buffers would not fit the 160 KiB of LDS)
-  constexpr int HTW = TW + 2 * DIL, HTH = TH + 2 * DIL, HP = HTH * HTW;
+  // KS = 3: a stage is one kernel row (3 taps) of a 32-channel chunk; KS = 1 (1x1 convolutions): a stage is
+  // the single tap of a chunk, no halo, and every stage hands the next chunk's tile over
+  constexpr int PADH = KS == 3 ? DIL : 0, KROWS = KS == 3 ? 3 : 1;
+  constexpr int HTW = TW + 2 * PADH, HTH = TH + 2 * PADH, HP = HTH * HTW;
+  static_assert(KS == 3 || (KS == 1 && DIL == 1 && !FUSE1), "kernel sizes 3 (any dilation) and 1");
   static_assert(!FUSE1 || DIL == 1, "the fused first layer is a dilation-1 path");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int WN = BN / 64;
   constexpr int WM = 8 / WN;
   constexpr int MT = TH / (2 * WM);      // 2x16-pixel MFMA row tiles per wave: 2 (BN=128) or 1 (BN=64)
-  constexpr int NBP = 3 * BN * 8 / 512;  // 16-B weight pieces per thread per stage: 6 or 3
   constexpr int ALD = (HP * 8 + 511) / 512;  // float4 halo pieces per thread: 6
   unsigned char* As = smem;                  // [HP][ROWB]
   unsigned char* Bs = smem + HP * ROWB;      // [2][3][BN][ROWB]
   // FUSE1 extras behind the weight buffers
   constexpr int PW = TW + 4, PH = TH + 4;    // image patch: halo of the halo
-  float* patch = (float*)(Bs + 2 * 3 * BN * ROWB);  // [3][PH][PW]
+  float* patch = (float*)(Bs + 2 * KS * BN * ROWB);  // [3][PH][PW]
   float* w1s = patch + 3 * PH * PW;                 // [27][64]
   float* b1s = w1s + 27 * 64;                       // [64]
 
@@ -120,7 +124,7 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_kernel(ConvK p) {
   for (int t = 0; t < 2; ++t) b_off[t] = (wn * 64 + t * 32 + i) * ROWB + kh * 16;
 
   const int nchunks = p.Cin / KC;
-  const int NST = nchunks * 3;  // stages
+  const int NST = nchunks * KROWS;  // stages
   const _Float16* wsp = (const _Float16*)p.wp;
   // weights: [chunk][ky][kx][cout][hi 32 | lo 32 | 8 pad] halfs = the LDS row image (144 B)
   const size_t slab = (size_t)p.Cout * 72;        // halfs per (chunk,ky,kx)
@@ -133,7 +137,7 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_kernel(ConvK p) {
     const int idx = tid + 512 * j;
     const int hp = idx >> 3, q = idx & 7;
     const int hy = hp / HTW, hx = hp - hy * HTW;
-    const int gy = ty0 - DIL + hy, gx = tx0 - DIL + hx;
+    const int gy = ty0 - PADH + hy, gx = tx0 - PADH + hx;
     const bool in = (idx < HP * 8) && ((unsigned)gy < (unsigned)H) && ((unsigned)gx < (unsigned)W);
     a_goff[j] = in ? ((b * H + gy) * W + gx) * p.in_stride + q * 4 : -1;
     a_loff[j] = (idx < HP * 8) ? hp * ROWB + q * 8 : -1;
@@ -144,13 +148,13 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_kernel(ConvK p) {
   // couts) is 3 contiguous runs copied in 1-KiB pieces, one piece per wave-instruction.
   constexpr int SLAB_B = BN * ROWB;            // bytes per slab in LDS and in global
   constexpr int PCS_SLAB = SLAB_B / 1024;      // 18 (BN=128) or 9 (BN=64)
-  constexpr int PCS = 3 * PCS_SLAB;
+  constexpr int PCS = KS * PCS_SLAB;
   static_assert(SLAB_B % 1024 == 0, "slab must be whole DMA pieces");
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
 #define F16X3_DMA_W(STAGE, BUF, NWAVES)                                                              \
   {                                                                                                  \
-    const unsigned char* ws_ = (const unsigned char*)(wbase + (size_t)(STAGE) * 3 * slab);           \
-    unsigned char* bd_ = Bs + (BUF) * (3 * SLAB_B);                                                  \
+    const unsigned char* ws_ = (const unsigned char*)(wbase + (size_t)(STAGE) * KS * slab);           \
+    unsigned char* bd_ = Bs + (BUF) * (KS * SLAB_B);                                                  \
     _Pragma("unroll") for (int j = 0; j < (PCS + (NWAVES) - 1) / (NWAVES); ++j) {                    \
       const int pc = wave_u + (NWAVES) * j;                                                          \
       if (pc < PCS) {                                                                                \
@@ -258,8 +262,8 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_kernel(ConvK p) {
    float4 areg[ALD];
    half4 ahi[ALD], alo[ALD];
 #pragma unroll
-   for (int ky = 0; ky < 3; ++ky) {
-    const int st = c * 3 + ky;
+   for (int ky = 0; ky < KROWS; ++ky) {
+    const int st = c * KROWS + ky;
     SHF_T(t0);
     // LDS-DMA is only ordered by the issuing wave's own vmcnt: drain it by hand before the barrier
     // (hipcc drops this wait when the DMA sits behind the loop back-edge / in a wave-uniform branch)
@@ -269,7 +273,7 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_kernel(ConvK p) {
 #if !F16X3_DMA_LATE
     if (st + 1 < NST) F16X3_DMA_W(st + 1, (st + 1) & 1, 8);
 #endif
-    const bool last_row = (ky == 2);
+    const bool last_row = (ky == KROWS - 1);
     const bool more_chunks = (c + 1 < nchunks);
     if constexpr (!FUSE1) {
       if (last_row && more_chunks) {
@@ -281,10 +285,10 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_kernel(ConvK p) {
     }
     SHF_T(t2);
     const unsigned char* Arow = As + (ky * DIL * HTW) * ROWB;
-    const unsigned char* Bst = Bs + (st & 1) * (3 * BN * ROWB);
+    const unsigned char* Bst = Bs + (st & 1) * (KS * BN * ROWB);
 #if F16X3_PIPE
     bool piped = false;
-    if constexpr (MT == 2) {
+    if constexpr (MT == 2 && KS == 3) {
       if (!(last_row && more_chunks)) {
         // software pipeline over the six k-steps of the stage: the fragments of step s+1 are fetched
         // from LDS (into the other register set) underneath the 12 MFMAs of step s.  The stage that
@@ -330,7 +334,7 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_kernel(ConvK p) {
     if (!piped)
 #endif
 #pragma unroll
-    for (int kx = 0; kx < 3; ++kx) {
+    for (int kx = 0; kx < KS; ++kx) {
       const unsigned char* Ap = Arow + kx * DIL * ROWB;
       const unsigned char* Bp = Bst + kx * (BN * ROWB);
 #pragma unroll
@@ -375,7 +379,7 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_kernel(ConvK p) {
             }
         }
       }
-      if (F16X3_CONV_MID && kx == 1 && last_row && more_chunks) {
+      if (F16X3_CONV_MID && kx == KS / 2 && last_row && more_chunks) {
         // prepare the next chunk's halo while the matrix pipe drains
         if constexpr (FUSE1) {
           if (f_own) first_conv(c + 1);
@@ -821,13 +825,16 @@ bool conv_f16x3_uses_w4(int Cin) {
 bool conv_f16x3_eligible(int Cin, int Cout, int k, int pad, int dil) {
   static const bool heads = !(getenv("SHF_F16X3_DILATED") && atoi(getenv("SHF_F16X3_DILATED")) == 0);
   const bool dil_ok = dil == 1 || (heads && (dil == 2 || dil == 4));
+  static const bool k1 = !(getenv("SHF_F16X3_1X1") && atoi(getenv("SHF_F16X3_1X1")) == 0);
+  if (k == 1) return k1 && pad == 0 && Cin % 32 == 0 && Cout % 64 == 0;
   return k == 3 && dil_ok && pad == dil && Cin % 32 == 0 && Cout % 64 == 0;
 }
 
-template <int BN, bool FUSE1, int DIL = 1>
+template <int BN, bool FUSE1, int DIL = 1, int KS = 3>
 static int launch_f16x3_t(const ConvArgs* as, int n, hipStream_t s) {
   using namespace f16x3;
-  constexpr int HP = (TH + 2 * DIL) * (TW + 2 * DIL);
+  constexpr int PADH = KS == 3 ? DIL : 0;
+  constexpr int HP = (TH + 2 * PADH) * (TW + 2 * PADH);
   const ConvArgs& a = as[0];
   ConvK p;
   p.wp = (const float*)a.wsplit16;
@@ -865,7 +872,8 @@ static int launch_f16x3_t(const ConvArgs* as, int n, hipStream_t s) {
     tiles += (long long)m.tiles_per_img * m.B;
   }
   if (vec_ok) p.relu |= 16;
-  const size_t lds = (size_t)HP * ROWB + 2 * 3 * (size_t)BN * ROWB +
+  // (the transposed epilogue needs 256 x (BN + 4) floats: the 1x1 variant's K-loop buffers are smaller than that)
+  const size_t lds = std::max((size_t)HP * ROWB + 2 * KS * (size_t)BN * ROWB, (size_t)256 * (BN + CS_PAD) * sizeof(float)) +
                      (FUSE1 ? (3 * (TH + 4) * (TW + 4) + 27 * 64 + 64) * sizeof(float) : 0);
 #ifdef SHF_CONV_TIMING
   static unsigned long long* dbg_dev = nullptr;
@@ -876,10 +884,10 @@ static int launch_f16x3_t(const ConvArgs* as, int n, hipStream_t s) {
   // the 4-wave kernel has the faster K loop (~6.2 k cycles per stage against ~7 k) but the dearer
   // prologue / epilogue (half the waves to fetch the first tiles and to write the result): it wins from
   // 4 input-channel chunks (Cin 128) up.  SHF_F16X3_W4 = 0 / 1 forces never / always (experiments).
-  if (BN == 128 && !FUSE1 && DIL == 1 && conv_f16x3_uses_w4(p.Cin))
+  if (BN == 128 && !FUSE1 && DIL == 1 && KS == 3 && conv_f16x3_uses_w4(p.Cin))
     hipLaunchKernelGGL(conv_mfma_f16x3_w4_kernel, dim3((unsigned)(tiles * p.nct)), dim3(256), lds, s, p);
   else
-    hipLaunchKernelGGL((conv_mfma_f16x3_kernel<BN, FUSE1, DIL>), dim3((unsigned)(tiles * p.nct)), dim3(512), lds, s, p);
+    hipLaunchKernelGGL((conv_mfma_f16x3_kernel<BN, FUSE1, DIL, KS>), dim3((unsigned)(tiles * p.nct)), dim3(512), lds, s, p);
   SHF_HIP_OK(hipGetLastError());
 #ifdef SHF_CONV_TIMING
   {
@@ -905,17 +913,21 @@ static int launch_f16x3_t(const ConvArgs* as, int n, hipStream_t s) {
 }
 
 int conv_f16x3_init_attributes() {
-  SHF_HIP_OK(hipFuncSetAttribute((const void*)conv_mfma_f16x3_kernel<128, false, 1>,
+  SHF_HIP_OK(hipFuncSetAttribute((const void*)conv_mfma_f16x3_kernel<128, false, 1, 3>,
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  SHF_HIP_OK(hipFuncSetAttribute((const void*)conv_mfma_f16x3_kernel<64, false, 2>,
+  SHF_HIP_OK(hipFuncSetAttribute((const void*)conv_mfma_f16x3_kernel<128, false, 1, 1>,
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  SHF_HIP_OK(hipFuncSetAttribute((const void*)conv_mfma_f16x3_kernel<64, false, 4>,
+  SHF_HIP_OK(hipFuncSetAttribute((const void*)conv_mfma_f16x3_kernel<64, false, 1, 1>,
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  SHF_HIP_OK(hipFuncSetAttribute((const void*)conv_mfma_f16x3_kernel<64, false, 2, 3>,
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  SHF_HIP_OK(hipFuncSetAttribute((const void*)conv_mfma_f16x3_kernel<64, false, 4, 3>,
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   SHF_HIP_OK(hipFuncSetAttribute((const void*)conv_mfma_f16x3_w4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                  160 * 1024));
-  SHF_HIP_OK(hipFuncSetAttribute((const void*)conv_mfma_f16x3_kernel<64, false, 1>,
+  SHF_HIP_OK(hipFuncSetAttribute((const void*)conv_mfma_f16x3_kernel<64, false, 1, 3>,
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  SHF_HIP_OK(hipFuncSetAttribute((const void*)conv_mfma_f16x3_kernel<64, true, 1>,
+  SHF_HIP_OK(hipFuncSetAttribute((const void*)conv_mfma_f16x3_kernel<64, true, 1, 3>,
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   return 0;
 }
@@ -929,6 +941,8 @@ int launch_conv_f16x3_group(const ConvArgs* as, int n, hipStream_t s) {
     if (as[0].in.C != 64 || !as[0].w1t) { set_error("conv f16x3: fused first layer needs 64 channels + transposed weights"); return -1; }
     return launch_f16x3_t<64, true>(as, n, s);  // conv1_1 computed in place (BN=64 tile: Cout 64 or any multiple of 64)
   }
+  if (as[0].k == 1)
+    return (as[0].out.C % 128 == 0) ? launch_f16x3_t<128, false, 1, 1>(as, n, s) : launch_f16x3_t<64, false, 1, 1>(as, n, s);
   if (as[0].dil == 2) return launch_f16x3_t<64, false, 2>(as, n, s);
   if (as[0].dil == 4) return launch_f16x3_t<64, false, 4>(as, n, s);
   return (as[0].out.C % 128 == 0) ? launch_f16x3_t<128, false>(as, n, s) : launch_f16x3_t<64, false>(as, n, s);
