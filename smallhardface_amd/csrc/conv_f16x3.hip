@@ -32,6 +32,7 @@ namespace shf {
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #ifndef F16X3_DMA_LATE
 #define F16X3_DMA_LATE 1   // 1: the early-finishing waves 0-3 issue the next stage's weight DMA after their MFMAs
@@ -175,9 +176,10 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_kernel(ConvK p) {
   auto first_conv = [&](int chunk) {
     // conv1_1 + ReLU for channels chunk*32 .. +31 at this thread's halo pixel; zero outside the image
     // (that is conv1_2's zero padding, not conv1_1 evaluated out there)
-    float acc[32];
+    // two channels per instruction (v_pk_fma_f32): the same fused multiply-adds at half the VALU issue
+    f32x2 acc2[16];
 #pragma unroll
-    for (int j = 0; j < 32; ++j) acc[j] = b1s[chunk * 32 + j];
+    for (int j = 0; j < 16; ++j) acc2[j] = f32x2{b1s[chunk * 32 + 2 * j], b1s[chunk * 32 + 2 * j + 1]};
 #pragma unroll
     for (int ci = 0; ci < 3; ++ci)
 #pragma unroll
@@ -185,16 +187,18 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_kernel(ConvK p) {
 #pragma unroll
         for (int kxx = 0; kxx < 3; ++kxx) {
           const float v = patch[(ci * PH + f_hy + kyy) * PW + f_hx + kxx];
+          const f32x2 vv = {v, v};
           const float4* wv = (const float4*)(w1s + ((ci * 3 + kyy) * 3 + kxx) * 64 + chunk * 32);
 #pragma unroll
           for (int q = 0; q < 8; ++q) {
             const float4 w4 = wv[q];
-            acc[4 * q + 0] = fmaf(v, w4.x, acc[4 * q + 0]);
-            acc[4 * q + 1] = fmaf(v, w4.y, acc[4 * q + 1]);
-            acc[4 * q + 2] = fmaf(v, w4.z, acc[4 * q + 2]);
-            acc[4 * q + 3] = fmaf(v, w4.w, acc[4 * q + 3]);
+            acc2[2 * q] = __builtin_elementwise_fma(vv, f32x2{w4.x, w4.y}, acc2[2 * q]);
+            acc2[2 * q + 1] = __builtin_elementwise_fma(vv, f32x2{w4.z, w4.w}, acc2[2 * q + 1]);
           }
         }
+    float acc[32];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { acc[2 * j] = acc2[j][0]; acc[2 * j + 1] = acc2[j][1]; }
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       float4 v4 = make_float4(fmaxf(acc[4 * q], 0.f), fmaxf(acc[4 * q + 1], 0.f), fmaxf(acc[4 * q + 2], 0.f),
