@@ -53,10 +53,7 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_f32_kernel(ConvK p) {
   const int bid = blockIdx.x;
   const int ct = bid % p.nct;
   int pt = bid / p.nct;
-  int mi = 0;
-#pragma unroll 1
-  for (int q = 1; q < p.nmem; ++q)
-    if (pt >= p.m[q].tile_start) mi = q;
+  const int mi = conv_find_member(p, pt);
   const ConvMember& mem = p.m[mi];
   pt -= mem.tile_start;
   const int b = pt / mem.tiles_per_img;
@@ -386,6 +383,7 @@ static int launch_mfma_t(const ConvArgs* as, int n, hipStream_t s) {
   p.relu |= dbg_flags;
   p.nct = p.Cout / BN;
   p.nmem = n;
+  for (int i = 0; i < MAX_GROUP; ++i) p.tile_starts[i] = 0x7fffffff;
   p.w1t = nullptr;
   p.b1 = nullptr;
   long long tiles = 0;
@@ -405,6 +403,7 @@ static int launch_mfma_t(const ConvArgs* as, int n, hipStream_t s) {
     m.tiles_x = (m.W + TW - 1) / TW;
     m.tiles_per_img = m.tiles_x * ((m.H + TH - 1) / TH);
     m.tile_start = (int)tiles;
+    p.tile_starts[i] = (int)tiles;
     tiles += (long long)m.tiles_per_img * m.B;
   }
   p.dbg = nullptr;

@@ -31,12 +31,22 @@ struct ConvK {
   const float* w1t;  // FUSE1: first-layer weights transposed to [27][64]
   const float* b1;   // FUSE1: first-layer bias [64]
   unsigned long long* dbg;  // SHF_CONV_TIMING builds only: per-wave phase cycle sums
+  int tile_starts[MAX_GROUP];  // m[q].tile_start again, contiguous (unused entries INT_MAX): ONE scalar load finds a
+                               // block's member instead of a chain of dependent ones (~1.5 k cycles per block)
   ConvMember m[MAX_GROUP];
 };
 
 // row i (0..31) of a 32-row MFMA tile -> pixel inside the wave's 2x16 strip.
 // The two low bits walk a 2x2 window so that the 4 consecutive C rows a lane owns
 // form one pooling window (kept for a fused 2x2 max-pool epilogue).
+// which member of the group does pixel tile `pt` belong to?
+__device__ __forceinline__ int conv_find_member(const ConvK& p, int pt) {
+  int mi = 0;
+#pragma unroll
+  for (int q = 1; q < MAX_GROUP; ++q) mi += (pt >= p.tile_starts[q]) ? 1 : 0;
+  return mi;
+}
+
 __device__ __forceinline__ void row_to_pixel(int i, int& dy, int& px) {
   dy = (i >> 1) & 1;
   px = ((i >> 2) << 1) | (i & 1);

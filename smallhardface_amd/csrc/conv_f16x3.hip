@@ -33,6 +33,7 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #ifndef F16X3_DMA_LATE
 #define F16X3_DMA_LATE 1   // 1: the early-finishing waves 0-3 issue the next stage's weight DMA after their MFMAs
@@ -85,6 +86,9 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_kernel(ConvK p) {
   static_assert(KS == 3 || (KS == 1 && DIL == 1 && !FUSE1), "kernel sizes 3 (any dilation) and 1");
   static_assert(!FUSE1 || DIL == 1, "the fused first layer is a dilation-1 path");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+#ifdef SHF_CONV_TIMING
+  const unsigned long long t_entry8 = __builtin_amdgcn_s_memtime();
+#endif
   constexpr int WN = BN / 64;
   constexpr int WM = 8 / WN;
   constexpr int MT = TH / (2 * WM);      // 2x16-pixel MFMA row tiles per wave: 2 (BN=128) or 1 (BN=64)
@@ -96,16 +100,16 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_kernel(ConvK p) {
   float* patch = (float*)(Bs + 2 * KS * BN * ROWB);  // [3][PH][PW]
   float* w1s = patch + 3 * PH * PW;                 // [27][64]
   float* b1s = w1s + 27 * 64;                       // [64]
+  // first-layer weights [27][64]: read through the CONSTANT address space so that the wave-uniform accesses
+  // become s_load_dwordx8/16 (scalar cache -> SGPRs), not per-lane memory instructions
+  const __attribute__((address_space(4))) float* w1g = (const __attribute__((address_space(4))) float*)(unsigned long long)p.w1t;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wn = wave % WN, wm = wave / WN;
   const int bid = blockIdx.x;
   const int ct = bid % p.nct;
   int pt = bid / p.nct;
-  int mi = 0;
-#pragma unroll 1
-  for (int q = 1; q < p.nmem; ++q)
-    if (pt >= p.m[q].tile_start) mi = q;
+  const int mi = conv_find_member(p, pt);
   const ConvMember& mem = p.m[mi];
   pt -= mem.tile_start;
   const int b = pt / mem.tiles_per_img;
@@ -188,12 +192,15 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_kernel(ConvK p) {
         for (int kxx = 0; kxx < 3; ++kxx) {
           const float v = patch[(ci * PH + f_hy + kyy) * PW + f_hx + kxx];
           const f32x2 vv = {v, v};
-          const float4* wv = (const float4*)(w1s + ((ci * 3 + kyy) * 3 + kxx) * 64 + chunk * 32);
+          // wave-uniform address into the kernel argument's array: scalar loads (s_load_dwordx8/16), weights stay
+          // in SGPRs.  (From LDS every tap was a dependent ds_read_b128 round trip: 216 x ~64 cycles per pass.)
+          const __attribute__((address_space(4))) f32x4* wv =
+              (const __attribute__((address_space(4))) f32x4*)(w1g + ((ci * 3 + kyy) * 3 + kxx) * 64 + chunk * 32);
 #pragma unroll
           for (int q = 0; q < 8; ++q) {
-            const float4 w4 = wv[q];
-            acc2[2 * q] = __builtin_elementwise_fma(vv, f32x2{w4.x, w4.y}, acc2[2 * q]);
-            acc2[2 * q + 1] = __builtin_elementwise_fma(vv, f32x2{w4.z, w4.w}, acc2[2 * q + 1]);
+            const f32x4 w4 = wv[q];
+            acc2[2 * q] = __builtin_elementwise_fma(vv, f32x2{w4[0], w4[1]}, acc2[2 * q]);
+            acc2[2 * q + 1] = __builtin_elementwise_fma(vv, f32x2{w4[2], w4[3]}, acc2[2 * q + 1]);
           }
         }
     float acc[32];
@@ -257,6 +264,7 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_kernel(ConvK p) {
   }
 
 #ifdef SHF_CONV_TIMING
+  const unsigned long long t_loop8 = __builtin_amdgcn_s_memtime();
   unsigned long long tb = 0, ti = 0, tc = 0, tx = 0, t0, t1, t2, t3;
 #define SHF_T(x) x = __builtin_amdgcn_s_memtime()
 #else
@@ -426,9 +434,11 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_kernel(ConvK p) {
    }
   }
 #ifdef SHF_CONV_TIMING
+  const unsigned long long t_end8 = __builtin_amdgcn_s_memtime();
   if (p.dbg && lane == 0 && (bid == 0 || bid == 100)) {
     unsigned long long* d = p.dbg + ((bid ? 1 : 0) * 8 + wave) * 5;
     d[0] = tb; d[1] = ti; d[2] = tc; d[3] = tx; d[4] = NST;
+    if (wave == 0) printf("[f16x3 8w] blk%d prologue %llu loop %llu (%d stages)\n", bid, t_loop8 - t_entry8, t_end8 - t_loop8, NST);
   }
 #endif
 #undef F16X3_DMA_W
@@ -450,6 +460,10 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_kernel(ConvK p) {
     __syncthreads();
     conv_flush_tile<BN, 512>(Cs, tid, ty0, tx0, H, W, b, ct * BN, gout, p.out_stride, mem.pool, p.pool_stride,
                              !(p.relu & 8));
+#ifdef SHF_CONV_TIMING
+    if (p.dbg && tid == 0 && (bid == 0 || bid == 100))
+      printf("[f16x3 8w] blk%d epilogue %llu\n", bid, (unsigned long long)__builtin_amdgcn_s_memtime() - t_end8);
+#endif
     return;
   }
 #pragma unroll
@@ -488,10 +502,7 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4_kernel(ConvK p) {
   const int bid = blockIdx.x;
   const int ct = bid % p.nct;
   int pt = bid / p.nct;
-  int mi = 0;
-#pragma unroll 1
-  for (int q = 1; q < p.nmem; ++q)
-    if (pt >= p.m[q].tile_start) mi = q;
+  const int mi = conv_find_member(p, pt);
   const ConvMember& mem = p.m[mi];
   pt -= mem.tile_start;
   const int b = pt / mem.tiles_per_img;
@@ -799,6 +810,226 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4_kernel(ConvK p) {
 #endif
 }
 
+// Producer / consumer variant of the fused first pair (conv1_1 -> conv1_2, Cin = Cout = 64).  With only
+// 64 couts a wave of the 8-wave kernel owns ONE 32-pixel MFMA row tile (MT = 1) and needs a ds_read_b128 per
+// MFMA -- LDS-bound at ~40 % matrix-pipe use -- and its conv1_1 (lane = halo pixel, 27 taps x 32 channels
+// with one weight fetch per packed FMA) is latency-bound: ~12 k cycles per 32-channel pass, two passes.
+// Here:
+//  * conv1_1 runs ONCE, in the prologue, on all eight waves with lane = output channel: the lane keeps
+//    its 27 weights in registers, the pixel values are wave-uniform LDS broadcasts of the image patch, and
+//    one v_pk_fma_f32 advances two neighbouring pixels.  Both 32-channel chunks of the 18x18 halo tile are
+//    written to LDS (two tiles: the first-layer weights no longer live there, so both fit) -- no second
+//    pass, no hand-over barrier in the K loop.
+//  * waves 0-3 are CONSUMERS (one per SIMD): 64 px x 64 couts = 4 accumulator tiles each, 8 fragment reads
+//    per 12 MFMAs, the six k-steps of a stage software-pipelined like the 4-wave kernel (~2.6 k cycles per
+//    stage against 2.3 k of pure MFMA issue).  Waves 4-7 are PRODUCERS: they issue every weight DMA.
+__global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
+  using namespace f16x3;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+#ifdef SHF_CONV_TIMING
+  unsigned long long tt[14];
+  int nt = 0;
+#define PC_T() tt[nt++] = __builtin_amdgcn_s_memtime()
+#else
+#define PC_T()
+#endif
+  PC_T();
+  constexpr int BN = 64, MT = 2;
+  constexpr int PW = TW + 4, PH = TH + 4;
+  unsigned char* As0 = smem;                        // [HP][ROWB] channels  0..31 of conv1_1's output
+  unsigned char* As1 = smem + HP * ROWB;            // [HP][ROWB] channels 32..63
+  unsigned char* Bs = smem + 2 * HP * ROWB;         // [2][3][BN][ROWB]
+  float* patch = (float*)(Bs + 2 * 3 * BN * ROWB);  // [3][PH][PW] raw image patch
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const bool consumer = wave_u < 4;
+  const int bid = blockIdx.x;
+  int pt = bid;  // nct == 1
+  const int mi = conv_find_member(p, pt);
+  const ConvMember& mem = p.m[mi];
+  pt -= mem.tile_start;
+  const int b = pt / mem.tiles_per_img;
+  pt -= b * mem.tiles_per_img;
+  const int ty0 = (pt / mem.tiles_x) * TH, tx0 = (pt % mem.tiles_x) * TW;
+  const int H = mem.H, W = mem.W;
+  float* __restrict__ gout = mem.out;
+
+  constexpr int SLAB_B = BN * ROWB;          // 9 KiB
+  constexpr int PCS_SLAB = SLAB_B / 1024;    // 9
+  constexpr int PCS = 3 * PCS_SLAB;          // 27 one-KiB pieces per stage
+  const size_t slab = (size_t)p.Cout * 72;
+  const _Float16* wbase = (const _Float16*)p.wp;
+  auto dma_w = [&](int stage, int buf) {     // producer waves only: 7 rounds of 4 pieces (the last one ragged)
+    const unsigned char* ws_ = (const unsigned char*)(wbase + (size_t)stage * 3 * slab);
+    unsigned char* bd_ = Bs + buf * (3 * SLAB_B);
+#pragma unroll
+    for (int j = 0; j < (PCS + 3) / 4; ++j) {
+      int pc = (wave_u - 4) + 4 * j;
+      pc = pc < PCS ? pc : PCS - 1;
+      const int sl = pc / PCS_SLAB, within = pc - sl * PCS_SLAB;
+      const unsigned char* src = ws_ + (size_t)sl * slab * 2 + within * 1024 + lane * 16;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(bd_ + pc * 1024), 16, 0, 0);
+    }
+  };
+  if (!consumer) dma_w(0, 0);
+
+  {  // prologue, all eight waves: conv1_1 + ReLU of the whole halo tile, lane = output channel
+    const float* img = mem.img + (size_t)b * 3 * H * W;
+    for (int idx = tid; idx < 3 * PH * PW; idx += 512) {
+      const int ci = idx / (PH * PW), r = idx - ci * (PH * PW);
+      const int py = r / PW, pxx = r - py * PW;
+      const int gy = ty0 - 2 + py, gx = tx0 - 2 + pxx;
+      patch[idx] = ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) ? img[((size_t)ci * H + gy) * W + gx] : 0.f;
+    }
+    PC_T();
+    float w1[27];
+#pragma unroll
+    for (int t = 0; t < 27; ++t) w1[t] = p.w1t[t * 64 + lane];
+    const float bias1 = p.b1 ? p.b1[lane] : 0.f;
+    unsigned char* Adst = (lane < 32 ? As0 : As1) + (lane & 31) * 2;
+    __syncthreads();
+    PC_T();
+    // pixel pairs (hy, hx..hx+1), hx even: 9 per halo row, 162 per tile, round-robin over the waves
+#pragma unroll 2
+    for (int pr = wave_u; pr < HTH * (HTW / 2); pr += 8) {
+      const int hy = pr / (HTW / 2), hx = (pr - hy * (HTW / 2)) * 2;
+      f32x2 acc = {bias1, bias1};
+#pragma unroll
+      for (int ci = 0; ci < 3; ++ci)
+#pragma unroll
+        for (int kyy = 0; kyy < 3; ++kyy)
+#pragma unroll
+          for (int kxx = 0; kxx < 3; ++kxx) {
+            const float* pp = patch + (ci * PH + hy + kyy) * PW + hx + kxx;   // wave-uniform: LDS broadcast
+            const float w = w1[(ci * 3 + kyy) * 3 + kxx];
+            acc = __builtin_elementwise_fma(f32x2{pp[0], pp[1]}, f32x2{w, w}, acc);
+          }
+      const bool row_in = (unsigned)(ty0 - 1 + hy) < (unsigned)H;
+      const bool in0 = row_in && (unsigned)(tx0 - 1 + hx) < (unsigned)W;      // outside the image: conv1_2's zero padding
+      const bool in1 = row_in && (unsigned)(tx0 + hx) < (unsigned)W;
+      const float v0 = in0 ? fmaxf(acc[0], 0.f) : 0.f, v1 = in1 ? fmaxf(acc[1], 0.f) : 0.f;
+      const _Float16 h0 = (_Float16)v0, h1 = (_Float16)v1;
+      const _Float16 l0 = (_Float16)((v0 - (float)h0) * LO_SCALE), l1 = (_Float16)((v1 - (float)h1) * LO_SCALE);
+      unsigned char* d = Adst + (hy * HTW + hx) * ROWB;
+      *(_Float16*)d = h0;
+      *(_Float16*)(d + 64) = l0;
+      *(_Float16*)(d + ROWB) = h1;
+      *(_Float16*)(d + ROWB + 64) = l1;
+    }
+  }
+
+  PC_T();
+  // consumer geometry: wave wm = rows 4 wm .. 4 wm + 3 (two 2x16-pixel MFMA row tiles), all 64 couts
+  const int i = lane & 31, kh = lane >> 5;
+  int dy, px;
+  row_to_pixel(i, dy, px);
+  const int wm = wave_u & 3;
+  int a_off[MT], b_off[2];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) a_off[t] = ((wm * 2 * MT + t * 2 + dy) * HTW + px) * ROWB + kh * 16;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) b_off[t] = (t * 32 + i) * ROWB + kh * 16;
+  f32x16 accm[MT][2], accc[MT][2];
+#pragma unroll
+  for (int a = 0; a < MT; ++a)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { accm[a][c][r] = 0.f; accc[a][c][r] = 0.f; }
+
+  auto mma_stage = [&](const unsigned char* Atile, int ky, int buf) {
+    const unsigned char* Arow = Atile + (ky * HTW) * ROWB;
+    const unsigned char* Bst = Bs + buf * (3 * BN * ROWB);
+    half8 fa[2][2 * MT], fb[2][4];
+    auto load_frag = [&](int s_, half8* a, half8* bf) {
+      const unsigned char* Ap = Arow + (s_ >> 1) * ROWB + (s_ & 1) * 32;
+      const unsigned char* Bp = Bst + (s_ >> 1) * (BN * ROWB) + (s_ & 1) * 32;
+#pragma unroll
+      for (int t = 0; t < MT; ++t) {
+        a[2 * t] = *(const half8*)(Ap + a_off[t]);
+        a[2 * t + 1] = *(const half8*)(Ap + a_off[t] + 64);
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        bf[2 * t] = *(const half8*)(Bp + b_off[t]);
+        bf[2 * t + 1] = *(const half8*)(Bp + b_off[t] + 64);
+      }
+    };
+    load_frag(0, fa[0], fb[0]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s_ = 0; s_ < 6; ++s_) {
+      half8* a = fa[s_ & 1];
+      half8* bf = fb[s_ & 1];
+      if (s_ + 1 < 6) load_frag(s_ + 1, fa[(s_ + 1) & 1], fb[(s_ + 1) & 1]);
+#pragma unroll
+      for (int tm = 0; tm < MT; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+          accm[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[2 * tm], bf[2 * tn], accm[tm][tn], 0, 0, 0);
+#pragma unroll
+      for (int tm = 0; tm < MT; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+          accc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[2 * tm], bf[2 * tn + 1], accc[tm][tn], 0, 0, 0);
+#pragma unroll
+      for (int tm = 0; tm < MT; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+          accc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[2 * tm + 1], bf[2 * tn], accc[tm][tn], 0, 0, 0);
+      if (s_ + 1 < 6) {
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 LDS read of the next step
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+#pragma unroll
+  for (int st = 0; st < 6; ++st) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // producers: their share of W(st) has landed
+    __syncthreads();
+    PC_T();
+    if (consumer) {
+      mma_stage(st < 3 ? As0 : As1, st % 3, st & 1);
+    } else if (st + 1 < 6) {
+      dma_w(st + 1, (st + 1) & 1);
+    }
+  }
+
+  PC_T();
+  // epilogue: transposed through LDS (conv_common.h), all 512 threads flush
+  __syncthreads();
+  float* Cs = (float*)smem;
+  if (consumer) {
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) {
+      const int cl = tn * 32 + i;
+      const float bv = p.bias ? p.bias[cl] : 0.f;
+#pragma unroll
+      for (int tm = 0; tm < MT; ++tm) {
+        const f32x16 am = accm[tm][tn], ac = accc[tm][tn];
+        conv_stage_tile<BN>(Cs, [&](int r) { return am[r] + ac[r] * LO_INV; }, bv, p.relu, wm * 2 * MT + tm * 2, kh, cl);
+      }
+    }
+  }
+  __syncthreads();
+  conv_flush_tile<BN, 512>(Cs, tid, ty0, tx0, H, W, b, 0, gout, p.out_stride, mem.pool, p.pool_stride, !(p.relu & 8));
+  PC_T();
+#ifdef SHF_CONV_TIMING
+  if (bid == 100 && lane == 0 && (wave == 0 || wave == 4 || wave == 7))
+    printf("[pc] wave%d setup %llu patch+barrier %llu conv1_1 %llu | to-stage0 %llu stages %llu %llu %llu %llu %llu last %llu | epilogue %llu\n", wave,
+           tt[1] - tt[0], tt[2] - tt[1], tt[3] - tt[2], tt[4] - tt[3], tt[5] - tt[4], tt[6] - tt[5], tt[7] - tt[6], tt[8] - tt[7],
+           tt[9] - tt[8], tt[10] - tt[9], tt[11] - tt[10]);
+#endif
+#undef PC_T
+}
+
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
@@ -819,6 +1050,11 @@ void pack_conv_weights_split16(const float* w, int Cout, int Cin, int k, void* d
         dst[row + (ci % 32)] = h;
         dst[row + 32 + (ci % 32)] = l;
       }
+}
+
+bool conv_f16x3_uses_pc() {
+  static const bool on = !(getenv("SHF_F16X3_PC") && atoi(getenv("SHF_F16X3_PC")) == 0);
+  return on;
 }
 
 bool conv_f16x3_uses_w4(int Cin) {
@@ -849,6 +1085,7 @@ static int launch_f16x3_t(const ConvArgs* as, int n, hipStream_t s) {
   p.pool_stride = a.pool.p ? a.pool.cstride : 0;
   p.nct = p.Cout / BN;
   p.nmem = n;
+  for (int i = 0; i < MAX_GROUP; ++i) p.tile_starts[i] = 0x7fffffff;
   p.dbg = nullptr;
   p.w1t = a.w1t;
   p.b1 = a.b1;
@@ -873,6 +1110,7 @@ static int launch_f16x3_t(const ConvArgs* as, int n, hipStream_t s) {
     m.tiles_x = (m.W + TW - 1) / TW;
     m.tiles_per_img = m.tiles_x * ((m.H + TH - 1) / TH);
     m.tile_start = (int)tiles;
+    p.tile_starts[i] = (int)tiles;
     tiles += (long long)m.tiles_per_img * m.B;
   }
   if (vec_ok) p.relu |= 16;
@@ -888,7 +1126,12 @@ static int launch_f16x3_t(const ConvArgs* as, int n, hipStream_t s) {
   // the 4-wave kernel has the faster K loop (~6.2 k cycles per stage against ~7 k) but the dearer
   // prologue / epilogue (half the waves to fetch the first tiles and to write the result): it wins from
   // 4 input-channel chunks (Cin 128) up.  SHF_F16X3_W4 = 0 / 1 forces never / always (experiments).
-  if (BN == 128 && !FUSE1 && DIL == 1 && KS == 3 && conv_f16x3_uses_w4(p.Cin))
+  if (FUSE1 && BN == 64 && conv_f16x3_uses_pc() && vec_ok && p.Cin == 64 && p.Cout == 64) {
+    // two halo tiles (both channel chunks of conv1_1's output) + the weight double buffer + the image patch
+    const size_t lds_pc = 2 * (size_t)HP * ROWB + 2 * 3 * (size_t)BN * ROWB + 3 * (TH + 4) * (TW + 4) * sizeof(float);
+    hipLaunchKernelGGL(conv_mfma_f16x3_pc_kernel, dim3((unsigned)tiles), dim3(512), lds_pc, s, p);
+  }
+  else if (BN == 128 && !FUSE1 && DIL == 1 && KS == 3 && conv_f16x3_uses_w4(p.Cin))
     hipLaunchKernelGGL(conv_mfma_f16x3_w4_kernel, dim3((unsigned)(tiles * p.nct)), dim3(256), lds, s, p);
   else
     hipLaunchKernelGGL((conv_mfma_f16x3_kernel<BN, FUSE1, DIL, KS>), dim3((unsigned)(tiles * p.nct)), dim3(512), lds, s, p);
@@ -928,6 +1171,8 @@ int conv_f16x3_init_attributes() {
   SHF_HIP_OK(hipFuncSetAttribute((const void*)conv_mfma_f16x3_kernel<64, false, 4, 3>,
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   SHF_HIP_OK(hipFuncSetAttribute((const void*)conv_mfma_f16x3_w4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 160 * 1024));
+  SHF_HIP_OK(hipFuncSetAttribute((const void*)conv_mfma_f16x3_pc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                  160 * 1024));
   SHF_HIP_OK(hipFuncSetAttribute((const void*)conv_mfma_f16x3_kernel<64, false, 1, 3>,
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

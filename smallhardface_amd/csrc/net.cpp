@@ -134,7 +134,7 @@ struct Layer {
 };
 
 // the first 8 classes are the instantiations of conv_mfma_f32_kernel, named like rocprofv3 prints them
-enum ProfClass { PC_CONV_MFMA, PC_CONV_MFMA_1 = 1, PC_CONV_MFMA_7 = 7, PC_CONV_F16X3_128, PC_CONV_F16X3_W4, PC_CONV_F16X3_64, PC_CONV_F16X3_64_FUSE1, PC_CONV_F16X3_64_D2, PC_CONV_F16X3_64_D4, PC_CONV_F16X3_128_K1, PC_CONV_F16X3_64_K1, PC_CONV_FIRST, PC_CONV_DIRECT, PC_POOL, PC_DECONV, PC_TAIL, PC_MERGE, PC_LAYOUT, PC_COUNT };
+enum ProfClass { PC_CONV_MFMA, PC_CONV_MFMA_1 = 1, PC_CONV_MFMA_7 = 7, PC_CONV_F16X3_128, PC_CONV_F16X3_W4, PC_CONV_F16X3_64, PC_CONV_F16X3_64_FUSE1, PC_CONV_F16X3_64_D2, PC_CONV_F16X3_64_D4, PC_CONV_F16X3_128_K1, PC_CONV_F16X3_64_K1, PC_CONV_F16X3_PC, PC_CONV_FIRST, PC_CONV_DIRECT, PC_POOL, PC_DECONV, PC_TAIL, PC_MERGE, PC_LAYOUT, PC_COUNT };
 static const char* kProfNames[PC_COUNT] = {"conv_mfma_f32_kernel<3, 1, 128, 8, 16>", "conv_mfma_f32_kernel<3, 2, 128, 8, 16>",
                                            "conv_mfma_f32_kernel<3, 4, 128, 8, 16>", "conv_mfma_f32_kernel<3, 1, 64, 16, 16>",
                                            "conv_mfma_f32_kernel<3, 2, 64, 16, 16>", "conv_mfma_f32_kernel<3, 4, 64, 16, 16>",
@@ -143,7 +143,7 @@ static const char* kProfNames[PC_COUNT] = {"conv_mfma_f32_kernel<3, 1, 128, 8, 1
                                            "conv_mfma_f16x3_kernel<64, false, 1, 3>",
                                            "conv_mfma_f16x3_kernel<64, true, 1, 3>", "conv_mfma_f16x3_kernel<64, false, 2, 3>",
                                            "conv_mfma_f16x3_kernel<64, false, 4, 3>", "conv_mfma_f16x3_kernel<128, false, 1, 1>",
-                                           "conv_mfma_f16x3_kernel<64, false, 1, 1>",
+                                           "conv_mfma_f16x3_kernel<64, false, 1, 1>", "conv_mfma_f16x3_pc_kernel",
                                            "conv_first_kernel", "conv_direct_kernel", "maxpool_kernel",
                                            "deconv_depthwise", "detect_tail", "box_merge", "layout"};
 
@@ -185,7 +185,7 @@ struct Prof {
 };
 
 static int f16x3_prof_class(const ConvArgs& a, int nout) {  // which split-fp16 kernel launch_conv_f16x3_group picks
-  if (a.img) return PC_CONV_F16X3_64_FUSE1;
+  if (a.img) return conv_f16x3_uses_pc() && a.in.C == 64 && nout == 64 ? PC_CONV_F16X3_PC : PC_CONV_F16X3_64_FUSE1;
   if (a.k == 1) return nout % 128 ? PC_CONV_F16X3_64_K1 : PC_CONV_F16X3_128_K1;
   if (a.dil == 2) return PC_CONV_F16X3_64_D2;
   if (a.dil == 4) return PC_CONV_F16X3_64_D4;

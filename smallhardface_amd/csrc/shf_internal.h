@@ -51,6 +51,7 @@ int launch_conv_direct(const ConvArgs& a, hipStream_t s);
 int conv_init_attributes();
 // split-fp16 (3 x fp16 MFMA, fp32-class accuracy) variant for 3x3 / dilation 1 layers
 bool conv_f16x3_eligible(int Cin, int Cout, int k, int pad, int dil);
+bool conv_f16x3_uses_pc();         // fused first pair: producer/consumer kernel (SHF_F16X3_PC=0 disables)
 bool conv_f16x3_uses_w4(int Cin);  // Cout % 128 == 0 layers: 4-wave (one per SIMD) kernel or the 8-wave one
 int conv_f16x3_init_attributes();
 int launch_conv_f16x3_group(const ConvArgs* as, int n, hipStream_t s);
