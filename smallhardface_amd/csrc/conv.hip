@@ -385,6 +385,7 @@ static int launch_mfma_t(const ConvArgs* as, int n, hipStream_t s) {
   p.nmem = n;
   for (int i = 0; i < MAX_GROUP; ++i) p.tile_starts[i] = 0x7fffffff;
   p.w1t = nullptr;
+  p.w1f = nullptr;
   p.b1 = nullptr;
   long long tiles = 0;
   for (int i = 0; i < n; ++i) {

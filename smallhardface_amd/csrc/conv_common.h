@@ -29,6 +29,7 @@ struct ConvK {
   int pool_stride;   // floats per pixel of the pool buffer
   int nct, nmem;
   const float* w1t;  // FUSE1: first-layer weights transposed to [27][64]
+  const void* w1f;   // FUSE1 (producer/consumer kernel): the same as split-fp16 MFMA B fragments (pack_first_conv_frags)
   const float* b1;   // FUSE1: first-layer bias [64]
   unsigned long long* dbg;  // SHF_CONV_TIMING builds only: per-wave phase cycle sums
   int tile_starts[MAX_GROUP];  // m[q].tile_start again, contiguous (unused entries INT_MAX): ONE scalar load finds a

@@ -854,6 +854,10 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
   const int ty0 = (pt / mem.tiles_x) * TH, tx0 = (pt % mem.tiles_x) * TW;
   const int H = mem.H, W = mem.W;
   float* __restrict__ gout = mem.out;
+#ifdef SHF_CONV_TIMING
+  asm volatile("" :: "s"(H), "s"(W), "s"(ty0), "s"(tx0));
+  const unsigned long long t_dec = __builtin_amdgcn_s_memtime();
+#endif
 
   constexpr int SLAB_B = BN * ROWB;          // 9 KiB
   constexpr int PCS_SLAB = SLAB_B / 1024;    // 9
@@ -874,8 +878,15 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
     }
   };
   if (!consumer) dma_w(0, 0);
+#ifdef SHF_CONV_TIMING
+  const unsigned long long t_dma = __builtin_amdgcn_s_memtime();
+#endif
 
-  {  // prologue, all eight waves: conv1_1 + ReLU of the whole halo tile, lane = output channel
+  {  // prologue, all eight waves: conv1_1 + ReLU of the whole halo tile ON THE MATRIX CORES
+    // [324 halo px x 27 taps (padded to 32)] x [32 x 64 couts] as split-fp16 MFMAs: 11 row tiles of 32 pixels,
+    // 12 MFMAs each; a lane builds its A fragments (pixel lane&31, 8 taps) from the LDS image patch, the B
+    // fragments (weights) come pre-packed from global memory.  N tile 0 / 1 = channel chunk 0 / 1 = halo tile
+    // As0 / As1.  (On the vector ALUs this was 15-18 k cycles per tile, a third of the block.)
     const float* img = mem.img + (size_t)b * 3 * H * W;
     for (int idx = tid; idx < 3 * PH * PW; idx += 512) {
       const int ci = idx / (PH * PW), r = idx - ci * (PH * PW);
@@ -884,43 +895,75 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
       patch[idx] = ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) ? img[((size_t)ci * H + gy) * W + gx] : 0.f;
     }
     PC_T();
-    float w1[27];
+    const int i1 = lane & 31, kh1 = lane >> 5;
+    half8 bw[2][2][2];  // [n][kk][hi/lo]
 #pragma unroll
-    for (int t = 0; t < 27; ++t) w1[t] = p.w1t[t * 64 + lane];
-    const float bias1 = p.b1 ? p.b1[lane] : 0.f;
-    unsigned char* Adst = (lane < 32 ? As0 : As1) + (lane & 31) * 2;
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int hl = 0; hl < 2; ++hl)
+          bw[n][kk][hl] = *(const half8*)((const _Float16*)p.w1f + ((size_t)((n * 2 + kk) * 2 + hl) * 64 + lane) * 8);
+    const float bias0 = p.b1 ? p.b1[i1] : 0.f, bias1 = p.b1 ? p.b1[32 + i1] : 0.f;
     __syncthreads();
     PC_T();
-    // pixel pairs (hy, hx..hx+1), hx even: 9 per halo row, 162 per tile, round-robin over the waves
-#pragma unroll 2
-    for (int pr = wave_u; pr < HTH * (HTW / 2); pr += 8) {
-      const int hy = pr / (HTW / 2), hx = (pr - hy * (HTW / 2)) * 2;
-      f32x2 acc = {bias1, bias1};
+    constexpr int NMT = (HP + 31) / 32;  // 11 row tiles
+#pragma unroll 1
+    for (int m = wave_u; m < NMT; m += 8) {
+      const int hp = m * 32 + i1 < HP ? m * 32 + i1 : HP - 1;
+      const int hy = hp / HTW, hx = hp - hy * HTW;
+      const float* pb = patch + hy * PW + hx;
+      half8 ah[2], al[2];
 #pragma unroll
-      for (int ci = 0; ci < 3; ++ci)
+      for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-        for (int kyy = 0; kyy < 3; ++kyy)
+        for (int j = 0; j < 8; ++j) {
+          // tap k = kk*16 + kh*8 + j -> (ci, ky, kx); taps 27..31 are padding
+          const int k0 = kk * 16 + j, k1 = kk * 16 + 8 + j;
+          const int o0 = ((k0 / 9) * PH + (k0 % 9) / 3) * PW + k0 % 3;
+          const int o1 = k1 < 27 ? ((k1 / 9) * PH + (k1 % 9) / 3) * PW + k1 % 3 : 0;
+          float x = pb[kh1 ? o1 : o0];
+          if (k1 >= 27 && kh1) x = 0.f;
+          const _Float16 h = (_Float16)x;
+          ah[kk][j] = h;
+          al[kk][j] = (_Float16)((x - (float)h) * LO_SCALE);
+        }
+      f32x16 cm[2], cc[2];
 #pragma unroll
-          for (int kxx = 0; kxx < 3; ++kxx) {
-            const float* pp = patch + (ci * PH + hy + kyy) * PW + hx + kxx;   // wave-uniform: LDS broadcast
-            const float w = w1[(ci * 3 + kyy) * 3 + kxx];
-            acc = __builtin_elementwise_fma(f32x2{pp[0], pp[1]}, f32x2{w, w}, acc);
+      for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { cm[n][r] = 0.f; cc[n][r] = 0.f; }
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+          cm[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[kk], bw[n][kk][0], cm[n], 0, 0, 0);
+          cc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[kk], bw[n][kk][1], cc[n], 0, 0, 0);
+        }
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) cc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[kk], bw[n][kk][0], cc[n], 0, 0, 0);
+      // C row (pixel) = (r & 3) + 8 (r >> 2) + 4 kh, C column (cout) = lane & 31
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int hq = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh1;
+        const int qy = hq / HTW, qx = hq - qy * HTW;
+        const bool in = (unsigned)(ty0 - 1 + qy) < (unsigned)H && (unsigned)(tx0 - 1 + qx) < (unsigned)W;  // else: conv1_2's zero padding
+        if (hq < HP) {
+#pragma unroll
+          for (int n = 0; n < 2; ++n) {
+            const float v = in ? fmaxf(cm[n][r] + cc[n][r] * LO_INV + (n ? bias1 : bias0), 0.f) : 0.f;
+            const _Float16 h = (_Float16)v;
+            unsigned char* d = (n ? As1 : As0) + hq * ROWB + i1 * 2;
+            *(_Float16*)d = h;
+            *(_Float16*)(d + 64) = (_Float16)((v - (float)h) * LO_SCALE);
           }
-      const bool row_in = (unsigned)(ty0 - 1 + hy) < (unsigned)H;
-      const bool in0 = row_in && (unsigned)(tx0 - 1 + hx) < (unsigned)W;      // outside the image: conv1_2's zero padding
-      const bool in1 = row_in && (unsigned)(tx0 + hx) < (unsigned)W;
-      const float v0 = in0 ? fmaxf(acc[0], 0.f) : 0.f, v1 = in1 ? fmaxf(acc[1], 0.f) : 0.f;
-      const _Float16 h0 = (_Float16)v0, h1 = (_Float16)v1;
-      const _Float16 l0 = (_Float16)((v0 - (float)h0) * LO_SCALE), l1 = (_Float16)((v1 - (float)h1) * LO_SCALE);
-      unsigned char* d = Adst + (hy * HTW + hx) * ROWB;
-      *(_Float16*)d = h0;
-      *(_Float16*)(d + 64) = l0;
-      *(_Float16*)(d + ROWB) = h1;
-      *(_Float16*)(d + ROWB + 64) = l1;
+        }
+      }
     }
   }
 
-  PC_T();
   // consumer geometry: wave wm = rows 4 wm .. 4 wm + 3 (two 2x16-pixel MFMA row tiles), all 64 couts
   const int i = lane & 31, kh = lane >> 5;
   int dy, px;
@@ -1023,8 +1066,8 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
   PC_T();
 #ifdef SHF_CONV_TIMING
   if (bid == 100 && lane == 0 && (wave == 0 || wave == 4 || wave == 7))
-    printf("[pc] wave%d setup %llu patch+barrier %llu conv1_1 %llu | to-stage0 %llu stages %llu %llu %llu %llu %llu last %llu | epilogue %llu\n", wave,
-           tt[1] - tt[0], tt[2] - tt[1], tt[3] - tt[2], tt[4] - tt[3], tt[5] - tt[4], tt[6] - tt[5], tt[7] - tt[6], tt[8] - tt[7],
+    printf("[pc] wave%d decode %llu dma-issue %llu | setup %llu patch+barrier %llu conv1_1 %llu | to-stage0 %llu stages %llu %llu %llu %llu %llu last %llu | epilogue %llu\n", wave,
+           t_dec - tt[0], t_dma - t_dec, tt[1] - tt[0], tt[2] - tt[1], tt[3] - tt[2], tt[4] - tt[3], tt[5] - tt[4], tt[6] - tt[5], tt[7] - tt[6], tt[8] - tt[7],
            tt[9] - tt[8], tt[10] - tt[9], tt[11] - tt[10]);
 #endif
 #undef PC_T
@@ -1050,6 +1093,21 @@ void pack_conv_weights_split16(const float* w, int Cout, int Cin, int k, void* d
         dst[row + (ci % 32)] = h;
         dst[row + 32 + (ci % 32)] = l;
       }
+}
+
+void pack_first_conv_frags(const float* w, void* dst_) {
+  _Float16* dst = (_Float16*)dst_;
+  for (int n = 0; n < 2; ++n)
+    for (int kk = 0; kk < 2; ++kk)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int j = 0; j < 8; ++j) {
+          const int i = lane & 31, kh = lane >> 5, k = kk * 16 + kh * 8 + j;
+          const float x = k < 27 ? w[(size_t)(n * 32 + i) * 27 + k] : 0.f;
+          const _Float16 h = (_Float16)x;
+          const _Float16 l = (_Float16)((x - (float)h) * f16x3::LO_SCALE);
+          dst[(((size_t)(n * 2 + kk) * 2 + 0) * 64 + lane) * 8 + j] = h;
+          dst[(((size_t)(n * 2 + kk) * 2 + 1) * 64 + lane) * 8 + j] = l;
+        }
 }
 
 bool conv_f16x3_uses_pc() {
@@ -1088,6 +1146,7 @@ static int launch_f16x3_t(const ConvArgs* as, int n, hipStream_t s) {
   for (int i = 0; i < MAX_GROUP; ++i) p.tile_starts[i] = 0x7fffffff;
   p.dbg = nullptr;
   p.w1t = a.w1t;
+  p.w1f = a.w1f;
   p.b1 = a.b1;
   long long tiles = 0;
   bool vec_ok = !(getenv("SHF_CONV_SCALAR_EPILOGUE") && atoi(getenv("SHF_CONV_SCALAR_EPILOGUE")));
@@ -1126,7 +1185,7 @@ static int launch_f16x3_t(const ConvArgs* as, int n, hipStream_t s) {
   // the 4-wave kernel has the faster K loop (~6.2 k cycles per stage against ~7 k) but the dearer
   // prologue / epilogue (half the waves to fetch the first tiles and to write the result): it wins from
   // 4 input-channel chunks (Cin 128) up.  SHF_F16X3_W4 = 0 / 1 forces never / always (experiments).
-  if (FUSE1 && BN == 64 && conv_f16x3_uses_pc() && vec_ok && p.Cin == 64 && p.Cout == 64) {
+  if (FUSE1 && BN == 64 && conv_f16x3_uses_pc() && vec_ok && p.Cin == 64 && p.Cout == 64 && p.w1f) {
     // two halo tiles (both channel chunks of conv1_1's output) + the weight double buffer + the image patch
     const size_t lds_pc = 2 * (size_t)HP * ROWB + 2 * 3 * (size_t)BN * ROWB + 3 * (TH + 4) * (TW + 4) * sizeof(float);
     hipLaunchKernelGGL(conv_mfma_f16x3_pc_kernel, dim3((unsigned)tiles), dim3(512), lds_pc, s, p);

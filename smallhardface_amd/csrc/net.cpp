@@ -87,7 +87,7 @@ struct HostBuf {
 struct ParamBlob {
   std::vector<int> shape;
   std::vector<float> host;
-  DevBuf raw, packed, packed16, first_t;
+  DevBuf raw, packed, packed16, first_t, first_frag;
   bool dirty = true;
   size_t count() const {
     size_t c = 1;
@@ -937,6 +937,12 @@ void shf_net::commit_params(int li) {
         for (int r = 0; r < K; ++r) t[(size_t)r * co + o] = p.host[(size_t)o * K + r];
       p.first_t.ensure(t.size() * 4);
       HIP_THROW(hipMemcpy(p.first_t.p, t.data(), t.size() * 4, hipMemcpyHostToDevice));
+      if (co == 64 && K == 27) {  // the shape the fused producer/consumer kernel computes on the matrix cores
+        std::vector<uint16_t> fr(kFirstConvFragHalfs);
+        pack_first_conv_frags(p.host.data(), fr.data());
+        p.first_frag.ensure(fr.size() * 2);
+        HIP_THROW(hipMemcpy(p.first_frag.p, fr.data(), fr.size() * 2, hipMemcpyHostToDevice));
+      }
     }
     if (pi == 0 && L.type == "Convolution" && L.kclass == 0 && !in_tail) {
       std::vector<float> packed(p.count());
@@ -1011,6 +1017,7 @@ void shf_net::forward_ops(bool fused_path, float im_h, float im_w, float im_scal
           Blob& db = blobs[F.bottoms[0]];
           a.img = db.ext_dev ? db.ext_dev : (const float*)db.dev.p;
           a.w1t = (const float*)F.params[0]->first_t.p;
+          a.w1f = F.params[0]->first_frag.p;
           a.b1 = F.params.size() > 1 ? (const float*)F.params[1]->raw.p : nullptr;
         }
         if (fused_path && conv_mode == 1 && L.first_dst >= 0 && layers[L.first_dst].params[0]->packed16.p)

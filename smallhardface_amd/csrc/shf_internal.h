@@ -36,6 +36,7 @@ struct ConvArgs {
   int relu = 0;
   const float* img = nullptr;  // fused first layer (f16x3 only): raw NCHW image, transposed weights, bias
   const float* w1t = nullptr;
+  const void* w1f = nullptr;   // first-layer weights as split-fp16 MFMA B fragments (pack_first_conv_frags)
   const float* b1 = nullptr;
   View pool;           // optional fused MAX 2x2/2 pool output (p == nullptr: none)
   int write_main = 1;  // 0: the un-pooled output has no other reader and is not written
@@ -57,6 +58,9 @@ int conv_f16x3_init_attributes();
 int launch_conv_f16x3_group(const ConvArgs* as, int n, hipStream_t s);
 size_t split16_conv_weight_halfs(int Cout, int Cin, int k);
 void pack_conv_weights_split16(const float* w, int Cout, int Cin, int k, void* dst);
+// first layer (64, 27) as the B operand of v_mfma_f32_32x32x16_f16: [n 2][kk 2][hi/lo 2][lane 64][8 halfs], K padded 27 -> 32
+constexpr size_t kFirstConvFragHalfs = 2 * 2 * 2 * 64 * 8;
+void pack_first_conv_frags(const float* w, void* dst);
 // host-side weight re-pack for the mfma kernel
 void pack_conv_weights(const float* w, int Cout, int Cin, int k, float* dst);
 size_t packed_conv_weight_floats(int Cout, int Cin, int k);

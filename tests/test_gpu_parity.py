@@ -263,7 +263,7 @@ def test_nms_vote_large(n):
     assert len(nms(d[keep], 0.4)) == len(keep)
 
 
-def test_detect_driver_vs_fused_vs_oracle():
+def test_detect_driver_vs_fused_vs_oracle(conv_mode):
     """lib/test.py control flow on the GPU net, the fused device path, and the oracle net."""
     from smallhardface_amd import test as T
     cfg.MODEL.DIFFERENT_DILATION.ENABLE = True
@@ -275,8 +275,18 @@ def test_detect_driver_vs_fused_vs_oracle():
         cfg.TEST.NMS_METHOD = method
         dets, _ = T.detect(gnet, None, thresh=0.05, pyramid=True, im=im)
         fused = T.detect_fused(gnet, T.pyramid_units(im), thresh=0.05)
-        assert dets[0].shape == fused[0].shape
-        np.testing.assert_array_equal(np.asarray(dets[0], dtype=np.float64), fused[0])
+        if conv_mode == "fp32":
+            # exact arithmetic everywhere: one Net.forward() per unit and the fused path agree bit for bit
+            assert dets[0].shape == fused[0].shape
+            np.testing.assert_array_equal(np.asarray(dets[0], dtype=np.float64), fused[0])
+        else:
+            # split-fp16: the fused path also computes conv1_1 on the matrix cores (fp32-class, not the same
+            # rounding as the stand-alone first-layer kernel behind Net.forward()): same detections within the
+            # north-star tolerances
+            assert abs(dets[0].shape[0] - fused[0].shape[0]) <= 2
+            n = min(dets[0].shape[0], fused[0].shape[0])
+            assert np.abs(np.asarray(dets[0])[:n, 4] - fused[0][:n, 4]).max() < SCORE_TOL
+            assert np.abs(np.asarray(dets[0])[:n, :4] - fused[0][:n, :4]).max() < 0.05
         assert dets[0].shape[0] > 0
         # units spread over 3 execution lanes (streams): same detections, same order
         laned = T.FusedDetector(gnet, n_lanes=3).detect(list(T.pyramid_units(im)), thresh=0.05)
