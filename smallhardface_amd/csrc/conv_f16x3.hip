@@ -836,10 +836,13 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
   PC_T();
   constexpr int BN = 64, MT = 2;
   constexpr int PW = TW + 4, PH = TH + 4;
-  unsigned char* As0 = smem;                        // [HP][ROWB] channels  0..31 of conv1_1's output
-  unsigned char* As1 = smem + HP * ROWB;            // [HP][ROWB] channels 32..63
-  unsigned char* Bs = smem + 2 * HP * ROWB;         // [2][3][BN][ROWB]
+  constexpr int HPP = (HP + 31) / 32 * 32;          // 352: tile rows padded to whole 32-row MFMA tiles, so that
+                                                    // conv1_1's epilogue stores need no per-row guard
+  unsigned char* As0 = smem;                        // [HPP][ROWB] channels  0..31 of conv1_1's output
+  unsigned char* As1 = smem + HPP * ROWB;           // [HPP][ROWB] channels 32..63
+  unsigned char* Bs = smem + 2 * HPP * ROWB;        // [2][3][BN][ROWB]
   float* patch = (float*)(Bs + 2 * 3 * BN * ROWB);  // [3][PH][PW] raw image patch
+  unsigned char* valid = (unsigned char*)(patch + 3 * PH * PW);  // [HPP] halo pixel inside the image? (0 in the padding)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
@@ -894,6 +897,10 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
       const int gy = ty0 - 2 + py, gx = tx0 - 2 + pxx;
       patch[idx] = ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) ? img[((size_t)ci * H + gy) * W + gx] : 0.f;
     }
+    if (tid < HPP) {
+      const int qy = tid / HTW, qx = tid - qy * HTW;
+      valid[tid] = (tid < HP && (unsigned)(ty0 - 1 + qy) < (unsigned)H && (unsigned)(tx0 - 1 + qx) < (unsigned)W) ? 1 : 0;
+    }
     PC_T();
     const int i1 = lane & 31, kh1 = lane >> 5;
     half8 bw[2][2][2];  // [n][kk][hi/lo]
@@ -908,8 +915,9 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
     __syncthreads();
     PC_T();
     constexpr int NMT = (HP + 31) / 32;  // 11 row tiles
-#pragma unroll 1
-    for (int m = wave_u; m < NMT; m += 8) {
+    // work items: tiles 0..7 whole (one per wave), tiles 8..10 split by N tile over waves 0..5: the longest
+    // wave does 1.5 tiles instead of 2
+    auto conv1_tile = [&](int m, int n_lo, int n_hi) {
       const int hp = m * 32 + i1 < HP ? m * 32 + i1 : HP - 1;
       const int hy = hp / HTW, hx = hp - hy * HTW;
       const float* pb = patch + hy * PW + hx;
@@ -928,40 +936,38 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
           ah[kk][j] = h;
           al[kk][j] = (_Float16)((x - (float)h) * LO_SCALE);
         }
-      f32x16 cm[2], cc[2];
 #pragma unroll
-      for (int n = 0; n < 2; ++n)
+      for (int n = 0; n < 2; ++n) {
+        if (n < n_lo || n >= n_hi) continue;  // wave-uniform
+        f32x16 cm, cc;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { cm[n][r] = 0.f; cc[n][r] = 0.f; }
+        for (int r = 0; r < 16; ++r) { cm[r] = 0.f; cc[r] = 0.f; }
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-        for (int n = 0; n < 2; ++n) {
-          cm[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[kk], bw[n][kk][0], cm[n], 0, 0, 0);
-          cc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[kk], bw[n][kk][1], cc[n], 0, 0, 0);
+        for (int kk = 0; kk < 2; ++kk) {
+          cm = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[kk], bw[n][kk][0], cm, 0, 0, 0);
+          cc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[kk], bw[n][kk][1], cc, 0, 0, 0);
         }
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk)
+        for (int kk = 0; kk < 2; ++kk) cc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[kk], bw[n][kk][0], cc, 0, 0, 0);
+        // C row (pixel) = (r & 3) + 8 (r >> 2) + 4 kh, C column (cout) = lane & 31
+        const float bias = n ? bias1 : bias0;
+        unsigned char* At = (n ? As1 : As0) + i1 * 2;
+        unsigned char ok[16];
 #pragma unroll
-        for (int n = 0; n < 2; ++n) cc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[kk], bw[n][kk][0], cc[n], 0, 0, 0);
-      // C row (pixel) = (r & 3) + 8 (r >> 2) + 4 kh, C column (cout) = lane & 31
+        for (int r = 0; r < 16; ++r) ok[r] = valid[m * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh1];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int hq = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh1;
-        const int qy = hq / HTW, qx = hq - qy * HTW;
-        const bool in = (unsigned)(ty0 - 1 + qy) < (unsigned)H && (unsigned)(tx0 - 1 + qx) < (unsigned)W;  // else: conv1_2's zero padding
-        if (hq < HP) {
-#pragma unroll
-          for (int n = 0; n < 2; ++n) {
-            const float v = in ? fmaxf(cm[n][r] + cc[n][r] * LO_INV + (n ? bias1 : bias0), 0.f) : 0.f;
-            const _Float16 h = (_Float16)v;
-            unsigned char* d = (n ? As1 : As0) + hq * ROWB + i1 * 2;
-            *(_Float16*)d = h;
-            *(_Float16*)(d + 64) = (_Float16)((v - (float)h) * LO_SCALE);
-          }
+        for (int r = 0; r < 16; ++r) {
+          const int hq = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh1;
+          // valid[]: 0 outside the image (conv1_2's zero padding, not conv1_1 evaluated out there)
+          const float v = ok[r] ? fmaxf(cm[r] + cc[r] * LO_INV + bias, 0.f) : 0.f;
+          const _Float16 h = (_Float16)v;
+          *(_Float16*)(At + hq * ROWB) = h;
+          *(_Float16*)(At + hq * ROWB + 64) = (_Float16)((v - (float)h) * LO_SCALE);
         }
       }
-    }
+    };
+    conv1_tile(wave_u, 0, 2);
+    if (wave_u < 2 * (NMT - 8)) conv1_tile(8 + wave_u % (NMT - 8), wave_u / (NMT - 8), wave_u / (NMT - 8) + 1);
   }
 
   // consumer geometry: wave wm = rows 4 wm .. 4 wm + 3 (two 2x16-pixel MFMA row tiles), all 64 couts
@@ -1187,7 +1193,8 @@ static int launch_f16x3_t(const ConvArgs* as, int n, hipStream_t s) {
   // 4 input-channel chunks (Cin 128) up.  SHF_F16X3_W4 = 0 / 1 forces never / always (experiments).
   if (FUSE1 && BN == 64 && conv_f16x3_uses_pc() && vec_ok && p.Cin == 64 && p.Cout == 64 && p.w1f) {
     // two halo tiles (both channel chunks of conv1_1's output) + the weight double buffer + the image patch
-    const size_t lds_pc = 2 * (size_t)HP * ROWB + 2 * 3 * (size_t)BN * ROWB + 3 * (TH + 4) * (TW + 4) * sizeof(float);
+    constexpr size_t HPP = (HP + 31) / 32 * 32;
+    const size_t lds_pc = 2 * HPP * ROWB + 2 * 3 * (size_t)BN * ROWB + 3 * (TH + 4) * (TW + 4) * sizeof(float) + HPP;
     hipLaunchKernelGGL(conv_mfma_f16x3_pc_kernel, dim3((unsigned)tiles), dim3(512), lds_pc, s, p);
   }
   else if (BN == 128 && !FUSE1 && DIL == 1 && KS == 3 && conv_f16x3_uses_w4(p.Cin))
