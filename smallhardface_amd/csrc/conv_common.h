@@ -90,7 +90,7 @@ __device__ __forceinline__ void conv_store_tile(GetV getv, float bv, int relu_fl
 // channel axis: float4 per lane, 512 contiguous bytes per pixel, and the fused 2x2 pool becomes a max
 // over four float4 rows.  Needs 16-byte aligned channel views (the launcher checks and otherwise keeps
 // the scalar conv_store_tile path).
-constexpr int CS_PAD = 4;
+constexpr int CS_PAD = 16;  // 2 x (BN + CS_PAD) words = 32 (mod 64 banks): the two half-waves of a staging ds_write_b32 (pixels x, x+2) never share a bank
 
 // stage the 2x16-pixel x 32-cout MFMA tile of one lane: local rows ly0, ly0+1; `cl` = local cout
 template <int BN, typename GetV>
