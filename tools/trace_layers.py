@@ -15,7 +15,8 @@ def main():
     f = sorted(glob.glob(os.path.join(root, "**", "*kernel_trace.csv"), recursive=True))[-1]
     rows = list(csv.DictReader(open(f)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    conv = [i for i, r in enumerate(rows) if "f16x3_kernel<64, true>" in r["Kernel_Name"] or "ELi64ELb1" in r["Kernel_Name"]]
+    conv = [i for i, r in enumerate(rows) if "f16x3_pc_kernel" in r["Kernel_Name"] or "f16x3_kernel<64, true" in r["Kernel_Name"]
+            or "ELi64ELb1" in r["Kernel_Name"]]
     if len(conv) < 2:
         conv = [i for i, r in enumerate(rows) if "conv_first" in r["Kernel_Name"]]
     a, b = conv[-2], conv[-1]  # one full image: from a first fused conv to the next
