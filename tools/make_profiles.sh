@@ -17,7 +17,7 @@ cd /tmp && export TMPDIR=/tmp && cd $root
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --steps 3 --warmup 1 > $out/bench_under_rocprof.out 2> $out/bench_under_rocprof.log
 grep '^{"metric"' $out/bench_under_rocprof.out | tail -1 > $dst/${tag}_bench_under_rocprof.json
 cp $(ls $out/stats/*/*kernel_stats.csv | head -1) $dst/${tag}_bench_kernel_stats.csv
-python3 bench.py --steps 20 --warmup 3 2>/dev/null | tail -1 > $dst/${tag}_bench.json
+python3 bench.py 2>/dev/null | tail -1 > $dst/${tag}_bench.json
 python3 bench.py --steps 5 --warmup 2 --conv-mode fp32 --no-cpu-baseline 2>/dev/null | tail -1 > $dst/${tag}_bench_fp32_mode.json
 python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --host-input image 2>/dev/null | tail -1 > $dst/${tag}_bench_from_uint8_image.json
 for c in FETCH_SIZE WRITE_SIZE; do
