@@ -248,12 +248,14 @@ def main():
     for _ in range(2):
         step()
     fence()
-    for _ in range(args.warmup):
+    if not args.no_events:  # HIP events on from the warm-up on: the event pool is created outside the timed region
+        for ln in lanes + getattr(fd, "_heads", []):
+            ln.prof_enable(True)
+    for _ in range(max(args.warmup, 0 if args.no_events else 1)):
         step()
     fence()
     if not args.no_events:
         for ln in lanes + getattr(fd, "_heads", []):
-            ln.prof_enable(True)
             ln.prof_reset()
     t0 = time.perf_counter()
     for _ in range(args.steps):

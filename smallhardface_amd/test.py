@@ -324,6 +324,10 @@ def inference_worker(rank, imdb, target_test, start, end, thresh, result_queue=N
     caffe.set_mode_gpu()
     caffe.set_device(cfg.GPU_ID)
     net = caffe.Net(str(target_test), str(cfg.TEST.MODEL), caffe.TEST)
+    if "SHF_CONV_MODE" not in os.environ:
+        # split-fp16 matrix-core arithmetic (fp32-class, same parity bars, 3x the throughput of the exact
+        # fp32 MFMA path); SHF_CONV_MODE=0 keeps the library default (exact fp32)
+        net.set_conv_mode("f16x3")
 
     timers = {'detect': Timer(), 'misc': Timer()}
     pyramid = True if len(cfg.TEST.SCALES) > 1 else False
