@@ -66,14 +66,16 @@ __global__ void deconv_dw_kernel(const float* __restrict__ in, const float* __re
     long long P = n / C4;
     const int ox = (int)(P % Wo), oy = (int)((P / Wo) % Ho), b = (int)(P / ((long long)Wo * Ho));
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int a = 0; a < k; ++a) {
+    // only the taps a = (oy+pad) mod stride, +stride, ... hit an integral source row (same for columns): walk
+    // exactly those, in the same ascending (a, bb) order as the full k x k scan
+    for (int a = (oy + pad) % stride; a < k; a += stride) {
       const int ty = oy + pad - a;
-      if (ty < 0 || ty % stride) continue;
+      if (ty < 0) break;
       const int iy = ty / stride;
       if (iy >= H) continue;
-      for (int bb = 0; bb < k; ++bb) {
+      for (int bb = (ox + pad) % stride; bb < k; bb += stride) {
         const int tx = ox + pad - bb;
-        if (tx < 0 || tx % stride) continue;
+        if (tx < 0) break;
         const int ix = tx / stride;
         if (ix >= W) continue;
         const float4 v = *(const float4*)(in + ((size_t)(b * H + iy) * W + ix) * in_stride + c4 * 4);
