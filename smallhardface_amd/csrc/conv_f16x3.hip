@@ -58,14 +58,17 @@ constexpr int TH = 16, TW = 16, HTW = TW + 2, HTH = TH + 2, HP = HTH * HTW;
 constexpr float LO_SCALE = 2048.0f, LO_INV = 1.0f / 2048.0f;
 }  // namespace f16x3
 
+// x -> (hi, lo) for four values, two per instruction: v_cvt_pk_f16_f32 for both halves, packed fp32
+// subtract / scale in between (3 VALU ops per value instead of 6; same results as the scalar form)
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split4(const float4 v, half4& hi, half4& lo) {
-  const float x[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const _Float16 h = (_Float16)x[j];
-    hi[j] = h;
-    lo[j] = (_Float16)((x[j] - (float)h) * f16x3::LO_SCALE);
-  }
+  const f32x2 x01 = {v.x, v.y}, x23 = {v.z, v.w};
+  const half2v h01 = __builtin_convertvector(x01, half2v), h23 = __builtin_convertvector(x23, half2v);
+  const f32x2 r01 = (x01 - __builtin_convertvector(h01, f32x2)) * f16x3::LO_SCALE;
+  const f32x2 r23 = (x23 - __builtin_convertvector(h23, f32x2)) * f16x3::LO_SCALE;
+  const half2v l01 = __builtin_convertvector(r01, half2v), l23 = __builtin_convertvector(r23, half2v);
+  hi = half4{h01[0], h01[1], h23[0], h23[1]};
+  lo = half4{l01[0], l01[1], l23[0], l23[1]};
 }
 
 // BN = 128: waves 4(M) x 2(N), each 64 px x 64 couts (MT = 2 M-tiles); BN = 64: waves 8 x 1, each 32 px x 64 couts.
@@ -538,9 +541,13 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4_kernel(ConvK p) {
   }
   // fp32 piece -> [hi half4 | lo half4] in the same four registers
   auto split_inplace = [&](float4& v, bool valid) {
+#ifdef F16X3_EXPERIMENT_NO_SPLIT  // upper bound of a pre-split activation format (WRONG results: timing only)
+    const float2 h2 = make_float2(v.x, v.y), l2 = make_float2(v.z, valid ? v.w : 0.f);
+#else
     half4 hi, lo;
     split4(valid ? v : make_float4(0.f, 0.f, 0.f, 0.f), hi, lo);
     const float2 h2 = __builtin_bit_cast(float2, hi), l2 = __builtin_bit_cast(float2, lo);
+#endif
     // Left alone the compiler sinks the conversion to its single use after the stage (the hand-over
     // bubble, ~1 k cycles per chunk).  Pinning it here (F16X3_W4_PIN) puts the VALU work under the MFMAs
     // and saves those cycles -- and measured 3 % SLOWER end to end on the same box: the chip is
