@@ -38,9 +38,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef F16X3_DMA_LATE
 #define F16X3_DMA_LATE 1   // 1: the early-finishing waves 0-3 issue the next stage's weight DMA after their MFMAs
 #endif
-#ifndef F16X3_PIPE
-#define F16X3_PIPE 0       // 1: explicit LDS->register software pipeline in the stages without a halo hand-over
-#endif
 #ifndef F16X3_W4_PREFETCH
 #define F16X3_W4_PREFETCH 0  // 4-wave kernel: request the next halo tile a stage early (1) or in the hand-over stage (0)
 #endif
@@ -301,53 +298,6 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_kernel(ConvK p) {
     SHF_T(t2);
     const unsigned char* Arow = As + (ky * DIL * HTW) * ROWB;
     const unsigned char* Bst = Bs + (st & 1) * (KS * BN * ROWB);
-#if F16X3_PIPE
-    bool piped = false;
-    if constexpr (MT == 2 && KS == 3) {
-      if (!(last_row && more_chunks)) {
-        // software pipeline over the six k-steps of the stage: the fragments of step s+1 are fetched
-        // from LDS (into the other register set) underneath the 12 MFMAs of step s.  The stage that
-        // also carries the next halo tile in registers has no room for the second set.
-        piped = true;
-        half8 fa[2][4], fb[2][4];
-        auto load_frag = [&](int s_, half8* a, half8* bf) {
-          const unsigned char* Ap = Arow + (s_ >> 1) * DIL * ROWB + (s_ & 1) * 32;
-          const unsigned char* Bp = Bst + (s_ >> 1) * (BN * ROWB) + (s_ & 1) * 32;
-#pragma unroll
-          for (int t = 0; t < 2; ++t) {
-            a[2 * t] = *(const half8*)(Ap + a_off[t]);
-            a[2 * t + 1] = *(const half8*)(Ap + a_off[t] + 64);
-            bf[2 * t] = *(const half8*)(Bp + b_off[t]);
-            bf[2 * t + 1] = *(const half8*)(Bp + b_off[t] + 64);
-          }
-        };
-        load_frag(0, fa[0], fb[0]);
-#pragma unroll
-        for (int s_ = 0; s_ < 6; ++s_) {
-          half8* a = fa[s_ & 1];
-          half8* bf = fb[s_ & 1];
-          if (s_ + 1 < 6) load_frag(s_ + 1, fa[(s_ + 1) & 1], fb[(s_ + 1) & 1]);
-#pragma unroll
-          for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-            for (int tn = 0; tn < 2; ++tn) {
-              accm[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[2 * tm], bf[2 * tn], accm[tm][tn], 0, 0, 0);
-              accc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[2 * tm], bf[2 * tn + 1], accc[tm][tn], 0, 0, 0);
-              accc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[2 * tm + 1], bf[2 * tn], accc[tm][tn], 0, 0, 0);
-            }
-          if (s_ + 1 < 6) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-              __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);  // 3 MFMA
-              __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // 2 LDS reads of the next step
-            }
-          }
-          __builtin_amdgcn_sched_barrier(0);  // keep the scheduler from piling later steps' reads up here
-        }
-      }
-    }
-    if (!piped)
-#endif
 #pragma unroll
     for (int kx = 0; kx < KS; ++kx) {
       const unsigned char* Ap = Arow + kx * DIL * ROWB;
