@@ -210,6 +210,9 @@ def main():
             last[i] = net.detect_finish(cfg.TEST.NMS_METHOD, cfg.TEST.NMS_THRESH)
 
     def step():
+        if world == 1 and args.mode == "streams":  # the older per-unit-streams schedule: one image at a time
+            last[0] = fd.detect(unit_list, thresh, on_device=True)[0]
+            return
         if world == 1:
             # two images in flight: image k's box merging / read-back overlaps image k+1's convolutions
             if args.host_input == "blobs":
