@@ -25,7 +25,8 @@ struct ConvK {
   int Cin, Cout;
   int in_stride, out_stride;
   int dil, relu;     // relu bit 0: ReLU; bit 3 (8): do NOT write the un-pooled output; bit 4 (16): views are
-                     // 16-byte aligned -> LDS-transposed float4 epilogue
+                     // 16-byte aligned -> LDS-transposed float4 epilogue; bit 5 (32) / bit 6 (64): write the
+                     // main / the pooled output in the split-fp16 activation format (ConvArgs::out_split)
   int pool_stride;   // floats per pixel of the pool buffer
   int nct, nmem;
   const float* w1t;  // FUSE1: first-layer weights transposed to [27][64]
@@ -112,10 +113,25 @@ __device__ __forceinline__ void conv_stage_tile(float* __restrict__ Cs, GetV get
 // A block-wide store covers PPI = NT / (BN/4) pixels; the walk over the 256 pixels is fully unrolled
 // with compile-time (row, column) steps so that an iteration is one LDS read, one predicate and one
 // float4 store off a running pointer.
+// four consecutive channels (c % 4 == 0) of one pixel in the split-fp16 activation format:
+// [chunk c/32][hi 32 halfs | lo 32 halfs], x = hi + lo / 2048
+__device__ __forceinline__ void conv_store_split4(float* __restrict__ pixel, int c, const float4 v) {
+  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  const f2 x01 = {v.x, v.y}, x23 = {v.z, v.w};
+  const h2 h01 = __builtin_convertvector(x01, h2), h23 = __builtin_convertvector(x23, h2);
+  const h2 l01 = __builtin_convertvector((x01 - __builtin_convertvector(h01, f2)) * 2048.0f, h2);
+  const h2 l23 = __builtin_convertvector((x23 - __builtin_convertvector(h23, f2)) * 2048.0f, h2);
+  unsigned char* d = (unsigned char*)(pixel + (c >> 5) * 32) + (c & 31) * 2;
+  *(float2*)d = make_float2(__builtin_bit_cast(float, h01), __builtin_bit_cast(float, h23));
+  *(float2*)(d + 64) = make_float2(__builtin_bit_cast(float, l01), __builtin_bit_cast(float, l23));
+}
+
 template <int BN, int NT>
 __device__ __forceinline__ void conv_flush_tile(const float* __restrict__ Cs, int tid, int ty0, int tx0, int H, int W,
                                                 int b, int cout0, float* __restrict__ gout, int out_stride,
-                                                float* __restrict__ gpool, int pool_stride, bool write_main) {
+                                                float* __restrict__ gpool, int pool_stride, bool write_main,
+                                                bool main_split = false, bool pool_split = false) {
   constexpr int CG = BN / 4;       // float4 groups per pixel
   constexpr int PPI = NT / CG;     // pixels per block-wide store instruction: 8 (4 waves x BN 128), 16 or 32
   static_assert(PPI == 8 || PPI == 16 || PPI == 32, "tile walk assumes 8, 16 or 32 pixels per store round");
@@ -134,7 +150,11 @@ __device__ __forceinline__ void conv_flush_tile(const float* __restrict__ Cs, in
         const int y = y0 + r * YS, x = x0 + c * PPI;
         if (y < H && x < W) {
           const float4 v = *(const float4*)(cs + (r * YS * 16 + c * PPI) * (BN + CS_PAD));
-          *(float4*)(g + r * YS * row_pitch + (size_t)(c * PPI) * out_stride) = v;
+          float* gp = g + r * YS * row_pitch + (size_t)(c * PPI) * out_stride;
+          if (main_split)
+            conv_store_split4(gp - (cout0 + cg * 4), cout0 + cg * 4, v);
+          else
+            *(float4*)gp = v;
         }
       }
     }
@@ -161,7 +181,11 @@ __device__ __forceinline__ void conv_flush_tile(const float* __restrict__ Cs, in
           mx(c0 + 16 * (BN + CS_PAD));
           if (x + 1 < W) mx(c0 + 17 * (BN + CS_PAD));
         }
-        *(float4*)(gpool + ((size_t)(b * Hp + (y >> 1)) * Wp + (x >> 1)) * pool_stride + cout0 + cg * 4) = m;
+        float* pp = gpool + ((size_t)(b * Hp + (y >> 1)) * Wp + (x >> 1)) * pool_stride;
+        if (pool_split)
+          conv_store_split4(pp, cout0 + cg * 4, m);
+        else
+          *(float4*)(pp + cout0 + cg * 4) = m;
       }
     }
   }

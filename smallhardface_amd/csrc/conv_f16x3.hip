@@ -412,7 +412,7 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_kernel(ConvK p) {
     }
     __syncthreads();
     conv_flush_tile<BN, 512>(Cs, tid, ty0, tx0, H, W, b, ct * BN, gout, p.out_stride, mem.pool, p.pool_stride,
-                             !(p.relu & 8));
+                             !(p.relu & 8), (p.relu & 32) != 0, (p.relu & 64) != 0);
 #ifdef SHF_CONV_TIMING
     if (p.dbg && tid == 0 && (bid == 0 || bid == 100))
       printf("[f16x3 8w] blk%d epilogue %llu\n", bid, (unsigned long long)__builtin_amdgcn_s_memtime() - t_end8);
@@ -439,6 +439,9 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_kernel(ConvK p) {
 // (step s+1's ds_reads interleaved 1:2 with step s's MFMAs) -- the matrix pipe only idles at the stage
 // barriers.  The weight DMA for stage st+1 is issued right after the barrier of stage st (a full stage
 // of slack), the next chunk's halo tile is fetched, split and parked in registers under the last stage.
+// IN_SPLIT: the input blob is in the split-fp16 activation format (written by the producer's epilogue): the
+// halo pieces are already [hi | lo] fp16 and go to LDS as they are -- no conversion anywhere in the K loop.
+template <bool IN_SPLIT>
 __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4_kernel(ConvK p) {
   using namespace f16x3;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -491,6 +494,10 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4_kernel(ConvK p) {
   }
   // fp32 piece -> [hi half4 | lo half4] in the same four registers
   auto split_inplace = [&](float4& v, bool valid) {
+    if constexpr (IN_SPLIT) {
+      if (!valid) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      return;
+    }
 #ifdef F16X3_EXPERIMENT_NO_SPLIT  // upper bound of a pre-split activation format (WRONG results: timing only)
     const float2 h2 = make_float2(v.x, v.y), l2 = make_float2(v.z, valid ? v.w : 0.f);
 #else
@@ -510,8 +517,12 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4_kernel(ConvK p) {
     v = make_float4(x0, x1, x2, x3);
   };
   auto store_piece = [&](const float4& v, int j) {
-    *(float2*)(As + a_loff0 + j * 32 * ROWB) = make_float2(v.x, v.y);
-    *(float2*)(As + a_loff0 + j * 32 * ROWB + 64) = make_float2(v.z, v.w);
+    if constexpr (IN_SPLIT) {  // 16-B piece q of the pixel's 128 B: hi pieces 0..3, lo pieces 4..7 = row offset q * 16
+      *(float4*)(As + (tid >> 3) * ROWB + (tid & 7) * 16 + j * 32 * ROWB) = v;
+    } else {
+      *(float2*)(As + a_loff0 + j * 32 * ROWB) = make_float2(v.x, v.y);
+      *(float2*)(As + a_loff0 + j * 32 * ROWB + 64) = make_float2(v.z, v.w);
+    }
   };
   constexpr int SLAB_B = BN * ROWB;
   constexpr int PCS_SLAB = SLAB_B / 1024;
@@ -732,7 +743,7 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4_kernel(ConvK p) {
     const unsigned long long te2 = __builtin_amdgcn_s_memtime();
 #endif
     conv_flush_tile<BN, NT>(Cs, tid, ty0, tx0, H, W, b, ct * BN, gout, p.out_stride, mem.pool, p.pool_stride,
-                            !(p.relu & 8));
+                            !(p.relu & 8), (p.relu & 32) != 0, (p.relu & 64) != 0);
 #ifdef SHF_CONV_TIMING_STEPS
     const unsigned long long te3 = __builtin_amdgcn_s_memtime();
     if (wave == 0 && bid == 0 && lane == 0)
@@ -1025,7 +1036,8 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
     }
   }
   __syncthreads();
-  conv_flush_tile<BN, 512>(Cs, tid, ty0, tx0, H, W, b, 0, gout, p.out_stride, mem.pool, p.pool_stride, !(p.relu & 8));
+  conv_flush_tile<BN, 512>(Cs, tid, ty0, tx0, H, W, b, 0, gout, p.out_stride, mem.pool, p.pool_stride, !(p.relu & 8),
+                           (p.relu & 32) != 0, (p.relu & 64) != 0);
   PC_T();
 #ifdef SHF_CONV_TIMING
   if (bid == 100 && lane == 0 && (wave == 0 || wave == 4 || wave == 7))
@@ -1119,7 +1131,8 @@ static int launch_f16x3_t(const ConvArgs* as, int n, hipStream_t s) {
              (!q.pool.p || ((q.pool.cstride % 4 == 0) && (q.pool.coff % 4 == 0) && (((uintptr_t)q.pool.p & 15) == 0)));
     if (FUSE1 && !q.img) { set_error("conv f16x3: fused first layer needs the image pointer"); return -1; }
     if (q.in.C != p.Cin || q.out.C != p.Cout || q.in.cstride != p.in_stride || q.out.cstride != p.out_stride ||
-        q.wsplit16 != a.wsplit16) {
+        q.wsplit16 != a.wsplit16 || q.in_split != a.in_split || q.out_split != a.out_split ||
+        q.pool_split != a.pool_split) {
       set_error("conv group: members must share the layer");
       return -1;
     }
@@ -1136,6 +1149,10 @@ static int launch_f16x3_t(const ConvArgs* as, int n, hipStream_t s) {
     tiles += (long long)m.tiles_per_img * m.B;
   }
   if (vec_ok) p.relu |= 16;
+  if (a.out_split || a.pool_split) {
+    if (!vec_ok) { set_error("conv f16x3: split-format output needs the aligned epilogue"); return -1; }
+    p.relu |= (a.out_split ? 32 : 0) | (a.pool_split ? 64 : 0);
+  }
   // (the transposed epilogue needs 256 x (BN + 4) floats: the 1x1 variant's K-loop buffers are smaller than that)
   const size_t lds = std::max((size_t)HP * ROWB + 2 * KS * (size_t)BN * ROWB, (size_t)256 * (BN + CS_PAD) * sizeof(float)) +
                      (FUSE1 ? (3 * (TH + 4) * (TW + 4) + 27 * 64 + 64) * sizeof(float) : 0);
@@ -1154,8 +1171,15 @@ static int launch_f16x3_t(const ConvArgs* as, int n, hipStream_t s) {
     const size_t lds_pc = 2 * HPP * ROWB + 2 * 3 * (size_t)BN * ROWB + 3 * (TH + 4) * (TW + 4) * sizeof(float) + HPP;
     hipLaunchKernelGGL(conv_mfma_f16x3_pc_kernel, dim3((unsigned)tiles), dim3(512), lds_pc, s, p);
   }
-  else if (BN == 128 && !FUSE1 && DIL == 1 && KS == 3 && conv_f16x3_uses_w4(p.Cin))
-    hipLaunchKernelGGL(conv_mfma_f16x3_w4_kernel, dim3((unsigned)(tiles * p.nct)), dim3(256), lds, s, p);
+  else if (BN == 128 && !FUSE1 && DIL == 1 && KS == 3 && conv_f16x3_uses_w4(p.Cin)) {
+    if (a.in_split)
+      hipLaunchKernelGGL(conv_mfma_f16x3_w4_kernel<true>, dim3((unsigned)(tiles * p.nct)), dim3(256), lds, s, p);
+    else
+      hipLaunchKernelGGL(conv_mfma_f16x3_w4_kernel<false>, dim3((unsigned)(tiles * p.nct)), dim3(256), lds, s, p);
+  } else if (a.in_split) {
+    set_error("conv f16x3: split-format input reached a kernel other than the 4-wave one");
+    return -1;
+  }
   else
     hipLaunchKernelGGL((conv_mfma_f16x3_kernel<BN, FUSE1, DIL, KS>), dim3((unsigned)(tiles * p.nct)), dim3(512), lds, s, p);
   SHF_HIP_OK(hipGetLastError());
@@ -1193,8 +1217,10 @@ int conv_f16x3_init_attributes() {
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   SHF_HIP_OK(hipFuncSetAttribute((const void*)conv_mfma_f16x3_kernel<64, false, 4, 3>,
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  SHF_HIP_OK(hipFuncSetAttribute((const void*)conv_mfma_f16x3_w4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 160 * 1024));
+  SHF_HIP_OK(hipFuncSetAttribute((const void*)conv_mfma_f16x3_w4_kernel<false>,
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  SHF_HIP_OK(hipFuncSetAttribute((const void*)conv_mfma_f16x3_w4_kernel<true>,
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   SHF_HIP_OK(hipFuncSetAttribute((const void*)conv_mfma_f16x3_pc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                  160 * 1024));
   SHF_HIP_OK(hipFuncSetAttribute((const void*)conv_mfma_f16x3_kernel<64, false, 1, 3>,

@@ -108,6 +108,7 @@ struct Blob {
   HostBuf host;
   bool host_newer = false, dev_newer = false;
   const float* ext_dev = nullptr;  // externally bound device input (fused path)
+  bool split_fused = false;        // fused split-fp16 path: stored pre-split ([chunk][hi|lo] fp16), see ConvArgs::in_split
   size_t count() const {
     size_t c = 1;
     for (int d : shape) c *= (size_t)d;
@@ -134,12 +135,13 @@ struct Layer {
 };
 
 // the first 8 classes are the instantiations of conv_mfma_f32_kernel, named like rocprofv3 prints them
-enum ProfClass { PC_CONV_MFMA, PC_CONV_MFMA_1 = 1, PC_CONV_MFMA_7 = 7, PC_CONV_F16X3_128, PC_CONV_F16X3_W4, PC_CONV_F16X3_64, PC_CONV_F16X3_64_FUSE1, PC_CONV_F16X3_64_D2, PC_CONV_F16X3_64_D4, PC_CONV_F16X3_128_K1, PC_CONV_F16X3_64_K1, PC_CONV_F16X3_PC, PC_CONV_FIRST, PC_CONV_DIRECT, PC_POOL, PC_DECONV, PC_TAIL, PC_MERGE, PC_LAYOUT, PC_COUNT };
+enum ProfClass { PC_CONV_MFMA, PC_CONV_MFMA_1 = 1, PC_CONV_MFMA_7 = 7, PC_CONV_F16X3_128, PC_CONV_F16X3_W4, PC_CONV_F16X3_W4_SPLIT, PC_CONV_F16X3_64, PC_CONV_F16X3_64_FUSE1, PC_CONV_F16X3_64_D2, PC_CONV_F16X3_64_D4, PC_CONV_F16X3_128_K1, PC_CONV_F16X3_64_K1, PC_CONV_F16X3_PC, PC_CONV_FIRST, PC_CONV_DIRECT, PC_POOL, PC_DECONV, PC_TAIL, PC_MERGE, PC_LAYOUT, PC_COUNT };
 static const char* kProfNames[PC_COUNT] = {"conv_mfma_f32_kernel<3, 1, 128, 8, 16>", "conv_mfma_f32_kernel<3, 2, 128, 8, 16>",
                                            "conv_mfma_f32_kernel<3, 4, 128, 8, 16>", "conv_mfma_f32_kernel<3, 1, 64, 16, 16>",
                                            "conv_mfma_f32_kernel<3, 2, 64, 16, 16>", "conv_mfma_f32_kernel<3, 4, 64, 16, 16>",
                                            "conv_mfma_f32_kernel<1, 0, 128, 8, 16>", "conv_mfma_f32_kernel<1, 0, 64, 16, 16>",
-                                           "conv_mfma_f16x3_kernel<128, false, 1, 3>", "conv_mfma_f16x3_w4_kernel",
+                                           "conv_mfma_f16x3_kernel<128, false, 1, 3>", "conv_mfma_f16x3_w4_kernel<false>",
+                                           "conv_mfma_f16x3_w4_kernel<true>",
                                            "conv_mfma_f16x3_kernel<64, false, 1, 3>",
                                            "conv_mfma_f16x3_kernel<64, true, 1, 3>", "conv_mfma_f16x3_kernel<64, false, 2, 3>",
                                            "conv_mfma_f16x3_kernel<64, false, 4, 3>", "conv_mfma_f16x3_kernel<128, false, 1, 1>",
@@ -190,7 +192,7 @@ static int f16x3_prof_class(const ConvArgs& a, int nout) {  // which split-fp16 
   if (a.dil == 2) return PC_CONV_F16X3_64_D2;
   if (a.dil == 4) return PC_CONV_F16X3_64_D4;
   if (nout % 128) return PC_CONV_F16X3_64;
-  return conv_f16x3_uses_w4(a.in.C) ? PC_CONV_F16X3_W4 : PC_CONV_F16X3_128;
+  return conv_f16x3_uses_w4(a.in.C) ? (a.in_split ? PC_CONV_F16X3_W4_SPLIT : PC_CONV_F16X3_W4) : PC_CONV_F16X3_128;
 }
 
 static int conv_prof_class(int k, int dil, int nout) {
@@ -785,6 +787,47 @@ void shf_net::build(const std::string& text, const char* caffemodel) {
     N.first_src = (int)li;
     F.first_dst = next;
   }
+  // ---- blobs the fused split-fp16 path keeps in the pre-split activation format: produced by a split-fp16 conv
+  //      (or by the pool fused into its epilogue) and read ONLY by convs that run on the 4-wave kernel
+  {
+    static const bool split_act = !(getenv("SHF_F16X3_SPLIT_ACT") && atoi(getenv("SHF_F16X3_SPLIT_ACT")) == 0);
+    auto w4_reader = [&](const Layer& Q, int cin) {
+      return Q.op == OP_CONV && Q.kclass == 0 && Q.k == 3 && Q.dil == 1 && Q.pad == 1 && cin % 32 == 0 && Q.nout % 128 == 0 &&
+             Q.first_src < 0 && conv_f16x3_uses_w4(cin) && conv_f16x3_eligible(cin, Q.nout, Q.k, Q.pad, Q.dil);
+    };
+    for (size_t bi = 0; bi < blobs.size() && split_act; ++bi) {
+      Blob& B = blobs[bi];
+      if (B.owner >= 0 || B.kind != BK_NHWC || B.shape.size() != 4) continue;
+      if (std::count(tail_feat_blobs.begin(), tail_feat_blobs.end(), (int)bi)) continue;
+      bool concat_member = false;
+      for (auto& O : blobs) concat_member = concat_member || O.owner == (int)bi;
+      if (concat_member) continue;
+      // producer: a kclass-0 conv eligible for a split-fp16 kernel, directly or through its fused pool
+      int prod = -1;
+      for (size_t lj = 0; lj < layers.size(); ++lj) {
+        Layer& Q = layers[lj];
+        if (Q.op == OP_CONV && Q.kclass == 0 && !Q.tops.empty() && Q.tops[0] == (int)bi) prod = (int)lj;
+        if (Q.op == OP_POOL && Q.fused_into >= 0 && !Q.tops.empty() && Q.tops[0] == (int)bi) prod = Q.fused_into;
+      }
+      if (prod < 0) continue;
+      const Layer& Pq = layers[prod];
+      const int pcin = blobs[Pq.bottoms[0]].shape.size() == 4 ? blobs[Pq.bottoms[0]].shape[1] : 0;
+      if (!conv_f16x3_eligible(Pq.first_src >= 0 ? 64 : pcin, Pq.nout, Pq.k, Pq.pad, Pq.dil)) continue;
+      int readers = 0;
+      bool all_w4 = true;
+      for (size_t lj = 0; lj < layers.size(); ++lj) {
+        Layer& Q = layers[lj];
+        if (Q.op == OP_SKIP && Q.type == "ReLU") continue;                       // in-place, part of the conv
+        if (Q.op == OP_POOL && Q.fused_into >= 0 && Q.bottoms[0] == (int)bi) continue;  // folded into the producer
+        for (int bb : Q.bottoms)
+          if (bb == (int)bi) {
+            ++readers;
+            all_w4 = all_w4 && w4_reader(Q, B.shape[1]);
+          }
+      }
+      B.split_fused = readers > 0 && all_w4;
+    }
+  }
   alloc_buffers();
   if (clone_src) {
     wgen = clone_src->wgen;
@@ -1011,6 +1054,11 @@ void shf_net::forward_ops(bool fused_path, float im_h, float im_w, float im_scal
         if (fused_path && L.fuse_pool >= 0) {
           a.pool = view_of(layers[L.fuse_pool].tops[0]);
           a.write_main = L.pool_only ? 0 : 1;
+          a.pool_split = split16 && blobs[layers[L.fuse_pool].tops[0]].split_fused;
+        }
+        if (fused_path && split16) {
+          a.in_split = ib.split_fused;
+          a.out_split = blobs[L.tops[0]].split_fused;
         }
         if (fused_path && split16 && L.first_src >= 0) {
           Layer& F = layers[L.first_src];

@@ -40,6 +40,10 @@ struct ConvArgs {
   const float* b1 = nullptr;
   View pool;           // optional fused MAX 2x2/2 pool output (p == nullptr: none)
   int write_main = 1;  // 0: the un-pooled output has no other reader and is not written
+  // split-fp16 activation format (fused path, conv_f16x3.hip): a blob whose only readers are 4-wave split-fp16
+  // convs is stored as [pixel][32-channel chunk][hi 32 halfs | lo 32 halfs] -- the same 4 B per element, already
+  // split, so the consumer's halo staging is a plain copy
+  int in_split = 0, out_split = 0, pool_split = 0;
 };
 // which kernel class a conv will use: 0 = mfma implicit GEMM, 1 = first-layer direct (NCHW in), 2 = generic direct
 int conv_kernel_class(int Cin, int Cout, int k, int pad, int dil, bool in_nchw);
