@@ -430,3 +430,48 @@ def test_device_preprocessing_feeds_the_detector():
         got = fd.detect(dp.units(im), thresh=0.05, on_device=True)[0]
         assert len(ref) > 0
         np.testing.assert_array_equal(got, ref)
+
+
+def test_kernel_selection_knobs_do_not_change_results(tmp_path, conv_mode):
+    """Every kernel-selection / data-format knob of the split-fp16 path is a pure performance choice: the
+    detections of the fused path are bit-identical with the 4-wave kernel, the producer/consumer first pair,
+    the split activation format and the logits-first tail schedule switched off one at a time... except the
+    first pair, whose conv1_1 runs on the matrix cores instead of the vector ALUs (tolerance)."""
+    if conv_mode != "f16x3":
+        pytest.skip("split-fp16 knobs")
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "run.py"
+    script.write_text('''
+import sys, numpy as np
+from smallhardface_amd.config import cfg
+from smallhardface_amd import test as T
+from tests import helpers as H
+cfg.MODEL.DIFFERENT_DILATION.ENABLE = True
+cfg.TEST.SCALES = [100, 300, 500]
+gnet, _ = H.make_pair(H.detector_msg(True), cls_bias=1.0)
+gnet.set_conv_mode("f16x3")
+im = np.random.default_rng(5).integers(0, 256, (150, 200, 3)).astype(np.uint8)
+fd = T.FusedDetector(gnet, n_lanes=6, mode="group")
+np.save(sys.argv[1], fd.detect(list(T.pyramid_units(im)), thresh=0.05)[0])
+''')
+    outs = {}
+    for name, env in (("default", {}), ("no_split_act", {"SHF_F16X3_SPLIT_ACT": "0"}), ("no_w4", {"SHF_F16X3_W4": "0"}),
+                      ("scalar_epilogue", {"SHF_CONV_SCALAR_EPILOGUE": "1", "SHF_F16X3_SPLIT_ACT": "0"}),
+                      ("no_pc", {"SHF_F16X3_PC": "0"})):
+        out = str(tmp_path / (name + ".npy"))
+        e = dict(os.environ, PYTHONPATH=root, **env)
+        r = subprocess.run([sys.executable, str(script), out], env=e, cwd=root, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (name, r.stderr[-1500:])
+        outs[name] = np.load(out)
+    assert len(outs["default"]) > 0
+    # (the scalar epilogue also rules the producer/consumer first pair out: its twin is "no_pc")
+    bad = [(name, ref) for name, ref in (("no_split_act", "default"), ("no_w4", "default"), ("scalar_epilogue", "no_pc"))
+           if outs[name].shape != outs[ref].shape or not np.array_equal(outs[name], outs[ref])]
+    assert not bad, bad
+    a, b = outs["default"], outs["no_pc"]
+    assert abs(len(a) - len(b)) <= 2
+    n = min(len(a), len(b))
+    assert np.abs(a[:n, 4] - b[:n, 4]).max() < SCORE_TOL and np.abs(a[:n, :4] - b[:n, :4]).max() < 0.05
