@@ -109,6 +109,30 @@ __device__ __forceinline__ void conv_stage_tile(float* __restrict__ Cs, GetV get
   }
 }
 
+// The same for the split-fp16 kernels' accumulator pair (out = main + corr * inv + bias), two pixels per
+// instruction: registers r, r+1 of a lane are x-adjacent pixels, so v_pk_fma / v_pk_add / v_pk_max do the
+// arithmetic and one ds_write2_b32 parks the pair (2.5 instead of 6.5 VALU ops per value).
+typedef float cs_f32x2 __attribute__((ext_vector_type(2)));
+typedef float cs_f32x16 __attribute__((ext_vector_type(16)));
+template <int BN, bool RELU>
+__device__ __forceinline__ void conv_stage_tile_pk(float* __restrict__ Cs, const cs_f32x16 am, const cs_f32x16 ac,
+                                                   float inv, float bv, int ly0, int kh, int cl) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int lx = 2 * (2 * q + kh);
+#pragma unroll
+    for (int sp = 0; sp < 4; sp += 2) {
+      const int r = 4 * q + sp;
+      cs_f32x2 v = __builtin_elementwise_fma(cs_f32x2{ac[r], ac[r + 1]}, cs_f32x2{inv, inv}, cs_f32x2{am[r], am[r + 1]});
+      v = v + cs_f32x2{bv, bv};
+      if (RELU) v = __builtin_elementwise_max(v, cs_f32x2{0.f, 0.f});
+      float* d = Cs + ((ly0 + (sp >> 1)) * 16 + lx) * (BN + CS_PAD) + cl;
+      d[0] = v[0];
+      d[BN + CS_PAD] = v[1];
+    }
+  }
+}
+
 // write the staged tile (and its 2x2/2 max-pool) to global memory; all NT threads of the block.
 // A block-wide store covers PPI = NT / (BN/4) pixels; the walk over the 256 pixels is fully unrolled
 // with compile-time (row, column) steps so that an iteration is one LDS read, one predicate and one

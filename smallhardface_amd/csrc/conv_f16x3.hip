@@ -406,8 +406,10 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_kernel(ConvK p) {
       const float bv = p.bias ? p.bias[ct * BN + cl] : 0.f;
 #pragma unroll
       for (int tm = 0; tm < MT; ++tm) {
-        const f32x16 am = accm[tm][tn], ac = accc[tm][tn];
-        conv_stage_tile<BN>(Cs, [&](int r) { return am[r] + ac[r] * LO_INV; }, bv, p.relu, wm * 2 * MT + tm * 2, kh, cl);
+        if (p.relu & 1)
+          conv_stage_tile_pk<BN, true>(Cs, accm[tm][tn], accc[tm][tn], LO_INV, bv, wm * 2 * MT + tm * 2, kh, cl);
+        else
+          conv_stage_tile_pk<BN, false>(Cs, accm[tm][tn], accc[tm][tn], LO_INV, bv, wm * 2 * MT + tm * 2, kh, cl);
       }
     }
     __syncthreads();
@@ -731,8 +733,10 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4_kernel(ConvK p) {
       const float bv = p.bias ? p.bias[ct * BN + cl] : 0.f;
 #pragma unroll
       for (int tm = 0; tm < MT; ++tm) {
-        const f32x16 am = accm[tm][tn], ac = accc[tm][tn];
-        conv_stage_tile<BN>(Cs, [&](int r) { return am[r] + ac[r] * LO_INV; }, bv, p.relu, wm * 2 * MT + tm * 2, kh, cl);
+        if (p.relu & 1)
+          conv_stage_tile_pk<BN, true>(Cs, accm[tm][tn], accc[tm][tn], LO_INV, bv, wm * 2 * MT + tm * 2, kh, cl);
+        else
+          conv_stage_tile_pk<BN, false>(Cs, accm[tm][tn], accc[tm][tn], LO_INV, bv, wm * 2 * MT + tm * 2, kh, cl);
       }
     }
 #ifdef SHF_CONV_TIMING_STEPS
@@ -1030,8 +1034,10 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
       const float bv = p.bias ? p.bias[cl] : 0.f;
 #pragma unroll
       for (int tm = 0; tm < MT; ++tm) {
-        const f32x16 am = accm[tm][tn], ac = accc[tm][tn];
-        conv_stage_tile<BN>(Cs, [&](int r) { return am[r] + ac[r] * LO_INV; }, bv, p.relu, wm * 2 * MT + tm * 2, kh, cl);
+        if (p.relu & 1)
+          conv_stage_tile_pk<BN, true>(Cs, accm[tm][tn], accc[tm][tn], LO_INV, bv, wm * 2 * MT + tm * 2, kh, cl);
+        else
+          conv_stage_tile_pk<BN, false>(Cs, accm[tm][tn], accc[tm][tn], LO_INV, bv, wm * 2 * MT + tm * 2, kh, cl);
       }
     }
   }
