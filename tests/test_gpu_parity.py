@@ -475,3 +475,45 @@ np.save(sys.argv[1], fd.detect(list(T.pyramid_units(im)), thresh=0.05)[0])
     assert abs(len(a) - len(b)) <= 2
     n = min(len(a), len(b))
     assert np.abs(a[:n, 4] - b[:n, 4]).max() < SCORE_TOL and np.abs(a[:n, :4] - b[:n, :4]).max() < 0.05
+
+
+def test_full_bench_pyramid_properties(conv_mode):
+    """BASELINE's full-size workload (1024x1024 source, scales 100..1400 x flip = 10 units, 5 TFLOP) through the
+    fused path: size-independent properties instead of an oracle run -- determinism (twice, and pipelined vs one
+    at a time, and from the raw uint8 image through the device pyramid), score order and range, boxes inside the
+    image, and idempotence of the merge (voting the voted boxes again changes nothing but exact duplicates)."""
+    if conv_mode != "f16x3":
+        pytest.skip("full-size run once, in the benchmarked arithmetic")
+    from smallhardface_amd import caffe, nms, test as T, weights
+    from smallhardface_amd.config import cfg_from_file
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg_from_file(os.path.join(root, "configs", "smallhardface.toml"))
+    msg = P._add_dimension_reduction(P.build_test_template(True))
+    net = caffe.Net(None, prototxt_text=P.dumps(msg))
+    H.load_params(net, weights.synth_params(msg, seed=1234))
+    net.set_conv_mode("f16x3")
+    im = np.random.default_rng(1000).integers(0, 256, (1024, 1024, 3)).astype(np.uint8)
+    units = list(T.pyramid_units(im))
+    assert len(units) == 10 and max(u[1] for u in units) == 1408
+    fd = T.FusedDetector(net, n_lanes=10, mode="group")
+    a = fd.detect(units, thresh=0.05)[0]
+    b = fd.detect(units, thresh=0.05)[0]
+    np.testing.assert_array_equal(a, b)
+    dp = T.DevicePyramid(net)
+    got = []
+    for _ in range(3):
+        fd.submit(dp.units(im, net=fd.next_head()), thresh=0.05, on_device=True)
+        if fd.pending() > 1:
+            got.append(fd.collect()[0])
+    while fd.pending():
+        got.append(fd.collect()[0])
+    for g in got:
+        np.testing.assert_array_equal(g, a)
+    assert len(a) > 0 and a.shape[1] == 5
+    assert np.all(a[:, 4] > 0.05) and np.all(a[:, 4] <= 1.0)
+    assert np.all(np.diff(a[:, 4]) <= 0)                       # bbox_vote emits clusters by falling head score
+    assert np.all(a[:, 0] <= a[:, 2]) and np.all(a[:, 1] <= a[:, 3])
+    assert a[:, :4].min() >= -1e-3 and a[:, [0, 2]].max() <= 1024 and a[:, [1, 3]].max() <= 1024
+    again = nms.bbox_vote(a.astype(np.float32), cfg.TEST.NMS_THRESH)
+    assert len(again) <= len(a) and np.all(np.diff(again[:, 4]) <= 0)
