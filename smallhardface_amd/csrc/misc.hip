@@ -55,39 +55,37 @@ int launch_maxpool(const View& in, const View& out, int k, int stride, int pad, 
 
 // out[b,y,x,c] = sum_{a,bb} in[b,(y+pad-a)/s,(x+pad-bb)/s,c] * w[c,a,bb] over taps whose
 // source index is integral and in range (col2im accumulation order a-major, like im2col.cpp:168-185).
+// Grid: x over (ox, channel quad) of one output row, y = output row, z = batch -- 32-bit index math only (the
+// flat 64-bit div/mod chain of a grid-stride loop cost more than the memory traffic).
 __global__ void deconv_dw_kernel(const float* __restrict__ in, const float* __restrict__ w,
                                  const float* __restrict__ bias, float* __restrict__ out, int B, int H, int W, int C,
                                  int Ho, int Wo, int k, int stride, int pad, int in_stride, int out_stride) {
-  const int C4 = C >> 2;
-  const long long total = (long long)B * Ho * Wo * C4;
-  for (long long n = (long long)blockIdx.x * blockDim.x + threadIdx.x; n < total;
-       n += (long long)gridDim.x * blockDim.x) {
-    const int c4 = (int)(n % C4);
-    long long P = n / C4;
-    const int ox = (int)(P % Wo), oy = (int)((P / Wo) % Ho), b = (int)(P / ((long long)Wo * Ho));
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    // only the taps a = (oy+pad) mod stride, +stride, ... hit an integral source row (same for columns): walk
-    // exactly those, in the same ascending (a, bb) order as the full k x k scan
-    for (int a = (oy + pad) % stride; a < k; a += stride) {
-      const int ty = oy + pad - a;
-      if (ty < 0) break;
-      const int iy = ty / stride;
-      if (iy >= H) continue;
-      for (int bb = (ox + pad) % stride; bb < k; bb += stride) {
-        const int tx = ox + pad - bb;
-        if (tx < 0) break;
-        const int ix = tx / stride;
-        if (ix >= W) continue;
-        const float4 v = *(const float4*)(in + ((size_t)(b * H + iy) * W + ix) * in_stride + c4 * 4);
-        const float vv[4] = {v.x, v.y, v.z, v.w};
+  const unsigned C4 = (unsigned)C >> 2;
+  const unsigned n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= (unsigned)Wo * C4) return;
+  const int c4 = (int)(n % C4), ox = (int)(n / C4), oy = blockIdx.y, b = blockIdx.z;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  // only the taps a = (oy+pad) mod stride, +stride, ... hit an integral source row (same for columns): walk
+  // exactly those, in the same ascending (a, bb) order as the full k x k scan
+  for (int a = (oy + pad) % stride; a < k; a += stride) {
+    const int ty = oy + pad - a;
+    if (ty < 0) break;
+    const int iy = ty / stride;
+    if (iy >= H) continue;
+    for (int bb = (ox + pad) % stride; bb < k; bb += stride) {
+      const int tx = ox + pad - bb;
+      if (tx < 0) break;
+      const int ix = tx / stride;
+      if (ix >= W) continue;
+      const float4 v = *(const float4*)(in + ((size_t)(b * H + iy) * W + ix) * in_stride + c4 * 4);
+      const float vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[j] = fmaf(vv[j], w[((size_t)(c4 * 4 + j) * k + a) * k + bb], acc[j]);
-      }
+      for (int j = 0; j < 4; ++j) acc[j] = fmaf(vv[j], w[((size_t)(c4 * 4 + j) * k + a) * k + bb], acc[j]);
     }
-    if (bias)
-      for (int j = 0; j < 4; ++j) acc[j] += bias[c4 * 4 + j];
-    *(float4*)(out + (size_t)P * out_stride + c4 * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
   }
+  if (bias)
+    for (int j = 0; j < 4; ++j) acc[j] += bias[c4 * 4 + j];
+  *(float4*)(out + ((size_t)(b * Ho + oy) * Wo + ox) * out_stride + c4 * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
 }
 
 int launch_deconv_depthwise(const View& in, const View& out, const float* w, const float* bias, int k, int stride,
@@ -96,9 +94,9 @@ int launch_deconv_depthwise(const View& in, const View& out, const float* w, con
     set_error("deconv: channel count / views must be multiples of 4");
     return -1;
   }
-  const long long total = (long long)out.B * out.H * out.W * (in.C / 4);
-  hipLaunchKernelGGL(deconv_dw_kernel, dim3(grid_for(total)), dim3(256), 0, s, in.p + in.coff, w, bias,
-                     out.p + out.coff, in.B, in.H, in.W, in.C, out.H, out.W, k, stride, pad, in.cstride,
+  const unsigned per_row = (unsigned)out.W * (unsigned)(in.C / 4);
+  hipLaunchKernelGGL(deconv_dw_kernel, dim3((per_row + 255) / 256, out.H, out.B), dim3(256), 0, s, in.p + in.coff, w,
+                     bias, out.p + out.coff, in.B, in.H, in.W, in.C, out.H, out.W, k, stride, pad, in.cstride,
                      out.cstride);
   SHF_HIP_OK(hipGetLastError());
   return 0;
