@@ -533,23 +533,30 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4_kernel(ConvK p) {
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   // rounds [j0, j0+n) of the weight DMA for `stage` into buffer `buf`; branch-free so that it can sit
   // inside the MFMA scheduling region
+  // Round j = 5 sl + i moves piece (wave + 4 i) of slab sl: the slab and the multiple of 4 KiB are compile-time,
+  // the wave's own KiB sits in two per-wave scalar bases, so a round is a couple of scalar adds, the M0 write
+  // and the DMA itself (scalar base + lane * 16 as the vector offset).  Waves 2, 3 have no fifth piece in a slab
+  // of 18: they repeat piece 17.
+  constexpr int DMA_ROUNDS_W4 = 15;
+  const unsigned lane16 = (unsigned)lane * 16u;
+  const int last_piece = wave_u + 16 < PCS_SLAB ? wave_u + 16 : PCS_SLAB - 1;
   auto dma_w = [&](int stage, int buf, int j0, int n) {
     const unsigned char* ws_ = (const unsigned char*)(wbase + (size_t)stage * 3 * slab);
     unsigned char* bd_ = Bs + buf * (3 * SLAB_B);
 #pragma unroll
     for (int j = j0; j < j0 + n; ++j) {
-      int pc = wave_u + 4 * j;
-      if (4 * j + 3 >= PCS) pc = pc < PCS ? pc : PCS - 1;
-      const int sl = pc / PCS_SLAB, within = pc - sl * PCS_SLAB;
-      const unsigned char* src = ws_ + (size_t)sl * slab * 2 + within * 1024 + lane * 16;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(bd_ + pc * 1024), 16, 0, 0);
+      const int sl = j / 5, i5 = j % 5;
+      const int within = i5 < 4 ? wave_u + 4 * i5 : last_piece;
+      const unsigned char* ub = ws_ + (size_t)sl * slab * 2 + within * 1024;   // wave-uniform
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ub + lane16),
+                                       (__attribute__((address_space(3))) void*)(bd_ + sl * SLAB_B + within * 1024), 16, 0,
+                                       0);
     }
   };
   // prologue: W(0) by DMA and the halo tile of chunk 0 are requested first; the accumulator clearing and
   // the fragment geometry fill the wait
   float4 areg0[ALD];
-  dma_w(0, 0, 0, DMA_ROUNDS);
+  dma_w(0, 0, 0, DMA_ROUNDS_W4);
 #pragma unroll
   for (int j = 0; j < ALD; ++j) areg0[j] = *(const float4*)(gin + a_gsafe[j]);
 
@@ -626,8 +633,10 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4_kernel(ConvK p) {
       half8* bf = fb[s_ & 1];
       if (s_ + 1 < 6) load_frag(s_ + 1, fa[(s_ + 1) & 1], fb[(s_ + 1) & 1]);
       // the stage's side jobs ride under the MFMAs, a few per k-step so that no queue ever fills
-      constexpr int DMA_J0[6] = {0, 3, 6, 9, 12, 14}, DMA_N[6] = {3, 3, 3, 3, 2, 0};
+      constexpr int DMA_J0[6] = {0, 3, 6, 9, 12, 15}, DMA_N[6] = {3, 3, 3, 3, 3, 0};
+#ifndef F16X3_EXPERIMENT_NO_DMA  // timing experiment only (stale weights): what the in-loop DMA issue costs
       if (DMA_N[s_]) dma_w(st_next, buf_next, DMA_J0[s_], DMA_N[s_]);
+#endif
       int n_vmem = DMA_N[s_];
 #if F16X3_W4_PREFETCH
       if constexpr (PREFETCH) {  // a whole stage of slack before the first use
