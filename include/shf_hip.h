@@ -177,6 +177,21 @@ int shf_caffemodel_read_blob(const char* path, const char* layer, int idx, float
 int shf_debug_merge(const float* dets5, int n, float thresh, int ge_pred, unsigned long long* mask_out,
                     int* cluster_out, int* heads_out, int* n_heads, float* sorted_out, int* perm_out);
 
+/* The proposal stage alone -- tail decode -> candidate select -> sort -> gather -- on INJECTED blobs, so the
+ * reference's own ProposalLayer.forward vectors (lib/layers/proposal_layer.py:60-220, incl. the
+ * np.seterr(over='raise') clamp branch of lib/utils/bbox_transform.py:52-65) reach the HIP kernels: scores =
+ * cls_prob_reshape_output (1,2A,h,w), deltas = bbox_pred_output (1,4A,h,w), im_info3 = (h, w, scale), all host
+ * fp32.  Anchors and cfg.TEST.* come from `net` (any net holding the proposal layer).  out_boxes5 (cap,5) /
+ * out_probs2 (cap,2) receive the layer's tops: *n_out = R rows (when R == 0 out_boxes5 holds the dummy roi);
+ * *overflow != 0 when the clamp branch was taken. */
+int shf_debug_proposal(shf_net* net, const float* scores, const float* deltas, int h, int w, const float* im_info3,
+                       float* out_boxes5, float* out_probs2, int cap, int* n_out, int* overflow);
+/* forward_net's flip fix + unscale (lib/test.py:52-54,59-66) and detect()'s > thresh cut (:163-167) on injected
+ * proposals boxes5 (R,5) / probs2 (R,2) (host, score-descending like the layer emits them): appended to the
+ * current image's device list as one more unit (after shf_detect_begin; read back with shf_detect_export). */
+int shf_debug_append(shf_net* net, const float* boxes5, const float* probs2, int R, int im_w, float im_scale,
+                     int flip, float thresh);
+
 /* ---- measurement ------------------------------------------------------------- */
 /* Per-kernel-class HIP-event timing on the net's stream.  enable!=0 starts recording
  * an event pair around every launch; shf_prof_read drains them (synchronises) and

@@ -100,6 +100,8 @@ def _declare(lib):
         "shf_detect_import": (ci, [vp, vp, ci]),
         "shf_detect_export_many": (ci, [vp, ci, C.POINTER(vp), C.POINTER(vp), ci, ip]),
         "shf_debug_merge": (ci, [vp, ci, cf, ci, vp, vp, vp, ip, vp, vp]),
+        "shf_debug_proposal": (ci, [vp, fp, fp, ci, ci, fp, fp, fp, ci, ip, ip]),
+        "shf_debug_append": (ci, [vp, fp, fp, ci, ci, cf, ci, cf]),
         "shf_caffemodel_read_blob": (ci, [C.c_char_p, C.c_char_p, ci, fp, ci, ip, ip]),
         "shf_nms": (ci, [fp, ci, cf, ci, C.POINTER(C.c_int32), ip]),
         "shf_bbox_vote": (ci, [fp, ci, cf, dp, ci, ip]),

@@ -324,6 +324,35 @@ class Net(object):
     def detect_import(self, src_ptr, n_rows):
         _lib.check(self._lib.shf_detect_import(self._h, C.c_void_p(int(src_ptr)), int(n_rows)), "detect_import")
 
+    # -- diagnostics (tests) -----------------------------------------------------------
+    def debug_proposal(self, scores, deltas, im_info):
+        """ProposalLayer.forward on injected blobs through the HIP tail (C ABI shf_debug_proposal):
+        scores (1,2A,h,w), deltas (1,4A,h,w), im_info (1,3) -> (boxes (max(R,1),5), probs (R,2), overflow flag)."""
+        sc = np.ascontiguousarray(scores, dtype=np.float32)
+        dl = np.ascontiguousarray(deltas, dtype=np.float32)
+        ii = np.ascontiguousarray(im_info, dtype=np.float32).reshape(-1)
+        h, w = sc.shape[2:]
+        A = sc.shape[1] // 2
+        assert dl.shape == (1, 4 * A, h, w), dl.shape
+        cap = h * w * A
+        boxes = np.zeros((cap, 5), np.float32)
+        probs = np.zeros((cap, 2), np.float32)
+        n, of = C.c_int(0), C.c_int(0)
+        F = C.POINTER(C.c_float)
+        _lib.check(self._lib.shf_debug_proposal(self._h, sc.ctypes.data_as(F), dl.ctypes.data_as(F), h, w,
+                                                ii.ctypes.data_as(F), boxes.ctypes.data_as(F), probs.ctypes.data_as(F),
+                                                cap, C.byref(n), C.byref(of)), "debug_proposal")
+        return boxes[:max(n.value, 1)].copy(), probs[:n.value].copy(), bool(of.value)
+
+    def debug_append(self, boxes5, probs2, im_w, im_scale, flip, thresh):
+        """forward_net's flip fix / unscale + the > thresh cut on injected proposals (C ABI shf_debug_append)."""
+        b = np.ascontiguousarray(boxes5, dtype=np.float32).reshape(-1, 5)
+        p = np.ascontiguousarray(probs2, dtype=np.float32).reshape(-1, 2)
+        assert len(b) == len(p)
+        F = C.POINTER(C.c_float)
+        _lib.check(self._lib.shf_debug_append(self._h, b.ctypes.data_as(F), p.ctypes.data_as(F), len(b), int(im_w),
+                                              float(im_scale), 1 if flip else 0, float(thresh)), "debug_append")
+
     def detect_finish(self, method="BBOX_VOTE", nms_thresh=0.4, cap=None):
         m = {"BBOX_VOTE": 0, "NMS": 1}[method]
         cap = cap or 4096

@@ -1828,6 +1828,95 @@ int shf_debug_merge(const float* dets5, int n, float thresh, int ge_pred, unsign
   API_END(-1)
 }
 
+// diagnostics: the proposal stage alone on injected blobs (tests only)
+int shf_debug_proposal(shf_net* net, const float* scores, const float* deltas, int h, int w, const float* im_info3,
+                       float* out_boxes5, float* out_probs2, int cap, int* n_out, int* overflow) {
+  API_BEGIN
+  if (net->tail_layer < 0) throw std::runtime_error("net has no proposal layer");
+  if (h < 1 || w < 1) throw std::runtime_error("debug_proposal: bad map size");
+  // size the tail workspace / output blobs for an (h, w) head map: reshape 'data' to the matching level
+  Blob& d = net->blobs[net->data_blob];
+  d.shape = {1, d.shape.size() == 4 ? d.shape[1] : 3, h * net->feat_stride, w * net->feat_stride};
+  net->infer_shapes();
+  net->alloc_buffers();
+  Blob& f = net->blobs[net->tail_feat_blobs[0]];
+  if (f.shape[2] != h || f.shape[3] != w) throw std::runtime_error("debug_proposal: head map does not come out (h, w)");
+  const int A = net->tail_A;
+  const size_t K = (size_t)h * w;
+  DevBuf ds, dd;
+  ds.ensure(K * 2 * A * 4);
+  dd.ensure(K * 4 * A * 4);
+  hipStream_t st = net->stream;
+  HIP_THROW(hipMemcpyAsync(ds.p, scores, K * 2 * A * 4, hipMemcpyHostToDevice, st));
+  HIP_THROW(hipMemcpyAsync(dd.p, deltas, K * 4 * A * 4, hipMemcpyHostToDevice, st));
+  TailArgs t;
+  t.A = A; t.heads = net->tail_heads; t.Cf = net->tail_Cf;
+  t.h = h; t.w = w;
+  for (int i = 0; i < A * 4; ++i) t.anchors[i] = (float)net->anchors[i];
+  for (int i = 0; i < A; ++i) t.sub_stride[i] = net->sub_stride[i];
+  t.feat_stride = net->feat_stride;
+  t.im_h = im_info3[0]; t.im_w = im_info3[1]; t.im_scale = im_info3[2];
+  t.min_size = net->min_size; t.score_thresh = net->score_thresh; t.pre_nms_topN = net->pre_nms_topN;
+  t.probs_given = 1;
+  float* boxes = (float*)net->blobs[net->boxes_blob].dev.p;
+  float* probs = net->prob_blob >= 0 ? (float*)net->blobs[net->prob_blob].dev.p : (float*)net->tw_rec.p;
+  CHECK_RC(launch_tail_inject(t, net->tw, (const float*)ds.p, (const float*)dd.p, st));
+  CHECK_RC(launch_tail(t, net->tw, boxes, probs, st, nullptr, 2));
+  int cnt[8];
+  HIP_THROW(hipMemcpyAsync(cnt, net->tw.counters, sizeof(cnt), hipMemcpyDeviceToHost, st));
+  HIP_THROW(hipStreamSynchronize(st));
+  const int R = cnt[2];
+  if (overflow) *overflow = cnt[1];
+  // ProposalLayer's tops: (max(R,1), 5) with the dummy roi when R == 0, and (R, 2)   proposal_layer.py:207-220
+  const int rows_b = std::max(R, 1);
+  if (n_out) *n_out = R;
+  HIP_THROW(hipMemcpy(out_boxes5, boxes, (size_t)std::min(rows_b, cap) * 5 * 4, hipMemcpyDeviceToHost));
+  if (R > 0) HIP_THROW(hipMemcpy(out_probs2, probs, (size_t)std::min(R, cap) * 2 * 4, hipMemcpyDeviceToHost));
+  net->blobs[net->boxes_blob].shape = {rows_b, 5};
+  if (net->prob_blob >= 0) net->blobs[net->prob_blob].shape = {R, 2};
+  return 0;
+  API_END(-1)
+}
+
+// diagnostics: forward_net's flip fix + unscale and detect()'s >thresh cut (append_dets_kernel) on injected
+// proposals, appended to the current image's list (shf_detect_begin first; export with shf_detect_export)
+int shf_debug_append(shf_net* net, const float* boxes5, const float* probs2, int R, int im_w, float im_scale,
+                     int flip, float thresh) {
+  API_BEGIN
+  if (net->tail_layer < 0) throw std::runtime_error("net has no proposal layer");
+  if (R < 0) throw std::runtime_error("debug_append: R < 0");
+  net->tw_counters.ensure(64);
+  net->tw.counters = (int*)net->tw_counters.p;
+  Blob& bb = net->blobs[net->boxes_blob];
+  bb.dev.ensure((size_t)std::max(R, 1) * 5 * 4);
+  float* probs;
+  if (net->prob_blob >= 0) {
+    net->blobs[net->prob_blob].dev.ensure((size_t)std::max(R, 1) * 2 * 4);
+    probs = (float*)net->blobs[net->prob_blob].dev.p;
+  } else {
+    net->tw_rec.ensure((size_t)std::max(R, 1) * 2 * 4);
+    probs = (float*)net->tw_rec.p;
+  }
+  hipStream_t st = net->stream;
+  if (R > 0) {
+    HIP_THROW(hipMemcpyAsync(bb.dev.p, boxes5, (size_t)R * 5 * 4, hipMemcpyHostToDevice, st));
+    HIP_THROW(hipMemcpyAsync(probs, probs2, (size_t)R * 2 * 4, hipMemcpyHostToDevice, st));
+  }
+  HIP_THROW(hipMemcpyAsync(net->tw.counters + 2, &R, 4, hipMemcpyHostToDevice, st));
+  HIP_THROW(hipStreamSynchronize(st));
+  const int saved = net->pre_nms_topN;
+  net->pre_nms_topN = std::max(R, 1);  // append_unit sizes its launch and the list growth from it
+  try {
+    append_unit(net, net, im_w, im_scale, flip, thresh);
+  } catch (...) {
+    net->pre_nms_topN = saved;
+    throw;
+  }
+  net->pre_nms_topN = saved;
+  return 0;
+  API_END(-1)
+}
+
 int shf_generate_anchors(int base_size, const double* ratios, int n_ratios, const double* scales, int n_scales,
                          const double* shifts, int n_shifts, const double* strides, double* out, int cap_rows) {
   API_BEGIN

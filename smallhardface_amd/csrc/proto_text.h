@@ -296,6 +296,20 @@ inline std::vector<WireLayer> read_caffemodel(const std::string& path) {
         else lr.skip(w2);
       }
       out.push_back(std::move(L));
+    } else if (fno == 2 && wt == 2) {
+      // legacy V1LayerParameter (NetParameter.layers = 2: name=4, type=5 enum, blobs=6; caffe.proto:1247-1290),
+      // what UpgradeV1Net (upgrade_proto.cpp) turns into `layer` before CopyTrainedLayersFrom matches by name
+      WireReader lr = r.sub();
+      WireLayer L;
+      L.type = "V1";
+      while (!lr.done()) {
+        int w2;
+        const uint32_t g = lr.tag(w2);
+        if (g == 4 && w2 == 2) L.name = lr.bytes();
+        else if (g == 6 && w2 == 2) L.blobs.push_back(read_blob(lr.sub()));
+        else lr.skip(w2);
+      }
+      out.push_back(std::move(L));
     } else {
       r.skip(wt);
     }

@@ -102,6 +102,7 @@ struct TailArgs {
   // optional materialised Caffe blobs (NCHW), may be null
   float* cls_prob_reshape_nchw = nullptr;  // (1,2A,h,w)
   float* bbox_pred_nchw = nullptr;         // (1,4A,h,w)
+  int probs_given = 0;       // diagnostics: the logits workspace already holds bg/fg probabilities (launch_tail_inject)
 };
 struct TailWork {  // device workspace owned by the net, sized for the largest level seen
   float* logits = nullptr;           // [K][A][6]
@@ -113,6 +114,10 @@ struct TailWork {  // device workspace owned by the net, sized for the largest l
 // runs logits -> decode -> select -> sort; leaves R (device counters[2]) rows in out_boxes/out_probs
 int launch_tail(const TailArgs& a, TailWork& ws, float* out_boxes5, float* out_probs2, hipStream_t s,
                 hipEvent_t after_logits = nullptr, int phase = 0);
+// diagnostics (shf_debug_proposal): fill the logits workspace from injected (1,2A,h,w) probabilities and
+// (1,4A,h,w) deltas (device pointers, NCHW) and raise the overflow flag; follow with launch_tail(phase 2, probs_given)
+int launch_tail_inject(const TailArgs& a, TailWork& ws, const float* scores_nchw, const float* deltas_nchw,
+                       hipStream_t s);
 // after_logits: recorded once the feature maps are consumed; phase 1 = only up to there, 2 = only the rest
 
 // generic device sort of u64 keys, descending; n_dev points at the element count on the device,

@@ -30,6 +30,14 @@ struct TailK {
   int* counters;       // [1] = overflow flag
 };
 
+// np.seterr(over='raise') around exp(dw) * widths (bbox_transform.py:9,52-56): does this delta overflow fp32?
+__device__ __forceinline__ bool delta_overflows(float v, float anchor_extent) {
+  if (!isfinite(v)) return false;
+  const float e = expf(v);
+  const float pw = e * anchor_extent;
+  return isinf(e) || isinf(pw);
+}
+
 // ---- 1x1 cls/reg convs: wave handles two pixels, 32 lanes x float4 per pixel -------------
 __global__ __launch_bounds__(256) void tail_logits_kernel(TailK p) {
   const int lane = threadIdx.x & 63;
@@ -65,11 +73,7 @@ __global__ __launch_bounds__(256) void tail_logits_kernel(TailK p) {
         for (int o = 0; o < 6; ++o) {
           const float v = part[o] + p.bt[a * 6 + o];
           L[o] = v;
-          if (o >= 4 && isfinite(v)) {  // np.seterr(over='raise'): bbox_transform.py:9,52-56
-            const float e = expf(v);
-            const float pw = e * (o == 4 ? p.aw[a] : p.ah[a]);
-            of |= isinf(e) || isinf(pw);
-          }
+          if (o >= 4) of |= delta_overflows(v, o == 4 ? p.aw[a] : p.ah[a]);
         }
         if (of) atomicOr(&p.counters[1], 1);
       }
@@ -89,7 +93,31 @@ struct DecodeK {
   float im_h, im_w, min_size_scaled, score_thresh;
   float* cls_nchw;   // optional (1,2A,h,w)
   float* bbox_nchw;  // optional (1,4A,h,w)
+  int probs_given;   // diagnostics (shf_debug_proposal): L[0..1] already hold bg/fg probabilities
 };
+
+// diagnostics: (1,2A,h,w) probabilities + (1,4A,h,w) deltas in the blobs' NCHW layout -> the tail's
+// [K][A][6] records, raising the same overflow flag the logits kernel raises
+__global__ void tail_inject_kernel(const float* __restrict__ scores, const float* __restrict__ deltas,
+                                   float* __restrict__ logits, int K, int A, TailK p) {
+  const long long total = (long long)K * A;
+  for (long long n = (long long)blockIdx.x * blockDim.x + threadIdx.x; n < total;
+       n += (long long)gridDim.x * blockDim.x) {
+    const int a = (int)(n % A);
+    const long long k = n / A;
+    float* L = logits + n * 6;
+    L[0] = scores[(size_t)a * K + k];
+    L[1] = scores[(size_t)(A + a) * K + k];
+    bool of = false;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float v = deltas[(size_t)(a * 4 + j) * K + k];
+      L[2 + j] = v;
+      if (j >= 2) of |= delta_overflows(v, j == 2 ? p.aw[a] : p.ah[a]);
+    }
+    if (of) atomicOr(&p.counters[1], 1);
+  }
+}
 
 __global__ __launch_bounds__(256) void tail_decode_kernel(DecodeK p) {
   const long long total = (long long)p.K * p.A;
@@ -113,7 +141,7 @@ __global__ __launch_bounds__(256) void tail_decode_kernel(DecodeK p) {
       const float m = fmaxf(c0, c1);
       const float e0 = expf(c0 - m), e1 = expf(c1 - m);
       const float sum = e0 + e1;
-      const float bg = e0 / sum, fg = e1 / sum;
+      const float bg = p.probs_given ? c0 : e0 / sum, fg = p.probs_given ? c1 : e1 / sum;
       float dx = L[2], dy = L[3], dw = L[4], dh = L[5];
       if (p.cls_nchw) {
         p.cls_nchw[(size_t)a * p.K + k] = bg;
@@ -354,12 +382,31 @@ int launch_tail(const TailArgs& a, TailWork& ws, float* out_boxes5, float* out_p
   dk.score_thresh = a.score_thresh;
   dk.cls_nchw = a.cls_prob_reshape_nchw;
   dk.bbox_nchw = a.bbox_pred_nchw;
+  dk.probs_given = a.probs_given;
   hipLaunchKernelGGL(tail_decode_kernel, dim3(grid_for(total)), dim3(256), 0, s, dk);
   if (launch_sort_desc_u64(ws.keys, ws.counters, (size_t)total, s)) return -1;
   hipLaunchKernelGGL(tail_finalize_kernel, dim3(1), dim3(1), 0, s, ws.keys, ws.counters, a.pre_nms_topN);
   const long long rmax = (a.pre_nms_topN > 0 && a.pre_nms_topN < total) ? a.pre_nms_topN : total;
   hipLaunchKernelGGL(tail_gather_kernel, dim3(grid_for(rmax)), dim3(256), 0, s, ws.keys, ws.rec, ws.counters,
                      out_boxes5, out_probs2);
+  SHF_HIP_OK(hipGetLastError());
+  return 0;
+}
+
+int launch_tail_inject(const TailArgs& a, TailWork& ws, const float* scores_nchw, const float* deltas_nchw,
+                       hipStream_t s) {
+  const int K = a.h * a.w;
+  const long long total = (long long)K * a.A;
+  if ((size_t)total > ws.cap_anchors) { set_error("tail: workspace too small"); return -1; }
+  SHF_HIP_OK(hipMemsetAsync(ws.counters, 0, 8 * sizeof(int), s));
+  TailK lk = {};
+  for (int i = 0; i < a.A; ++i) {
+    lk.aw[i] = a.anchors[i * 4 + 2] - a.anchors[i * 4 + 0] + 1.0f;
+    lk.ah[i] = a.anchors[i * 4 + 3] - a.anchors[i * 4 + 1] + 1.0f;
+  }
+  lk.counters = ws.counters;
+  hipLaunchKernelGGL(tail_inject_kernel, dim3(grid_for(total)), dim3(256), 0, s, scores_nchw, deltas_nchw, ws.logits,
+                     K, a.A, lk);
   SHF_HIP_OK(hipGetLastError());
   return 0;
 }

@@ -323,6 +323,10 @@ def inference_worker(rank, imdb, target_test, start, end, thresh, result_queue=N
     cfg.GPU_ID = cfg.TEST.GPU_ID[rank]
     caffe.set_mode_gpu()
     caffe.set_device(cfg.GPU_ID)
+    if not str(cfg.TEST.MODEL):
+        # Caffe aborts in CopyTrainedLayersFrom on an empty path (net.cpp:733-768); an all-zero net would
+        # otherwise write detection files without a word
+        raise IOError("TEST.MODEL is empty: pass --amend TEST.MODEL <file>.caffemodel")
     net = caffe.Net(str(target_test), str(cfg.TEST.MODEL), caffe.TEST)
     if "SHF_CONV_MODE" not in os.environ:
         # split-fp16 matrix-core arithmetic (fp32-class, same parity bars, 3x the throughput of the exact

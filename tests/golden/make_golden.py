@@ -27,6 +27,7 @@ Reference entry points exercised (file:line in /root/reference):
   lib/utils/test_utils.py:8           _compute_scaling_factor (+ test.py:131-137)
   lib/utils/get_config.py:134,140     cfg_from_file / cfg_from_list
   lib/datasets/wider.py:143           write_detections line format
+  models/test_*template.prototxt      structural digest of both inference templates
 """
 import io
 import json
@@ -156,6 +157,33 @@ class FakeBlob(object):
     @property
     def shape(self):
         return self.data.shape
+
+
+class FakeNet(object):
+    """Returns canned proposal outputs; records what the driver fed it."""
+
+    def __init__(self, seed):
+        self.rng = np.random.default_rng(seed)
+        self.blobs = {"data": FakeBlob(np.zeros((1, 3, 16, 16))),
+                      "im_info": FakeBlob(np.zeros((1, 3))),
+                      "boxes": FakeBlob(np.zeros((1, 5))),
+                      "cls_prob": FakeBlob(np.zeros((1, 2)))}
+        self.calls = []
+
+    def forward(self, data=None, im_info=None):
+        h, w, s = im_info[0]
+        self.calls.append((tuple(data.shape), im_info.copy(),
+                           float(data.sum()), float(data[0, 0, 0, 0])))
+        n = int(self.rng.integers(3, 40))
+        x1 = self.rng.uniform(0, w - 2, n)
+        y1 = self.rng.uniform(0, h - 2, n)
+        x2 = np.minimum(x1 + self.rng.uniform(1, w / 3 + 2, n), w - 1)
+        y2 = np.minimum(y1 + self.rng.uniform(1, h / 3 + 2, n), h - 1)
+        fg = np.sort(self.rng.uniform(0.002, 1, n))[::-1]
+        self.blobs["boxes"].data = np.stack(
+            [np.zeros(n), x1, y1, x2, y2], 1).astype(np.float32)
+        self.blobs["cls_prob"].data = np.stack([1 - fg, fg], 1).astype(np.float32)
+        return {"boxes": self.blobs["boxes"].data, "cls_prob": self.blobs["cls_prob"].data}
 
 
 def softmax_blob(rng, h, w, bias):
@@ -361,32 +389,6 @@ def main():
     np.savez_compressed(os.path.join(OUT, "vote_nms.npz"), **vn)
 
     # ---------------- forward_net (flip/unscale/tile) ------------------
-    class FakeNet(object):
-        """Returns canned proposal outputs; records what the driver fed it."""
-
-        def __init__(self, seed):
-            self.rng = np.random.default_rng(seed)
-            self.blobs = {"data": FakeBlob(np.zeros((1, 3, 16, 16))),
-                          "im_info": FakeBlob(np.zeros((1, 3))),
-                          "boxes": FakeBlob(np.zeros((1, 5))),
-                          "cls_prob": FakeBlob(np.zeros((1, 2)))}
-            self.calls = []
-
-        def forward(self, data=None, im_info=None):
-            h, w, s = im_info[0]
-            self.calls.append((tuple(data.shape), im_info.copy(),
-                               float(data.sum()), float(data[0, 0, 0, 0])))
-            n = int(self.rng.integers(3, 40))
-            x1 = self.rng.uniform(0, w - 2, n)
-            y1 = self.rng.uniform(0, h - 2, n)
-            x2 = np.minimum(x1 + self.rng.uniform(1, w / 3 + 2, n), w - 1)
-            y2 = np.minimum(y1 + self.rng.uniform(1, h / 3 + 2, n), h - 1)
-            fg = np.sort(self.rng.uniform(0.002, 1, n))[::-1]
-            self.blobs["boxes"].data = np.stack(
-                [np.zeros(n), x1, y1, x2, y2], 1).astype(np.float32)
-            self.blobs["cls_prob"].data = np.stack([1 - fg, fg], 1).astype(np.float32)
-            return {"boxes": self.blobs["boxes"].data, "cls_prob": self.blobs["cls_prob"].data}
-
     fw = {}
     for i, (h, w, s, flip) in enumerate([(100, 100, 0.09765625, False), (150, 301, 0.29296875, True),
                                          (64, 80, 1.0, True), (37, 53, 1.37, False)]):
@@ -436,6 +438,21 @@ def main():
     # format pin (the wider imdb class itself needs datasets on disk to construct)
     json.dump({"rows": rows.tolist(), "lines": lines},
               open(os.path.join(OUT, "write_detections.json"), "w"), indent=1)
+
+    # ---------------- inference templates: structural digest -------------
+    # models/test_template.prototxt and models/test_different_dilation_template.prototxt parsed with the
+    # runtime's own text-format parser and reduced to a canonical dump; only its SHA-256 and a few counts
+    # are committed (the product generates the templates itself, prototxt.build_test_template).
+    import hashlib
+    from smallhardface_amd import prototxt as P
+    tdig = {}
+    for key, fn in (("plain", "test_template.prototxt"), ("different_dilation", "test_different_dilation_template.prototxt")):
+        msg = P.parse(open(os.path.join(REF, "models", fn)).read())
+        canon = P.dumps(msg)
+        layers = msg.getall("layer")
+        tdig[key] = {"sha256": hashlib.sha256(canon.encode()).hexdigest(), "n_layers": len(layers),
+                     "n_chars": len(canon)}
+    json.dump(tdig, open(os.path.join(OUT, "template_digest.json"), "w"), indent=1, sort_keys=True)
 
     shutil.rmtree(tmp, ignore_errors=True)
     print("golden fixtures written to", OUT)
