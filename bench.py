@@ -14,8 +14,8 @@ detections of an image are gathered on its owner rank with an RCCL all_gather
 (smallhardface_amd/pyramid.py).
 
 Rank 0 prints ONE JSON line (contract in the task description) with two extra objects:
-  roofline      dominant kernel (fp32 MFMA implicit-GEMM conv) measured live with HIP
-                events on the runtime's own stream over the timed region
+  roofline      dominant kernel (split-fp16 MFMA implicit-GEMM conv, or the exact fp32 MFMA one with
+                --conv-mode fp32) measured live with HIP events on the runtime's own stream over the timed region
   cpu_baseline  the numpy/OpenBLAS oracle (Caffe's im2col+SGEMM algorithm) timed on the
                 host cores on one pyramid level and scaled by algorithmic FLOPs
 """
@@ -37,25 +37,29 @@ PEAK_F16_MFMA_TFLOPS = 2500.0  # v_mfma_f32_32x32x16_f16 (dense; the 5 PF market
 SRC_H = SRC_W = 1024
 
 
-def build_units(image_index):
-    """The 10 (data, H, W, im_h, im_w, scale, flip) units of one synthetic 1024^2 image."""
+def build_units(image_index, src_hw=(SRC_H, SRC_W)):
+    """The (data, H, W, im_h, im_w, scale, flip) units of one synthetic source image (10 for the default workload)."""
     from smallhardface_amd.test import pyramid_units
     rng = np.random.default_rng(1000 + image_index)
-    im = rng.integers(0, 256, (SRC_H, SRC_W, 3)).astype(np.uint8)
+    im = rng.integers(0, 256, (src_hw[0], src_hw[1], 3)).astype(np.uint8)
     return list(pyramid_units(im))
 
 
-def hbm_traffic_per_launch(kernel_name):
-    """HBM bytes per launch of ``kernel_name`` from the committed PMC passes (None when absent)."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_bytes.json")
+PMC_FILE = "profiles/r02_pmc.json"   # written by tools/make_profiles.sh (separate rocprofv3 --pmc passes of this command)
+
+
+def committed_pmc(kernel_name):
+    """Counter-based figures for ``kernel_name`` from the committed PMC passes (tools/make_profiles.sh): they are NOT
+    measured in this run -- the entry carries the kernel-source hash it was taken with and is reported only while
+    that still matches the sources (None otherwise)."""
     try:
-        tab = json.load(open(path))
+        tab = json.load(open(os.path.join(ROOT, PMC_FILE)))
     except Exception:
         return None
-    for k, v in tab.items():
-        if kernel_name in k:
-            return (2.0 * v["fetch_size_kb_per_launch"] + v["write_size_kb_per_launch"]) * 1024.0
-    return None
+    from tools.kernel_hash import kernel_source_hash
+    if tab.get("kernel_source_hash") != kernel_source_hash():
+        return {"stale": True}
+    return tab.get("kernels", {}).get(kernel_name)
 
 
 def cpu_baseline(msg, params, seconds_budget=25.0):
@@ -112,6 +116,13 @@ def main():
     ap.add_argument("--lanes", type=int, default=5, help="execution lanes (HIP streams) per GPU in --mode streams")
     ap.add_argument("--mode", default="group", choices=["group", "streams"],
                     help="group: one grid per conv layer over all units of the image; streams: units on HIP streams")
+    ap.add_argument("--shard", default="window", choices=["window", "strict"],
+                    help="N>1: 'window' = one unit of every (level, flip) kind per rank per window (balanced); "
+                         "'strict' = the north star's one-scale-per-GPU form, level l on rank l mod N (SURVEY.md 8e)")
+    ap.add_argument("--source", default="1024x1024", help="HxW of the synthetic source images (C4: 768x1024)")
+    ap.add_argument("--scales", default=None, help="comma list overriding TEST.SCALES (C4: 300,600,1000,1400)")
+    ap.add_argument("--no-flip", action="store_true", help="TEST.FLIP = false")
+    ap.add_argument("--no-latency", action="store_true", help="skip the single-image (un-pipelined) latency leg")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -121,8 +132,13 @@ def main():
         raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world))
 
     import torch
-    if os.environ.get("SHF_BENCH_ONE_GPU") == "1":
+    one_gpu = os.environ.get("SHF_BENCH_ONE_GPU") == "1"
+    if one_gpu:
         local_rank = 0  # validation only: every rank on device 0 (needs --backend gloo)
+    n_dev = torch.cuda.device_count()   # (does not initialise the GPU)
+    if n_dev < (1 if one_gpu else max(world, 1)):
+        raise SystemExit("bench.py --gpus %d needs %d visible MI355X, found %d (SHF_BENCH_ONE_GPU=1 --backend gloo runs "
+                         "all ranks on one GPU for validation)" % (args.gpus, world, n_dev))
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
@@ -139,6 +155,11 @@ def main():
     cfg_from_file(os.path.join(ROOT, "configs", "smallhardface.toml"))
     if args.method:
         cfg.TEST.NMS_METHOD = args.method
+    if args.scales:
+        cfg.TEST.SCALES = [int(v) for v in args.scales.split(",")]
+    if args.no_flip:
+        cfg.TEST.FLIP = False
+    src_hw = tuple(int(v) for v in args.source.lower().split("x"))
     caffe.set_mode_gpu()
     caffe.set_device(local_rank)
 
@@ -152,19 +173,20 @@ def main():
     net.set_conv_mode(args.conv_mode)
 
     # ---- the window: `world` images, this rank's share of their units resident in HBM
-    n_units = len(cfg.TEST.SCALES) * (2 if cfg.TEST.FLIP else 1)
-    mine = pyramid.my_units(rank, world, world, n_units)
+    n_flip = 2 if cfg.TEST.FLIP else 1
+    n_units = len(cfg.TEST.SCALES) * n_flip
+    mine = pyramid.my_units(rank, world, world, n_units, shard=args.shard, units_per_level=n_flip)
+    if len(mine) > 16:
+        raise SystemExit("a rank's share of the window is %d units; one grouped pass holds 16" % len(mine))
     units = {}
     cache = {}
     for (i, u) in mine:
         if i not in cache:
-            cache = {i: build_units(i)}
+            cache = {i: build_units(i, src_hw)}
         data, H, W, im_h, im_w, s, flip = cache[i][u]
         t = torch.from_numpy(data).to(dev)
         units[(i, u)] = (t, H, W, im_h, im_w, s, flip)
     del cache
-    flops_per_image = sum(pyramid.level_flops(v[1], v[2]) for v in units.values()) * (1.0 if world == 1 else 0.0)
-    exp_cap = n_units * cfg.TEST.N_DETS_PER_MODULE
     export = [torch.empty((cfg.TEST.N_DETS_PER_MODULE, 5), dtype=torch.float32, device=dev)
               for _ in range(len(mine))] if world > 1 else None
     thresh = 0.05
@@ -180,7 +202,7 @@ def main():
         elif args.host_input == "image":
             from smallhardface_amd.test import DevicePyramid
             dp = DevicePyramid(net, n_slots=2)
-            host_im = np.random.default_rng(1000).integers(0, 256, (SRC_H, SRC_W, 3)).astype(np.uint8)
+            host_im = np.random.default_rng(1000).integers(0, 256, (src_hw[0], src_hw[1], 3)).astype(np.uint8)
     else:
         # two lane sets: window k+1's convolutions are enqueued (on the other set's head stream) before window
         # k's detections are exported, gathered over RCCL and merged -- the exchange hides under compute
@@ -190,11 +212,11 @@ def main():
         lane_sets = [lanes[1:1 + len(mine)], lanes[1 + len(mine):1 + 2 * len(mine)]]
         export_sets = [export, [torch.empty_like(e) for e in export]]
         mine_units = [(units[k][0].data_ptr(),) + units[k][1:] for k in mine]
-    state = {"k": 0, "pending": None}
+    state = {"k": 0, "pending": None, "collectives": 0}
 
     def finish_window(w):
         ls, ex = lane_sets[w], export_sets[w]
-        counts = ls[0].detect_export_many(ls, [e.data_ptr() for e in ex], cfg.TEST.N_DETS_PER_MODULE)
+        counts = ls[0].detect_export_many(ls, [e.data_ptr() for e in ex], cfg.TEST.N_DETS_PER_MODULE) if ls else []
         parts = {i: [] for i in range(world)}
         for m, (i, u) in enumerate(mine):
             if counts[m]:
@@ -202,6 +224,7 @@ def main():
         empty = torch.zeros((0, 5), dtype=torch.float32, device=dev)
         local = {i: (torch.cat(p, 0) if p else empty) for i, p in parts.items()}
         got = pyramid.gather_window(local, world, rank, world, device=dev)
+        state["collectives"] += 2
         torch.cuda.synchronize()
         for i, t in got.items():
             net.detect_begin()
@@ -224,12 +247,13 @@ def main():
             if fd.pending() > 1:
                 last[0] = fd.collect()[0]
             return
-        # this rank's 10 units (one of each kind, from different images) as ONE grouped pass;
-        # every lane keeps the detections of its unit, which are then routed to the unit's image
+        # this rank's units (from different images) as ONE grouped pass; every lane keeps the detections of its
+        # unit, which are then routed to the unit's image
         w = state["k"] & 1
         state["k"] += 1
         ls = lane_sets[w]
-        ls[0].detect_add_levels(ls, mine_units, thresh, on_device=True, per_member_lists=True)
+        if ls:
+            ls[0].detect_add_levels(ls, mine_units, thresh, on_device=True, per_member_lists=True)
         if state["pending"] is not None:
             finish_window(state["pending"])
         state["pending"] = w
@@ -278,11 +302,25 @@ def main():
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
 
+    # ---- single-image latency: ONE image, nothing else in flight, submit -> merged detections on the host
+    latency_ms = None
+    if world == 1 and args.mode == "group" and not args.no_latency and not args.host_input:
+        lat = []
+        for _ in range(7):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            last[0] = fd.detect(unit_list, thresh, on_device=True)[0]
+            lat.append(1000.0 * (time.perf_counter() - t1))
+        latency_ms = float(np.median(lat[2:]))
+
     if rank == 0 and args.dump_dets and 0 in last:
         np.save(args.dump_dets, np.asarray(last[0]))
     if rank == 0:
         images = world * args.steps
         value = images / elapsed
+        lv = [(v[1], v[2]) for v in (unit_list if world == 1 else build_units(0, src_hw))]
+        gflop_image = sum(pyramid.level_flops(h, w) for h, w in lv) / 1e9
+        default_wl = (src_hw == (1024, 1024) and list(cfg.TEST.SCALES) == [100, 300, 600, 1000, 1400] and cfg.TEST.FLIP)
         out = {
             "metric": "images_per_sec_full_multiscale_pyramid", "value": value, "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -291,18 +329,32 @@ def main():
             "dtype": "f32 via split-f16 MFMA (3x fp16 products, f32 accumulate)" if args.conv_mode == "f16x3" else "f32",
             "data": "synthetic",
             "config": {
-                "workload": "C5: full smallhardface.toml test pyramid of a 1024x1024 source: scales "
-                            "[100,300,600,1000,1400] -> padded 112/304/608/1008/1408, x flip = 10 units/image "
-                            "(5021.6 GFLOP), VGG-16 + shared-weight dilated heads (different_dilation + dim_red), "
-                            "fp32 activations, conv mode %s, proposal tail + >0.05 cut + %s on device"
-                            % (args.conv_mode, cfg.TEST.NMS_METHOD),
-                "images_per_step": world, "units_per_image": n_units, "lanes_per_gpu": len(lanes), "unit_execution": args.mode, "parallelism":
-                    "pyramid units sharded 1-of-each-kind per GPU per window; RCCL all_gather of detections to the "
-                    "image's owner rank" if world > 1 else "single GPU",
+                "workload": ("C5: full smallhardface.toml test pyramid" if default_wl else "test pyramid") +
+                            " of a %dx%d (HxW) source: scales %s -> padded levels %s%s = %d units/image (%.1f GFLOP), "
+                            "VGG-16 + shared-weight dilated heads (different_dilation + dim_red), fp32 activations, conv "
+                            "mode %s, proposal tail + >0.05 cut + %s on device"
+                            % (src_hw[0], src_hw[1], list(cfg.TEST.SCALES),
+                               "/".join("%dx%d" % hw for hw in lv[::n_flip]), " x flip" if cfg.TEST.FLIP else "",
+                               n_units, gflop_image, args.conv_mode, cfg.TEST.NMS_METHOD),
+                "images_per_step": world, "units_per_image": n_units, "lanes_per_gpu": len(lanes),
+                "unit_execution": args.mode, "shard": args.shard if world > 1 else None,
+                "parallelism": ("single GPU" if world == 1 else
+                                ("pyramid units sharded 1-of-each-kind per GPU per window" if args.shard == "window" else
+                                 "strict one-scale-per-GPU: level l (all its flips, every image of the window) on rank "
+                                 "l mod N") + "; all_gather of detections to the image's owner rank over %s"
+                                % ("RCCL" if args.backend == "nccl" else args.backend)),
                 "weights": "seeded synthetic (no trained caffemodel exists in the reference tree)",
                 "detections_last_image": int(len(next(iter(last.values())))) if last else 0,
             },
         }
+        if world > 1:
+            out["rccl_ranks"] = int(dist.get_world_size()) if args.backend == "nccl" else 0
+            out["collective_backend"] = str(dist.get_backend())
+            out["collectives_issued_rank0"] = int(state["collectives"])
+            out["all_ranks_on_one_gpu"] = bool(one_gpu)
+        if latency_ms is not None:
+            out["latency_ms"] = latency_ms
+            out["latency_note"] = "one image, no pipelining: submit of the 10-unit grouped pass -> merged boxes on the host"
         # ---- roofline of the dominant kernel -----------------------------------------
         convs = {k: v for k, v in prof.items() if k.startswith("conv_mfma") and v["launches"] > 0}
         if convs:
@@ -311,21 +363,33 @@ def main():
             all_ms = sum(v["ms"] for v in prof.values())
             split = "f16x3" in name
             peak = PEAK_F16_MFMA_TFLOPS if split else PEAK_F32_MFMA_TFLOPS
+            pmc = committed_pmc(name)
+            stale = bool(pmc and pmc.get("stale"))
+            pmc = None if (pmc is None or stale) else pmc
             out["roofline"] = {
                 "bound": "mfma", "kernel": name, "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-                "frac": ach / peak, "traffic": hbm_traffic_per_launch(name),
+                "frac": ach / peak,
+                "traffic": pmc.get("hbm_bytes_per_launch") if pmc else None,
+                "traffic_measured_in_this_run": False,
+                "traffic_source": ("%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of this command, bytes = "
+                                   "(2 x FETCH_SIZE + WRITE_SIZE) x 1024 per launch: gfx950 FETCH_SIZE counts 128-B requests "
+                                   "as 64 B, MI355X_MICROARCH.md HBM section); taken on the kernel sources of this tree "
+                                   "(hash checked)" % PMC_FILE) if pmc else
+                                  ("%s is stale (kernel sources changed since the PMC passes): not reported" % PMC_FILE
+                                   if stale else None),
                 "mfma_dtype": "fp16 x3 (split-fp16: 3 MFMA FLOPs issued per algorithmic FLOP)" if split else "fp32",
+                "frac_issued": ach * (3.0 if split else 1.0) / peak,
                 "issued_mfma_achieved": ach * (3.0 if split else 1.0),
-                "issued_mfma_frac": ach * (3.0 if split else 1.0) / peak,
-                "traffic_source": "profiles/r01_pmc_hbm_bytes.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate "
-                                  "passes of this command, bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 per launch "
-                                  "(gfx950 FETCH_SIZE counts 128-B requests as 64 B, MI355X_MICROARCH.md HBM section)",
+                "mfma_busy": pmc.get("mfma_busy") if pmc else None,
+                "mfma_busy_source": ("%s: SQ_VALU_MFMA_BUSY_CYCLES / (SQ_BUSY_CYCLES-derived kernel cycles x 4 SIMDs x CUs), "
+                                     "not measured in this run" % PMC_FILE) if pmc and pmc.get("mfma_busy") is not None else None,
                 "launches": dom["launches"], "avg_launch_ms": dom["ms"] / dom["launches"],
                 "algorithmic_gflop_per_launch": dom["flops"] / dom["launches"] / 1e9,
                 "all_conv_mfma_achieved": sum(v["flops"] for v in convs.values()) /
                                           (sum(v["ms"] for v in convs.values()) * 1e-3) / 1e12,
                 "kernel_ms_share": {k: round(v["ms"] / all_ms, 4) for k, v in prof.items() if v["ms"] > 0},
                 "kernel_ms_per_image": {k: round(v["ms"] / args.steps, 3) for k, v in prof.items() if v["ms"] > 0},
+                "launches_per_image": {k: round(v["launches"] / args.steps, 2) for k, v in prof.items() if v["launches"] > 0},
             }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(msg, params)

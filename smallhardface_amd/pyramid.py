@@ -25,14 +25,24 @@ def image_owner(image, world):
     return image % world
 
 
-def my_units(rank, world, n_images, n_units):
-    """[(image, unit)] this rank runs for a window of ``n_images`` images, image-major."""
-    return [(i, u) for i in range(n_images) for u in range(n_units) if unit_rank(i, u, world) == rank]
-
-
 def strict_level_rank(level, world):
     """The north star's plain mode: pyramid level -> GPU (both flips of a level together)."""
     return level % world
+
+
+def my_units(rank, world, n_images, n_units, shard="window", units_per_level=2):
+    """[(image, unit)] this rank runs for a window of ``n_images`` images, image-major.
+
+    shard "window": unit u of window image i on rank (u + i) mod world -- one unit of every kind per rank.
+    shard "strict": the north star's one-scale-per-GPU form -- every unit of pyramid level l (its
+    ``units_per_level`` flips, of every image of the window) on rank l mod world; with fewer ranks than levels a
+    rank holds several levels, with more ranks than levels the surplus ranks only take part in the gather."""
+    if shard == "strict":
+        return [(i, u) for i in range(n_images) for u in range(n_units)
+                if strict_level_rank(u // max(1, units_per_level), world) == rank]
+    if shard != "window":
+        raise ValueError("shard must be 'window' or 'strict'")
+    return [(i, u) for i in range(n_images) for u in range(n_units) if unit_rank(i, u, world) == rank]
 
 
 def gather_window(local, n_images, rank, world, device=None, group=None):

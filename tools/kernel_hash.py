@@ -1,0 +1,18 @@
+"""Hash of the kernel sources: ties a committed PMC summary (profiles/*.json) to the code it was measured on."""
+import hashlib
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FILES = ["conv.hip", "conv_f16x3.hip", "conv_common.h", "misc.hip", "tail.hip", "merge.hip", "pre.hip", "shf_internal.h"]
+
+
+def kernel_source_hash():
+    h = hashlib.sha256()
+    for f in FILES:
+        with open(os.path.join(ROOT, "smallhardface_amd", "csrc", f), "rb") as fh:
+            h.update(f.encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
+
+
+if __name__ == "__main__":
+    print(kernel_source_hash())
