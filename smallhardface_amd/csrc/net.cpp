@@ -455,6 +455,7 @@ struct shf_net {
   void build(const std::string& text, const char* caffemodel);
   void infer_shapes();
   void alloc_buffers();
+  void ensure_tail_workspace(size_t total_anchors);
   void commit_params(int li);
   void build_tail_weights();
   void forward_ops(bool fused_path, float im_h, float im_w, float im_scale, hipStream_t s_override = nullptr,
@@ -909,24 +910,27 @@ void shf_net::alloc_buffers() {
   }
   if (tail_layer >= 0) {
     Blob& f = blobs[tail_feat_blobs[0]];
-    const size_t K = (size_t)f.shape[2] * f.shape[3];
-    const size_t total = K * tail_A;
-    size_t npad = 1;
-    while (npad < total) npad <<= 1;
-    tw_logits.ensure(total * 6 * 4);
-    tw_rec.ensure(total * 6 * 4);
-    tw_keys.ensure(std::max<size_t>(npad, 16384) * 8);
-    tw_counters.ensure(64);
-    tw.logits = (float*)tw_logits.p;
-    tw.rec = (float*)tw_rec.p;
-    tw.keys = (unsigned long long*)tw_keys.p;
-    tw.counters = (int*)tw_counters.p;
-    tw.cap_anchors = total;
-    tw.cap_keys = npad;
-    const size_t rmax = (pre_nms_topN > 0) ? std::min<size_t>(total, (size_t)pre_nms_topN) : total;
-    blobs[boxes_blob].dev.ensure(std::max<size_t>(rmax, 1) * 5 * 4);
-    if (prob_blob >= 0) blobs[prob_blob].dev.ensure(std::max<size_t>(rmax, 1) * 2 * 4);
+    ensure_tail_workspace((size_t)f.shape[2] * f.shape[3] * tail_A);
   }
+}
+
+// tail workspace + proposal output blobs for `total` anchors (grow-only)
+void shf_net::ensure_tail_workspace(size_t total) {
+  size_t npad = 1;
+  while (npad < total) npad <<= 1;
+  tw_logits.ensure(total * 6 * 4);
+  tw_rec.ensure(total * 6 * 4);
+  tw_keys.ensure(std::max<size_t>(npad, 16384) * 8);
+  tw_counters.ensure(64);
+  tw.logits = (float*)tw_logits.p;
+  tw.rec = (float*)tw_rec.p;
+  tw.keys = (unsigned long long*)tw_keys.p;
+  tw.counters = (int*)tw_counters.p;
+  tw.cap_anchors = total;
+  tw.cap_keys = npad;
+  const size_t rmax = (pre_nms_topN > 0) ? std::min<size_t>(total, (size_t)pre_nms_topN) : total;
+  blobs[boxes_blob].dev.ensure(std::max<size_t>(rmax, 1) * 5 * 4);
+  if (prob_blob >= 0) blobs[prob_blob].dev.ensure(std::max<size_t>(rmax, 1) * 2 * 4);
 }
 
 void shf_net::build_tail_weights() {
@@ -1834,15 +1838,10 @@ int shf_debug_proposal(shf_net* net, const float* scores, const float* deltas, i
   API_BEGIN
   if (net->tail_layer < 0) throw std::runtime_error("net has no proposal layer");
   if (h < 1 || w < 1) throw std::runtime_error("debug_proposal: bad map size");
-  // size the tail workspace / output blobs for an (h, w) head map: reshape 'data' to the matching level
-  Blob& d = net->blobs[net->data_blob];
-  d.shape = {1, d.shape.size() == 4 ? d.shape[1] : 3, h * net->feat_stride, w * net->feat_stride};
-  net->infer_shapes();
-  net->alloc_buffers();
-  Blob& f = net->blobs[net->tail_feat_blobs[0]];
-  if (f.shape[2] != h || f.shape[3] != w) throw std::runtime_error("debug_proposal: head map does not come out (h, w)");
+  // (any (h, w): the layer itself does not care that the real graph only produces even head maps)
   const int A = net->tail_A;
   const size_t K = (size_t)h * w;
+  net->ensure_tail_workspace(K * A);
   DevBuf ds, dd;
   ds.ensure(K * 2 * A * 4);
   dd.ensure(K * 4 * A * 4);

@@ -1,6 +1,6 @@
 """Per-layer micro-benchmark of the MFMA conv kernel (HIP events on the runtime's stream).
 
-    python -m tests.bench_conv [reps]
+    python -m tools.bench_conv [reps]
 
 Shapes are the detector's layers at the 1408x1408 pyramid level (the unit that carries
 57 % of an image's FLOPs) plus a grouped launch over all ten units of the bench image.
