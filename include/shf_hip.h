@@ -79,12 +79,19 @@ int shf_net_forward(shf_net* net);
  * the native proposal stage takes them here. */
 int shf_net_set_proposal_cfg(shf_net* net, int pre_nms_topN, float score_thresh, float min_size);
 
-/* Arithmetic of the 3x3 / dilation-1 convolutions: 0 = exact fp32 matrix cores
+/* Arithmetic of the MFMA convolutions (3x3 at any dilation and 1x1): 0 = exact fp32 matrix cores
  * (v_mfma_f32_32x32x2_f32, bit-for-bit an fmaf chain); 1 = split-fp16: x = hi + lo*2^-11 with
  * three fp16 MFMAs per product, fp32 accumulate (2^-22 relative per product: fp32-class, 5.3x
- * the fp32 MFMA rate).  Default 0, or the SHF_CONV_MODE environment variable at creation.
- * Set it before cloning lanes. */
+ * the fp32 MFMA rate).  Default 0, or the SHF_CONV_MODE environment variable at creation.  The mode is shared by
+ * a net and all lanes cloned from it (like the proposal configuration above). */
 int shf_net_set_conv_mode(shf_net* net, int mode);
+/* fp16 range guard of mode 1 (the reference is fp32 everywhere, caffe/python/caffe/_caffe.cpp:46-48): hi = fp16(x)
+ * overflows above 65504.  Weights are checked when they are packed (shf_net_param_commit / shf_net_set_conv_mode
+ * fail with a message).  Every split-fp16 convolution raises a device flag when one of its outputs leaves the range:
+ * shf_net_forward then re-runs that forward on the exact fp32 kernels (the count of such re-runs is returned here,
+ * shared by a net and its lanes); on the fused path shf_detect_finish / shf_detect_export(_many) fail with
+ * "split-fp16 range exceeded ..." so that the caller can re-run the image in mode 0 -- never a silent inf/NaN. */
+long long shf_net_range_fallbacks(shf_net* net);
 
 /* ---- fused per-image path (device-resident pyramid; lib/test.py:109-178) ---- */
 /* detect(): begin an image */

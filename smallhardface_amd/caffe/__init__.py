@@ -168,6 +168,12 @@ class Net(object):
         self.commit_params()
         _lib.check(self._lib.shf_net_set_conv_mode(self._h, m), "set_conv_mode")
 
+    @property
+    def range_fallbacks(self):
+        """Forwards this net (and its lanes) re-ran on the exact fp32 kernels because a split-fp16 convolution left
+        the fp16 range (C ABI shf_net_range_fallbacks)."""
+        return int(self._lib.shf_net_range_fallbacks(self._h))
+
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
         if h:

@@ -257,13 +257,14 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_f32_kernel(ConvK p) {
 __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict__ in, const float* __restrict__ wt,
                                                           const float* __restrict__ bias, float* __restrict__ out,
                                                           int B, int H, int W, int Cin, int Cout, int k, int dil,
-                                                          int pad, int relu, int out_stride) {
+                                                          int pad, int relu, int out_stride, int* range_flag) {
   extern __shared__ __attribute__((aligned(16))) float tile[];  // [64][Cout + 4]
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int pitch = Cout + 4;
   const int ngroups = Cout / 16;
   const int c4n = Cout / 4;
   const long long total = (long long)B * H * W;
+  float amax = 0.f;  // split-fp16 mode: the consumer splits these outputs to fp16 hi/lo (range guard, conv_common.h)
   for (long long P0 = (long long)blockIdx.x * 64; P0 < total; P0 += (long long)gridDim.x * 64) {
     const long long P = P0 + lane;
     const bool valid = P < total;
@@ -296,6 +297,7 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict
         if (relu) {
           v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
         }
+        amax = fmaxf(fmaxf(fmaxf(amax, fabsf(v.x)), fmaxf(fabsf(v.y), fabsf(v.z))), fabsf(v.w));
         *(float4*)(tile + lane * pitch + g * 16 + j) = v;
       }
     }
@@ -307,6 +309,7 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict
     }
     __syncthreads();
   }
+  conv_raise_range_flag(range_flag, amax);
 }
 
 // ---------------------------------------------------------------------------
@@ -474,7 +477,7 @@ int launch_conv_first(const float* in_nchw, const ConvArgs& a, hipStream_t s) {
   if (blocks > 256 * 8) blocks = 256 * 8;  // persistent blocks, grid-stride over 64-pixel groups
   hipLaunchKernelGGL(conv_first_kernel, dim3((unsigned)blocks), dim3(256), lds, s, in_nchw, a.wfirst, a.bias,
                      a.out.p + a.out.coff, a.in.B, a.in.H, a.in.W, Cin, Cout, a.k, a.dil, a.pad, a.relu,
-                     a.out.cstride);
+                     a.out.cstride, a.range_flag);
   SHF_HIP_OK(hipGetLastError());
   return 0;
 }

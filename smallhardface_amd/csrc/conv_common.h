@@ -33,6 +33,7 @@ struct ConvK {
   const void* w1f;   // FUSE1 (producer/consumer kernel): the same as split-fp16 MFMA B fragments (pack_first_conv_frags)
   const float* b1;   // FUSE1: first-layer bias [64]
   unsigned long long* dbg;  // SHF_CONV_TIMING builds only: per-wave phase cycle sums
+  int* range_flag;   // split-fp16 kernels: set to 1 when an output value leaves the fp16 range (|x| > 65504), or null
   int tile_starts[MAX_GROUP];  // m[q].tile_start again, contiguous (unused entries INT_MAX): ONE scalar load finds a
                                // block's member instead of a chain of dependent ones (~1.5 k cycles per block)
   ConvMember m[MAX_GROUP];
@@ -61,7 +62,8 @@ __device__ __forceinline__ void row_to_pixel(int i, int& dy, int& px) {
 template <typename GetV>
 __device__ __forceinline__ void conv_store_tile(GetV getv, float bv, int relu_flags, int gy0, int gx0, int kh,
                                                 int H, int W, int b, int cout, float* __restrict__ gout,
-                                                int out_stride, float* __restrict__ gpool, int pool_stride) {
+                                                int out_stride, float* __restrict__ gpool, int pool_stride,
+                                                float* amax = nullptr) {
   const bool write_main = !(relu_flags & 8);
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
@@ -72,6 +74,7 @@ __device__ __forceinline__ void conv_store_tile(GetV getv, float bv, int relu_fl
       const int y = gy0 + (s >> 1), x = gx + (s & 1);
       float v = getv(4 * q + s) + bv;
       if (relu_flags & 1) v = fmaxf(v, 0.f);
+      if (amax) *amax = fmaxf(*amax, fabsf(v));
       if (y < H && x < W) {
         if (write_main) gout[((size_t)(b * H + y) * W + x) * out_stride + cout] = v;
         m = v > m ? v : m;
@@ -116,7 +119,7 @@ typedef float cs_f32x2 __attribute__((ext_vector_type(2)));
 typedef float cs_f32x16 __attribute__((ext_vector_type(16)));
 template <int BN, bool RELU>
 __device__ __forceinline__ void conv_stage_tile_pk(float* __restrict__ Cs, const cs_f32x16 am, const cs_f32x16 ac,
-                                                   float inv, float bv, int ly0, int kh, int cl) {
+                                                   float inv, float bv, int ly0, int kh, int cl, float& amax) {
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int lx = 2 * (2 * q + kh);
@@ -126,11 +129,19 @@ __device__ __forceinline__ void conv_stage_tile_pk(float* __restrict__ Cs, const
       cs_f32x2 v = __builtin_elementwise_fma(cs_f32x2{ac[r], ac[r + 1]}, cs_f32x2{inv, inv}, cs_f32x2{am[r], am[r + 1]});
       v = v + cs_f32x2{bv, bv};
       if (RELU) v = __builtin_elementwise_max(v, cs_f32x2{0.f, 0.f});
+      amax = fmaxf(fmaxf(amax, fabsf(v[0])), fabsf(v[1]));  // fp16 range guard (v_max3 with abs modifiers)
       float* d = Cs + ((ly0 + (sp >> 1)) * 16 + lx) * (BN + CS_PAD) + cl;
       d[0] = v[0];
       d[BN + CS_PAD] = v[1];
     }
   }
+}
+
+// fp16 range guard of the split-fp16 kernels: `amax` = largest |output| this lane produced.  hi = fp16(x) of the
+// consumer's split overflows above 65504; inf compares greater.  (fmaxf drops NaNs, but a NaN only ever appears
+// downstream of an inf, which has raised the flag of the same pass already.)
+__device__ __forceinline__ void conv_raise_range_flag(int* flag, float amax) {
+  if (flag && !(amax <= 65504.0f)) atomicOr(flag, 1);
 }
 
 // write the staged tile (and its 2x2/2 max-pool) to global memory; all NT threads of the block.

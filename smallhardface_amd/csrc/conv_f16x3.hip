@@ -397,6 +397,7 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_kernel(ConvK p) {
 #undef F16X3_DMA_W
 
   // epilogue: C row = (r&3) + 8*(r>>2) + 4*(lane>>5), C col = lane&31
+  float amax = 0.f;  // fp16 range guard: largest |output| of this lane
   if (p.relu & 16) {
     __syncthreads();  // the K loop's LDS buffers are dead: the output tile is transposed through them
     float* Cs = (float*)smem;
@@ -407,14 +408,15 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_kernel(ConvK p) {
 #pragma unroll
       for (int tm = 0; tm < MT; ++tm) {
         if (p.relu & 1)
-          conv_stage_tile_pk<BN, true>(Cs, accm[tm][tn], accc[tm][tn], LO_INV, bv, wm * 2 * MT + tm * 2, kh, cl);
+          conv_stage_tile_pk<BN, true>(Cs, accm[tm][tn], accc[tm][tn], LO_INV, bv, wm * 2 * MT + tm * 2, kh, cl, amax);
         else
-          conv_stage_tile_pk<BN, false>(Cs, accm[tm][tn], accc[tm][tn], LO_INV, bv, wm * 2 * MT + tm * 2, kh, cl);
+          conv_stage_tile_pk<BN, false>(Cs, accm[tm][tn], accc[tm][tn], LO_INV, bv, wm * 2 * MT + tm * 2, kh, cl, amax);
       }
     }
     __syncthreads();
     conv_flush_tile<BN, 512>(Cs, tid, ty0, tx0, H, W, b, ct * BN, gout, p.out_stride, mem.pool, p.pool_stride,
                              !(p.relu & 8), (p.relu & 32) != 0, (p.relu & 64) != 0);
+    conv_raise_range_flag(p.range_flag, amax);
 #ifdef SHF_CONV_TIMING
     if (p.dbg && tid == 0 && (bid == 0 || bid == 100))
       printf("[f16x3 8w] blk%d epilogue %llu\n", bid, (unsigned long long)__builtin_amdgcn_s_memtime() - t_end8);
@@ -429,9 +431,10 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_kernel(ConvK p) {
     for (int tm = 0; tm < MT; ++tm) {
       const f32x16 am = accm[tm][tn], ac = accc[tm][tn];
       conv_store_tile([&](int r) { return am[r] + ac[r] * LO_INV; }, bv, p.relu, ty0 + wm * 2 * MT + tm * 2, tx0, kh,
-                      H, W, b, cout, gout, p.out_stride, mem.pool, p.pool_stride);
+                      H, W, b, cout, gout, p.out_stride, mem.pool, p.pool_stride, &amax);
     }
   }
+  conv_raise_range_flag(p.range_flag, amax);
 }
 
 // One-wave-per-SIMD variant for Cout % 128 == 0: block = 256 threads = 4 waves (2 M x 2 N), each wave
@@ -733,6 +736,7 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4_kernel(ConvK p) {
   const unsigned long long t_loop_end = __builtin_amdgcn_s_memtime();
 #endif
 
+  float amax = 0.f;  // fp16 range guard: largest |output| of this lane
   if (p.relu & 16) {
     __syncthreads();  // the K loop's LDS buffers are dead: the output tile is transposed through them
     float* Cs = (float*)smem;
@@ -743,9 +747,9 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4_kernel(ConvK p) {
 #pragma unroll
       for (int tm = 0; tm < MT; ++tm) {
         if (p.relu & 1)
-          conv_stage_tile_pk<BN, true>(Cs, accm[tm][tn], accc[tm][tn], LO_INV, bv, wm * 2 * MT + tm * 2, kh, cl);
+          conv_stage_tile_pk<BN, true>(Cs, accm[tm][tn], accc[tm][tn], LO_INV, bv, wm * 2 * MT + tm * 2, kh, cl, amax);
         else
-          conv_stage_tile_pk<BN, false>(Cs, accm[tm][tn], accc[tm][tn], LO_INV, bv, wm * 2 * MT + tm * 2, kh, cl);
+          conv_stage_tile_pk<BN, false>(Cs, accm[tm][tn], accc[tm][tn], LO_INV, bv, wm * 2 * MT + tm * 2, kh, cl, amax);
       }
     }
 #ifdef SHF_CONV_TIMING_STEPS
@@ -771,10 +775,11 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4_kernel(ConvK p) {
       for (int tm = 0; tm < MT; ++tm) {
         const f32x16 am = accm[tm][tn], ac = accc[tm][tn];
         conv_store_tile([&](int r) { return am[r] + ac[r] * LO_INV; }, bv, p.relu, ty0 + wm * 2 * MT + tm * 2, tx0,
-                        kh, H, W, b, cout, gout, p.out_stride, mem.pool, p.pool_stride);
+                        kh, H, W, b, cout, gout, p.out_stride, mem.pool, p.pool_stride, &amax);
       }
     }
   }
+  conv_raise_range_flag(p.range_flag, amax);
 #ifdef SHF_CONV_TIMING
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   const unsigned long long t_exit = __builtin_amdgcn_s_memtime(), r_exit = __builtin_amdgcn_s_memrealtime();
@@ -866,6 +871,7 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
   const unsigned long long t_dma = __builtin_amdgcn_s_memtime();
 #endif
 
+  float amax1 = 0.f;  // fp16 range guard for conv1_1's outputs (split right here, never seen by another epilogue)
   {  // prologue, all eight waves: conv1_1 + ReLU of the whole halo tile ON THE MATRIX CORES
     // [324 halo px x 27 taps (padded to 32)] x [32 x 64 couts] as split-fp16 MFMAs: 11 row tiles of 32 pixels,
     // 12 MFMAs each; a lane builds its A fragments (pixel lane&31, 8 taps) from the LDS image patch, the B
@@ -941,6 +947,7 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
           const int hq = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh1;
           // valid[]: 0 outside the image (conv1_2's zero padding, not conv1_1 evaluated out there)
           const float v = ok[r] ? fmaxf(cm[r] + cc[r] * LO_INV + bias, 0.f) : 0.f;
+          amax1 = fmaxf(amax1, v);
           const _Float16 h = (_Float16)v;
           *(_Float16*)(At + hq * ROWB) = h;
           *(_Float16*)(At + hq * ROWB + 64) = (_Float16)((v - (float)h) * LO_SCALE);
@@ -1036,6 +1043,7 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
   // epilogue: transposed through LDS (conv_common.h), all 512 threads flush
   __syncthreads();
   float* Cs = (float*)smem;
+  float amax = amax1;  // fp16 range guard: conv1_1's outputs (prologue) and this layer's
   if (consumer) {
 #pragma unroll
     for (int tn = 0; tn < 2; ++tn) {
@@ -1044,15 +1052,16 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
 #pragma unroll
       for (int tm = 0; tm < MT; ++tm) {
         if (p.relu & 1)
-          conv_stage_tile_pk<BN, true>(Cs, accm[tm][tn], accc[tm][tn], LO_INV, bv, wm * 2 * MT + tm * 2, kh, cl);
+          conv_stage_tile_pk<BN, true>(Cs, accm[tm][tn], accc[tm][tn], LO_INV, bv, wm * 2 * MT + tm * 2, kh, cl, amax);
         else
-          conv_stage_tile_pk<BN, false>(Cs, accm[tm][tn], accc[tm][tn], LO_INV, bv, wm * 2 * MT + tm * 2, kh, cl);
+          conv_stage_tile_pk<BN, false>(Cs, accm[tm][tn], accc[tm][tn], LO_INV, bv, wm * 2 * MT + tm * 2, kh, cl, amax);
       }
     }
   }
   __syncthreads();
   conv_flush_tile<BN, 512>(Cs, tid, ty0, tx0, H, W, b, 0, gout, p.out_stride, mem.pool, p.pool_stride, !(p.relu & 8),
                            (p.relu & 32) != 0, (p.relu & 64) != 0);
+  conv_raise_range_flag(p.range_flag, amax);
   PC_T();
 #ifdef SHF_CONV_TIMING
   if (bid == 100 && lane == 0 && (wave == 0 || wave == 4 || wave == 7))
@@ -1135,6 +1144,7 @@ static int launch_f16x3_t(const ConvArgs* as, int n, hipStream_t s) {
   p.nmem = n;
   for (int i = 0; i < MAX_GROUP; ++i) p.tile_starts[i] = 0x7fffffff;
   p.dbg = nullptr;
+  p.range_flag = a.range_flag;
   p.w1t = a.w1t;
   p.w1f = a.w1f;
   p.b1 = a.b1;

@@ -59,7 +59,8 @@ int launch_maxpool(const View& in, const View& out, int k, int stride, int pad, 
 // flat 64-bit div/mod chain of a grid-stride loop cost more than the memory traffic).
 __global__ void deconv_dw_kernel(const float* __restrict__ in, const float* __restrict__ w,
                                  const float* __restrict__ bias, float* __restrict__ out, int B, int H, int W, int C,
-                                 int Ho, int Wo, int k, int stride, int pad, int in_stride, int out_stride) {
+                                 int Ho, int Wo, int k, int stride, int pad, int in_stride, int out_stride,
+                                 int* range_flag) {
   const unsigned C4 = (unsigned)C >> 2;
   const unsigned n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= (unsigned)Wo * C4) return;
@@ -86,10 +87,13 @@ __global__ void deconv_dw_kernel(const float* __restrict__ in, const float* __re
   if (bias)
     for (int j = 0; j < 4; ++j) acc[j] += bias[c4 * 4 + j];
   *(float4*)(out + ((size_t)(b * Ho + oy) * Wo + ox) * out_stride + c4 * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+  // split-fp16 mode: the consumer of this map splits it to fp16 hi/lo -- raise the range flag beyond 65504
+  if (range_flag && !(fmaxf(fmaxf(fabsf(acc[0]), fabsf(acc[1])), fmaxf(fabsf(acc[2]), fabsf(acc[3]))) <= 65504.0f))
+    atomicOr(range_flag, 1);
 }
 
 int launch_deconv_depthwise(const View& in, const View& out, const float* w, const float* bias, int k, int stride,
-                            int pad, hipStream_t s) {
+                            int pad, hipStream_t s, int* range_flag) {
   if (in.C % 4 || in.cstride % 4 || in.coff % 4 || out.cstride % 4 || out.coff % 4) {
     set_error("deconv: channel count / views must be multiples of 4");
     return -1;
@@ -97,7 +101,7 @@ int launch_deconv_depthwise(const View& in, const View& out, const float* w, con
   const unsigned per_row = (unsigned)out.W * (unsigned)(in.C / 4);
   hipLaunchKernelGGL(deconv_dw_kernel, dim3((per_row + 255) / 256, out.H, out.B), dim3(256), 0, s, in.p + in.coff, w,
                      bias, out.p + out.coff, in.B, in.H, in.W, in.C, out.H, out.W, k, stride, pad, in.cstride,
-                     out.cstride);
+                     out.cstride, range_flag);
   SHF_HIP_OK(hipGetLastError());
   return 0;
 }

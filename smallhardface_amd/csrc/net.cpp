@@ -369,7 +369,25 @@ static int conv_out(int n, int k, int pad, int stride, int dil) {
 
 using namespace shf;
 
+// configuration shared by a net and every lane cloned from it: the arithmetic mode and what the reference's Python
+// layer reads from the global cfg at every forward (lib/layers/proposal_layer.py:88-92)
+struct NetShared {
+  int conv_mode = 0;  // 0: exact fp32 MFMA everywhere; 1: split-fp16 MFMA (fp32-class accuracy)
+  int pre_nms_topN = 10000;
+  float score_thresh = 0.002f, min_size = 0.f;
+  bool weights_exceed_f16 = false;  // some conv weight is outside the fp16 range: split-fp16 mode refuses to run
+  long long range_fallbacks = 0;    // forwards re-run on the exact fp32 kernels after a split-fp16 range overflow
+};
+
 struct shf_net {
+  std::shared_ptr<NetShared> sh;
+  int& conv_mode;
+  int& pre_nms_topN;
+  float& score_thresh;
+  float& min_size;
+  explicit shf_net(std::shared_ptr<NetShared> shared = nullptr)
+      : sh(shared ? shared : std::make_shared<NetShared>()), conv_mode(sh->conv_mode), pre_nms_topN(sh->pre_nms_topN),
+        score_thresh(sh->score_thresh), min_size(sh->min_size) {}
   std::shared_ptr<PMsg> root;
   std::deque<Blob> blobs;
   std::vector<Layer> layers;
@@ -401,11 +419,10 @@ struct shf_net {
   std::vector<hipStream_t> tail_pool;  // head-owned streams the detection tails of a group pass fan out over
   std::vector<hipEvent_t> tail_pool_ev;
   shf_net* pred = nullptr;         // shf_net_set_predecessor: the head lane whose image precedes this one's
-  int conv_mode = 0;  // 0: exact fp32 MFMA everywhere; 1: split-fp16 MFMA for the 3x3 / dilation-1 layers
+  int* flag_ptr = nullptr;  // the flag this net's kernels raise: its own, or the head's during a grouped pass
+  DevBuf range_flag;  // device int: raised by a split-fp16 conv epilogue that produced |x| > 65504 (fp16 hi overflows)
   TailWork tw;
   DevBuf tw_logits, tw_rec, tw_keys, tw_counters;
-  int pre_nms_topN = 10000;
-  float score_thresh = 0.002f, min_size = 0.f;
   bool materialize_tail = true;
   std::vector<int> last_data_shape;
   // fused per-image path
@@ -471,8 +488,9 @@ static int geti(const PMsg* m, const char* n, int d) { return m ? (int)m->num(n,
 
 void shf_net::build(const std::string& text, const char* caffemodel) {
   proto_text = text;
-  if (clone_src) conv_mode = clone_src->conv_mode;
-  else if (getenv("SHF_CONV_MODE")) conv_mode = atoi(getenv("SHF_CONV_MODE"));
+  if (!clone_src && getenv("SHF_CONV_MODE")) conv_mode = atoi(getenv("SHF_CONV_MODE"));
+  range_flag.ensure(64);
+  HIP_THROW(hipMemset(range_flag.p, 0, 64));
   TextParser tp(proto_text);
   root = tp.parse();
   HIP_THROW(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
@@ -832,10 +850,6 @@ void shf_net::build(const std::string& text, const char* caffemodel) {
   alloc_buffers();
   if (clone_src) {
     wgen = clone_src->wgen;
-    pre_nms_topN = clone_src->pre_nms_topN;
-    score_thresh = clone_src->score_thresh;
-    min_size = clone_src->min_size;
-    alloc_buffers();
     return;
   }
   if (caffemodel && caffemodel[0]) load_caffemodel(caffemodel);
@@ -969,7 +983,8 @@ void shf_net::build_tail_weights() {
 void shf_net::commit_params(int li) {
   Layer& L = layers[li];
   if (L.params.empty()) return;
-  HIP_THROW(hipStreamSynchronize(stream));
+  // the raw / packed tensors are shared by every lane cloned from this net: nothing may be in flight on any stream
+  HIP_THROW(hipDeviceSynchronize());
   const bool in_tail = std::count(tail_cls_layers.begin(), tail_cls_layers.end(), li) ||
                        std::count(tail_box_layers.begin(), tail_box_layers.end(), li);
   for (size_t pi = 0; pi < L.params.size(); ++pi) {
@@ -997,6 +1012,12 @@ void shf_net::commit_params(int li) {
       p.packed.ensure(packed.size() * 4);
       HIP_THROW(hipMemcpy(p.packed.p, packed.data(), packed.size() * 4, hipMemcpyHostToDevice));
       if (conv_mode == 1 && conv_f16x3_eligible(p.shape[1], p.shape[0], L.k, L.pad, L.dil)) {
+        // split-fp16 keeps hi = fp16(w): a weight beyond the fp16 range would become inf (the reference is fp32
+        // everywhere, caffe/python/caffe/_caffe.cpp:46-48) -- refuse the mode instead of computing garbage
+        for (float w : p.host)
+          if (!(std::fabs(w) <= 65504.f))
+            throw std::runtime_error("layer '" + L.name + "': a weight is outside the fp16 range (|w| > 65504 or not "
+                                     "finite); the split-fp16 conv mode cannot represent it -- use conv mode fp32");
         std::vector<uint16_t> sp(split16_conv_weight_halfs(p.shape[0], p.shape[1], p.shape[2]));
         pack_conv_weights_split16(p.host.data(), p.shape[0], p.shape[1], p.shape[2], sp.data());
         p.packed16.ensure(sp.size() * 2);
@@ -1060,6 +1081,8 @@ void shf_net::forward_ops(bool fused_path, float im_h, float im_w, float im_scal
           a.write_main = L.pool_only ? 0 : 1;
           a.pool_split = split16 && blobs[layers[L.fuse_pool].tops[0]].split_fused;
         }
+        // split-fp16 mode: every producer of a map that a split-fp16 conv may read guards the fp16 range
+        a.range_flag = conv_mode == 1 ? (flag_ptr ? flag_ptr : (int*)range_flag.p) : nullptr;
         if (fused_path && split16) {
           a.in_split = ib.split_fused;
           a.out_split = blobs[L.tops[0]].split_fused;
@@ -1111,7 +1134,8 @@ void shf_net::forward_ops(bool fused_path, float im_h, float im_w, float im_scal
                      4.0 * (blobs[L.bottoms[0]].count() + blobs[L.tops[0]].count()));
         CHECK_RC(launch_deconv_depthwise(view_of(L.bottoms[0]), view_of(L.tops[0]), (const float*)L.params[0]->raw.p,
                                          L.params.size() > 1 ? (const float*)L.params[1]->raw.p : nullptr, L.k,
-                                         L.stride, L.pad, st));
+                                         L.stride, L.pad, st,
+                                         conv_mode == 1 ? (flag_ptr ? flag_ptr : (int*)range_flag.p) : nullptr));
         break;
       }
       case OP_TAIL: {
@@ -1131,6 +1155,7 @@ void shf_net::forward_ops(bool fused_path, float im_h, float im_w, float im_scal
           t.cls_prob_reshape_nchw = (float*)blobs[tail_cls_blob].dev.p;
           t.bbox_pred_nchw = (float*)blobs[tail_box_blob].dev.p;
         }
+        ensure_tail_workspace((size_t)t.h * t.w * tail_A);  // pre_nms_topN is shared with the other lanes and may have grown
         const double K = (double)t.h * t.w;
         ProfScope ps(pf, st, PC_TAIL, 2.0 * K * tail_A * 6 * tail_Cf,
                      4.0 * K * (tail_heads * tail_Cf + tail_A * 18));
@@ -1161,19 +1186,37 @@ void shf_net::forward() {
   float ii[3] = {0, 0, 1};
   if (im_info_blob >= 0 && blobs[im_info_blob].host.p && blobs[im_info_blob].count() >= 3)
     memcpy(ii, blobs[im_info_blob].host.p, 12);
-  forward_ops(false, ii[0], ii[1], ii[2]);
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    if (conv_mode == 1) HIP_THROW(hipMemsetAsync(range_flag.p, 0, 4, stream));
+    forward_ops(false, ii[0], ii[1], ii[2]);
+    int cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, flag = 0;
+    if (tail_layer >= 0) HIP_THROW(hipMemcpyAsync(cnt, tw.counters, sizeof(cnt), hipMemcpyDeviceToHost, stream));
+    if (conv_mode == 1) HIP_THROW(hipMemcpyAsync(&flag, range_flag.p, 4, hipMemcpyDeviceToHost, stream));
+    HIP_THROW(hipStreamSynchronize(stream));
+    if (flag && conv_mode == 1) {
+      // a convolution produced |x| > 65504: fp16(hi) of the split overflowed somewhere downstream.  The reference
+      // computes in fp32 (_caffe.cpp:46-48): redo THIS forward on the exact fp32 matrix-core kernels.
+      ++sh->range_fallbacks;
+      conv_mode = 0;
+      try {
+        forward_ops(false, ii[0], ii[1], ii[2]);
+        if (tail_layer >= 0) HIP_THROW(hipMemcpyAsync(cnt, tw.counters, sizeof(cnt), hipMemcpyDeviceToHost, stream));
+        HIP_THROW(hipStreamSynchronize(stream));
+      } catch (...) {
+        conv_mode = 1;
+        throw;
+      }
+      conv_mode = 1;
+    }
+    if (tail_layer >= 0) {
+      const int R = cnt[2];
+      blobs[boxes_blob].shape = {std::max(R, 1), 5};
+      if (prob_blob >= 0) blobs[prob_blob].shape = {R, 2};
+    }
+    break;
+  }
   for (size_t i = 0; i < blobs.size(); ++i)
     if (!std::count(inputs.begin(), inputs.end(), (int)i) && blobs[i].kind != BK_FUSED) blobs[i].dev_newer = true;
-  if (tail_layer >= 0) {
-    int cnt[8];
-    HIP_THROW(hipMemcpyAsync(cnt, tw.counters, sizeof(cnt), hipMemcpyDeviceToHost, stream));
-    HIP_THROW(hipStreamSynchronize(stream));
-    const int R = cnt[2];
-    blobs[boxes_blob].shape = {std::max(R, 1), 5};
-    if (prob_blob >= 0) blobs[prob_blob].shape = {R, 2};
-  } else {
-    HIP_THROW(hipStreamSynchronize(stream));
-  }
 }
 
 float* shf_net::host_data(int bi) {
@@ -1266,7 +1309,7 @@ shf_net* shf_net_create(const char* prototxt_path, const char* prototxt_text, co
 
 shf_net* shf_net_clone(shf_net* src) {
   API_BEGIN
-  std::unique_ptr<shf_net> net(new shf_net());
+  std::unique_ptr<shf_net> net(new shf_net(src->sh));
   net->phase = src->phase;
   net->clone_src = src;
   net->build(src->proto_text, nullptr);
@@ -1369,13 +1412,28 @@ int shf_net_set_proposal_cfg(shf_net* net, int pre_nms_topN, float score_thresh,
 int shf_net_set_conv_mode(shf_net* net, int mode) {
   API_BEGIN
   if (mode != 0 && mode != 1) throw std::runtime_error("conv mode must be 0 (fp32) or 1 (split-fp16)");
-  if (net->conv_mode != mode) {
-    net->conv_mode = mode;
-    for (size_t li = 0; li < net->layers.size(); ++li) net->commit_params((int)li);
+  if (net->conv_mode == mode) return 0;
+  HIP_THROW(hipDeviceSynchronize());  // the mode is shared with every lane: nothing may be in flight while it flips
+  net->conv_mode = mode;
+  if (mode == 1) {
+    // the fp32 packs always exist; the split-fp16 packs are made on first use (and re-made by every commit)
+    try {
+      for (size_t li = 0; li < net->layers.size(); ++li) {
+        Layer& L = net->layers[li];
+        if (L.type == "Convolution" && L.kclass == 0 && !L.params.empty() && !L.params[0]->packed16.p &&
+            conv_f16x3_eligible(L.params[0]->shape[1], L.params[0]->shape[0], L.k, L.pad, L.dil))
+          net->commit_params((int)li);
+      }
+    } catch (...) {
+      net->conv_mode = 0;  // e.g. a weight outside the fp16 range: stay on the exact kernels
+      throw;
+    }
   }
   return 0;
   API_END(-1)
 }
+
+long long shf_net_range_fallbacks(shf_net* net) { return net->sh->range_fallbacks; }
 
 int shf_net_record_event(shf_net* net) {
   API_BEGIN
@@ -1399,9 +1457,22 @@ int shf_net_set_predecessor(shf_net* net, shf_net* prev) {
   API_END(-1)
 }
 
+// fused path: has a split-fp16 convolution enqueued on `net` (as head of a pass) left the fp16 range?  Synchronises.
+static const char* kRangeMsg =
+    "split-fp16 range exceeded: a convolution output has |x| > 65504 (fp16 hi overflows); this image must be "
+    "re-run with conv mode fp32";
+static void throw_if_out_of_range(shf_net* net) {
+  if (net->conv_mode != 1) return;
+  int flag = 0;
+  HIP_THROW(hipMemcpyAsync(&flag, net->range_flag.p, 4, hipMemcpyDeviceToHost, net->stream));
+  HIP_THROW(hipStreamSynchronize(net->stream));
+  if (flag) throw std::runtime_error(kRangeMsg);
+}
+
 int shf_detect_begin(shf_net* net) {
   API_BEGIN
   if (net->tail_layer < 0) throw std::runtime_error("net has no proposal layer");
+  HIP_THROW(hipMemsetAsync(net->range_flag.p, 0, 4, net->stream));
   net->img_count.ensure(64);
   HIP_THROW(hipMemsetAsync(net->img_count.p, 0, 64, net->stream));
   net->img_units = 0;
@@ -1527,6 +1598,12 @@ int shf_detect_add_levels(shf_net* net, int n, shf_net** members, const float* c
     if (!early_start && members[m]->ev_logits) HIP_THROW(hipStreamWaitEvent(net->stream, members[m]->ev_logits, 0));
     members[m]->prepare_unit(data[m], data_on_device, H[m], W[m], net->stream);
   }
+  if (per_member_lists) HIP_THROW(hipMemsetAsync(net->range_flag.p, 0, 4, net->stream));  // no detect_begin on this path
+  struct FlagScope {  // one range flag per pass: the head's
+    shf_net** mb; int n;
+    FlagScope(shf_net** m, int n_, int* f) : mb(m), n(n_) { for (int i = 0; i < n; ++i) mb[i]->flag_ptr = f; }
+    ~FlagScope() { for (int i = 0; i < n; ++i) mb[i]->flag_ptr = nullptr; }
+  } flag_scope(members, n, (int*)net->range_flag.p);
   std::vector<ConvArgs> group(n);
   for (size_t li = 0; li < net->layers.size(); ++li) {
     Layer& L = net->layers[li];
@@ -1653,19 +1730,26 @@ int shf_detect_add_levels(shf_net* net, int n, shf_net** members, const float* c
   API_END(-1)
 }
 
+// rows gathered so far + (same synchronisation) the split-fp16 range flag of the passes enqueued on `net`
+static int detect_count_checked(shf_net* net, bool check_range) {
+  int c[2] = {0, 0}, flag = 0;
+  HIP_THROW(hipMemcpyAsync(c, net->img_count.p, 8, hipMemcpyDeviceToHost, net->stream));
+  if (check_range && net->conv_mode == 1)
+    HIP_THROW(hipMemcpyAsync(&flag, net->range_flag.p, 4, hipMemcpyDeviceToHost, net->stream));
+  HIP_THROW(hipStreamSynchronize(net->stream));
+  if (flag) throw std::runtime_error(kRangeMsg);
+  return c[net->img_units & 1];
+}
+
 int shf_detect_count(shf_net* net) {
   API_BEGIN
-  int c[2] = {0, 0};
-  HIP_THROW(hipMemcpyAsync(c, net->img_count.p, 8, hipMemcpyDeviceToHost, net->stream));
-  HIP_THROW(hipStreamSynchronize(net->stream));
-  return c[net->img_units & 1];
+  return detect_count_checked(net, false);
   API_END(-1)
 }
 
 int shf_detect_export(shf_net* net, float* dst_dev5, int cap_rows, int* n_rows) {
   API_BEGIN
-  const int n = shf_detect_count(net);
-  if (n < 0) return -1;
+  const int n = detect_count_checked(net, true);
   *n_rows = n;
   const int w = std::min(n, cap_rows);
   if (w > 0) {
@@ -1681,7 +1765,7 @@ int shf_detect_export_many(shf_net* net, int n, shf_net** members, float* const*
   API_BEGIN
   // after a per_member_lists pass: everything was enqueued on `net`'s stream -> one sync, then all
   // counts, then the row copies, then one more sync
-  HIP_THROW(hipStreamSynchronize(net->stream));
+  throw_if_out_of_range(net);  // (synchronises net's stream)
   for (int m = 0; m < n; ++m) {
     int c[2] = {0, 0};
     HIP_THROW(hipMemcpyAsync(c, members[m]->img_count.p, 8, hipMemcpyDeviceToHost, net->stream));
@@ -1729,9 +1813,8 @@ int shf_detect_import(shf_net* net, const float* src_dev5, int n_rows) {
 
 int shf_detect_finish(shf_net* net, int method, float nms_thresh, double* out5, int cap, int* n_out) {
   API_BEGIN
-  const int n = shf_detect_count(net);
-  if (n < 0) return -1;
   *n_out = 0;
+  const int n = detect_count_checked(net, true);
   if (n == 0) {
     if (method == 0) {  // bbox_vote on an empty set (test.py:184-186)
       const double d[5] = {10, 10, 20, 20, 0.0001};

@@ -44,6 +44,7 @@ struct ConvArgs {
   // convs is stored as [pixel][32-channel chunk][hi 32 halfs | lo 32 halfs] -- the same 4 B per element, already
   // split, so the consumer's halo staging is a plain copy
   int in_split = 0, out_split = 0, pool_split = 0;
+  int* range_flag = nullptr;  // split-fp16 kernels raise it when an output leaves the fp16 range (net.cpp: fp32 re-run)
 };
 // which kernel class a conv will use: 0 = mfma implicit GEMM, 1 = first-layer direct (NCHW in), 2 = generic direct
 int conv_kernel_class(int Cin, int Cout, int k, int pad, int dil, bool in_nchw);
@@ -73,7 +74,7 @@ size_t packed_conv_weight_floats(int Cout, int Cin, int k);
 int launch_maxpool(const View& in, const View& out, int k, int stride, int pad, hipStream_t s);
 // depthwise transposed conv (group == C), weights (C,1,k,k) Caffe layout
 int launch_deconv_depthwise(const View& in, const View& out, const float* w, const float* bias, int k,
-                            int stride, int pad, hipStream_t s);
+                            int stride, int pad, hipStream_t s, int* range_flag = nullptr);
 int launch_copy_view(const View& in, const View& out, hipStream_t s);       // concat fallback
 int launch_nhwc_to_nchw(const View& in, float* out_nchw, hipStream_t s);    // blob.data read-back
 int launch_nchw_to_nhwc(const float* in_nchw, const View& out, hipStream_t s);

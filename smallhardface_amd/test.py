@@ -23,7 +23,7 @@ import sys
 
 import numpy as np
 
-from . import caffe
+from . import _lib, caffe
 from .config import cfg
 from .nms import bbox_vote, nms
 from .test_utils import _compute_scaling_factor, _get_image_blob, pyramid_scales
@@ -244,34 +244,79 @@ class FusedDetector(object):
         same stream: DevicePyramid.units(im, net=fd.next_head()))."""
         if not hasattr(self, "_heads"):
             self._heads = [self.net.clone(), self.net.clone()]
-            self._heads[0].set_predecessor(self._heads[1])
-            self._heads[1].set_predecessor(self._heads[0])
+            # SHF_PIPE_OVERLAP=1 (experiment): each head owns a full lane set, so the two images in flight share no
+            # buffers and their kernels are free to overlap (tail rounds of one grid filled by the other image's
+            # blocks); default: one lane set, image k+1's convolutions queue behind image k's
+            self._overlap = os.environ.get("SHF_PIPE_OVERLAP", "0") == "1"
+            if self._overlap:
+                self._lane_sets = [self.lanes, [self.net.clone() for _ in self.lanes]]
+            else:
+                self._heads[0].set_predecessor(self._heads[1])
+                self._heads[1].set_predecessor(self._heads[0])
             self._turn = 0
             self._inflight = []
         return self._heads[self._turn]
+
+    # -- fp16 range guard of the split-fp16 mode: a pass whose convolutions left the fp16 range fails in
+    #    detect_finish with a distinct message (C ABI shf_net_range_fallbacks); the image is then redone on the
+    #    exact fp32 kernels -- the reference computes in fp32 everywhere -- never a silent inf/NaN.
+    range_fallbacks = 0
+
+    @staticmethod
+    def _is_range_error(e):
+        return "split-fp16 range exceeded" in str(e)
+
+    def _redo_fp32(self, units, thresh, on_device):
+        self.range_fallbacks += 1
+        logger.warning("split-fp16 range exceeded: image redone on the exact fp32 kernels")
+        self.net.set_conv_mode("fp32")      # shared by every lane
+        try:
+            return self.detect(units, thresh, on_device=on_device)
+        finally:
+            self.net.set_conv_mode("f16x3")
 
     def submit(self, units, thresh=0.05, on_device=False):
         units = list(units)
         assert self.mode == "group" and len(units) <= 16
         head = self.next_head()
-        while len(self.lanes) < len(units):
-            self.lanes.append(self.net.clone())
+        lanes = self._lane_sets[self._turn] if self._overlap else self.lanes
+        while len(lanes) < len(units):
+            lanes.append(self.net.clone())
         head.detect_begin()
         # no wait here: add_levels starts as soon as the previous image's logits kernels have consumed
         # the member lanes' feature maps and only awaits its appends before this image's own tails
-        head.detect_add_levels(self.lanes[:len(units)], units, thresh, on_device=on_device)
+        head.detect_add_levels(lanes[:len(units)], units, thresh, on_device=on_device)
         head.record_event()
-        self._inflight.append(head)
+        self._inflight.append((head, units, thresh, on_device))
         self._turn = 1 - self._turn
         return head
 
     def collect(self):
         """Detections of the oldest submitted image (blocks until its merge is done)."""
-        head = self._inflight.pop(0)
-        return [head.detect_finish(cfg.TEST.NMS_METHOD, cfg.TEST.NMS_THRESH)]
+        if getattr(self, "_done", None):
+            return self._done.pop(0)
+        head, units, thresh, on_device = self._inflight.pop(0)
+        try:
+            return [head.detect_finish(cfg.TEST.NMS_METHOD, cfg.TEST.NMS_THRESH)]
+        except _lib.ShfError as e:
+            if not self._is_range_error(e):
+                raise
+        # drain what is in flight (the redo reuses the lanes' buffers), then redo the flagged image(s) exactly
+        rest = []
+        while self._inflight:
+            h, u, t, od = self._inflight.pop(0)
+            try:
+                rest.append([h.detect_finish(cfg.TEST.NMS_METHOD, cfg.TEST.NMS_THRESH)])
+            except _lib.ShfError as e:
+                if not self._is_range_error(e):
+                    raise
+                rest.append((u, t, od))
+        out = self._redo_fp32(units, thresh, on_device)
+        self._done = [r if isinstance(r, list) else self._redo_fp32(*r) for r in rest]
+        return out
 
     def pending(self):
-        return len(getattr(self, "_inflight", []))
+        return len(getattr(self, "_inflight", [])) + len(getattr(self, "_done", None) or [])
 
     def detect(self, units, thresh=0.05, on_device=False):
         """``units``: list of (data, H, W, im_h, im_w, scale, flip); data = host array or device pointer."""
@@ -284,7 +329,12 @@ class FusedDetector(object):
             for a in range(0, len(units), 16):
                 chunk = units[a:a + 16]
                 head.detect_add_levels(self.lanes[:len(chunk)], chunk, thresh, on_device=on_device)
-            return [head.detect_finish(cfg.TEST.NMS_METHOD, cfg.TEST.NMS_THRESH)]
+            try:
+                return [head.detect_finish(cfg.TEST.NMS_METHOD, cfg.TEST.NMS_THRESH)]
+            except _lib.ShfError as e:
+                if not self._is_range_error(e):
+                    raise
+            return self._redo_fp32(units, thresh, on_device)
         ranges = lane_ranges([u[1] * u[2] for u in units], len(self.lanes))
         used = []
         # issue the most expensive ranges first
