@@ -13,8 +13,8 @@ from tests.test_gpu_parity import conv_layer
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("scale,expect_fallback", [(1.0, False), (3.0e4, True)])
-def test_forward_with_activations_beyond_fp16_range(scale, expect_fallback):
+@pytest.mark.parametrize("target,expect_fallback", [(None, False), (3.0e5, True)])
+def test_forward_with_activations_beyond_fp16_range(target, expect_fallback):
     """c0 -> c1 -> pool -> c2 with inputs scaled so that c0's outputs reach ~1e5: Net.forward() in split-fp16 mode
     still matches the oracle (the forward is redone on the fp32 kernels) and says so."""
     h, w = 40, 56
@@ -24,7 +24,12 @@ def test_forward_with_activations_beyond_fp16_range(scale, expect_fallback):
         conv_layer("c2", "p", 128, 3, 1), 3, h, w)
     gnet, onet = H.make_pair(P.parse(txt), seed=11)
     gnet.set_conv_mode("f16x3")
-    data = (np.random.default_rng(2).normal(0, 1, (1, 3, h, w)) * scale).astype(np.float32)
+    data = np.random.default_rng(2).normal(0, 1, (1, 3, h, w)).astype(np.float32)
+    if target:   # scale the input so that c0's largest output is `target` (> 65504)
+        onet.blobs['data'].reshape(*data.shape)
+        onet.blobs['im_info'].reshape(1, 3)
+        onet.forward(data=data, im_info=np.array([[h, w, 1]], np.float32))
+        data = data * np.float32(target / np.abs(onet.blobs["c0"].data).max())
     before = gnet.range_fallbacks
     go, oo = H.run_both(gnet, onet, data, np.array([[h, w, 1]], np.float32))
     assert np.isfinite(go["c2"]).all()
