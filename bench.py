@@ -213,6 +213,7 @@ def main():
         export_sets = [export, [torch.empty_like(e) for e in export]]
         mine_units = [(units[k][0].data_ptr(),) + units[k][1:] for k in mine]
     state = {"k": 0, "pending": None, "collectives": 0}
+    host_trace = [] if os.environ.get("SHF_BENCH_HOST_TRACE") == "1" else None   # diagnostics: where the host waits
 
     def finish_window(w):
         ls, ex = lane_sets[w], export_sets[w]
@@ -243,9 +244,15 @@ def main():
             elif args.host_input == "image":
                 fd.submit(dp.units(host_im, net=fd.next_head()), thresh, on_device=True)
             else:
+                if host_trace is not None:
+                    host_trace.append(("submit>", time.perf_counter()))
                 fd.submit(unit_list, thresh, on_device=True)
+                if host_trace is not None:
+                    host_trace.append(("submit<", time.perf_counter()))
             if fd.pending() > 1:
                 last[0] = fd.collect()[0]
+                if host_trace is not None:
+                    host_trace.append(("collect<", time.perf_counter()))
             return
         # this rank's units (from different images) as ONE grouped pass; every lane keeps the detections of its
         # unit, which are then routed to the unit's image
@@ -289,6 +296,9 @@ def main():
         step()
     fence()
     elapsed = time.perf_counter() - t0
+    if host_trace:
+        base = [t for k, t in host_trace if t >= t0][0]
+        print(" ".join("%s%.2f" % (k, 1000 * (t - base)) for k, t in host_trace if t >= t0)[:4000], file=sys.stderr)
     prof = {}
     if not args.no_events:
         for ln in lanes + getattr(fd, "_heads", []):

@@ -140,6 +140,13 @@ int shf_net_wait_event(shf_net* net, shf_net* other);
  * shf_net_record_event mark only before its own tails, which reuse the members' tail buffers.
  * prev = NULL clears it. */
 int shf_net_set_predecessor(shf_net* net, shf_net* prev);
+/* Image pipeline over head lanes, robust form: with enable != 0 the grouped passes of `net` put their convolutions
+ * and logits kernels on ONE in-order stream shared by the net and all its lanes (consecutive images queue behind
+ * each other, no cross-stream hand-over of the activation buffers), and only the rest of the tails, the appends and
+ * the merge run on `net`'s own stream, which is re-created with the highest stream priority so that its tiny kernels
+ * are dispatched beside the next image's convolutions.  Combine with shf_net_set_predecessor (the members' tail
+ * workspaces are handed from head to head). */
+int shf_net_set_pipeline(shf_net* net, int enable);
 /* Box merging for the image (test.py:168-175): method 0 = BBOX_VOTE (test.py:181),
  * 1 = NMS (lib/nms).  out5 rows are (x1,y1,x2,y2,score) as double (bbox_vote
  * returns float64).  *n_out = number of rows (may exceed cap; only cap written). */

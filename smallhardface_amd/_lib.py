@@ -95,6 +95,7 @@ def _declare(lib):
         "shf_pyramid_level_shape": (ci, [ci, ci, C.c_double, ci, ip, ip, ip, ip]),
         "shf_make_pyramid_level": (ci, [vp, vp, ci, ci, C.c_double, ci, dp, vp, ci, ci, ci, ci]),
         "shf_net_set_predecessor": (ci, [vp, vp]),
+        "shf_net_set_pipeline": (ci, [vp, ci]),
         "shf_detect_finish": (ci, [vp, ci, cf, dp, ci, ip]),
         "shf_detect_count": (ci, [vp]),
         "shf_detect_export": (ci, [vp, vp, ci, ip]),

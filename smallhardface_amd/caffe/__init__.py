@@ -299,6 +299,10 @@ class Net(object):
         """Pipeline hand-over at logits granularity (C ABI shf_net_set_predecessor)."""
         _lib.check(self._lib.shf_net_set_predecessor(self._h, prev._h if prev is not None else None), "set_predecessor")
 
+    def set_pipeline(self, enable=True):
+        """Shared in-order conv stream + high-priority own stream for this head (C ABI shf_net_set_pipeline)."""
+        _lib.check(self._lib.shf_net_set_pipeline(self._h, 1 if enable else 0), "set_pipeline")
+
     def record_event(self):
         _lib.check(self._lib.shf_net_record_event(self._h), "record_event")
 

@@ -783,8 +783,9 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4_kernel(ConvK p) {
 #ifdef SHF_CONV_TIMING
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   const unsigned long long t_exit = __builtin_amdgcn_s_memtime(), r_exit = __builtin_amdgcn_s_memrealtime();
-  if (p.dbg && lane == 0 && (bid == 0 || bid == 100)) {
-    unsigned long long* d = p.dbg + ((bid ? 1 : 0) * 8 + wave) * 5;
+  // sampled blocks: two of the first round (every CU in its prologue at once) and two of later rounds
+  if (p.dbg && lane == 0 && wave < 4 && (bid == 0 || bid == 100 || bid == 700 || bid == 1500)) {
+    unsigned long long* d = p.dbg + ((bid == 0 ? 0 : bid == 100 ? 1 : bid == 700 ? 2 : 3) * 4 + wave) * 5;
     d[0] = tb; d[1] = ((t_loop - t_entry) << 32) | (t_exit - t_loop_end); d[2] = tc; d[3] = tx;
     d[4] = NST | ((t_exit - t_entry) << 16) | ((r_exit - r_entry) << 40);
 #ifdef SHF_CONV_TIMING_STEPS

@@ -377,6 +377,15 @@ struct NetShared {
   float score_thresh = 0.002f, min_size = 0.f;
   bool weights_exceed_f16 = false;  // some conv weight is outside the fp16 range: split-fp16 mode refuses to run
   long long range_fallbacks = 0;    // forwards re-run on the exact fp32 kernels after a split-fp16 range overflow
+  // image pipeline (shf_net_set_pipeline): ONE in-order stream carries the convolutions + logits kernels of every
+  // image; each head's own (high-priority) stream carries the rest of its image's tails, appends and the merge
+  hipStream_t conv_stream = nullptr;
+  ~NetShared() {
+    if (conv_stream) {
+      (void)hipStreamSynchronize(conv_stream);
+      (void)hipStreamDestroy(conv_stream);
+    }
+  }
 };
 
 struct shf_net {
@@ -419,6 +428,8 @@ struct shf_net {
   std::vector<hipStream_t> tail_pool;  // head-owned streams the detection tails of a group pass fan out over
   std::vector<hipEvent_t> tail_pool_ev;
   shf_net* pred = nullptr;         // shf_net_set_predecessor: the head lane whose image precedes this one's
+  bool pipelined = false;   // shf_net_set_pipeline: convolutions go to sh->conv_stream, the rest stays on `stream`
+  hipStream_t cstream() { return pipelined && sh->conv_stream ? sh->conv_stream : stream; }
   int* flag_ptr = nullptr;  // the flag this net's kernels raise: its own, or the head's during a grouped pass
   DevBuf range_flag;  // device int: raised by a split-fp16 conv epilogue that produced |x| > 65504 (fp16 hi overflows)
   TailWork tw;
@@ -1450,6 +1461,29 @@ int shf_net_wait_event(shf_net* net, shf_net* other) {
   API_END(-1)
 }
 
+int shf_net_set_pipeline(shf_net* net, int enable) {
+  API_BEGIN
+  if (!enable) {
+    net->pipelined = false;
+    return 0;
+  }
+  HIP_THROW(hipDeviceSynchronize());
+  if (!net->sh->conv_stream) HIP_THROW(hipStreamCreateWithFlags(&net->sh->conv_stream, hipStreamNonBlocking));
+  // this head's own stream carries ~100 tiny kernels per image beside the convolutions of the next image:
+  // highest priority, so the dispatcher never parks them behind a grid of thousands of workgroups
+  int least = 0, greatest = 0;
+  HIP_THROW(hipDeviceGetStreamPriorityRange(&least, &greatest));
+  if (greatest != least) {
+    hipStream_t hs = nullptr;
+    HIP_THROW(hipStreamCreateWithPriority(&hs, hipStreamNonBlocking, greatest));
+    (void)hipStreamDestroy(net->stream);
+    net->stream = hs;
+  }
+  net->pipelined = true;
+  return 0;
+  API_END(-1)
+}
+
 int shf_net_set_predecessor(shf_net* net, shf_net* prev) {
   API_BEGIN
   net->pred = prev;
@@ -1472,7 +1506,7 @@ static void throw_if_out_of_range(shf_net* net) {
 int shf_detect_begin(shf_net* net) {
   API_BEGIN
   if (net->tail_layer < 0) throw std::runtime_error("net has no proposal layer");
-  HIP_THROW(hipMemsetAsync(net->range_flag.p, 0, 4, net->stream));
+  if (!net->pipelined) HIP_THROW(hipMemsetAsync(net->range_flag.p, 0, 4, net->stream));
   net->img_count.ensure(64);
   HIP_THROW(hipMemsetAsync(net->img_count.p, 0, 64, net->stream));
   net->img_units = 0;
@@ -1552,9 +1586,9 @@ int shf_make_pyramid_level(shf_net* net, const uint8_t* im_bgr_dev, int im_h, in
   API_BEGIN
   if (!im_bgr_dev || !out_dev || !pixel_means) throw std::runtime_error("make_pyramid_level: null pointer");
   if (lvl_h > H || lvl_w > W || lvl_h < 1 || lvl_w < 1) throw std::runtime_error("make_pyramid_level: bad geometry");
-  ProfScope ps(net->prof, net->stream, PC_LAYOUT, 0, 15.0 * H * W);
+  ProfScope ps(net->prof, net->cstream(), PC_LAYOUT, 0, 15.0 * H * W);
   CHECK_RC(launch_pyramid_level(im_bgr_dev, im_h, im_w, scale, flip, pixel_means, out_dev, H, W, lvl_h, lvl_w,
-                                net->stream));
+                                net->cstream()));
   return 0;
   API_END(-1)
 }
@@ -1592,12 +1626,19 @@ int shf_detect_add_levels(shf_net* net, int n, shf_net** members, const float* c
     for (int t : net->layers[li].tops)
       for (int f : net->tail_feat_blobs)
         if (t == f && (int)li < first_feat_writer) first_feat_writer = (int)li;
-  const bool early_start = net->pred && net->pred->ev_convs && first_feat_writer < (int)net->layers.size();
+  // Pipelined heads (shf_net_set_pipeline): the convolutions and logits kernels of consecutive images share ONE
+  // in-order stream, so no cross-stream hand-over is needed for the activation buffers; only the rest of the tails,
+  // the appends and the merge run on this head's own stream, beside the next image's convolutions.
+  const bool shared = net->pipelined && net->sh->conv_stream && !per_member_lists;
+  hipStream_t cs = shared ? net->sh->conv_stream : net->stream;
+  const bool early_start = !shared && net->pred && net->pred->ev_convs && first_feat_writer < (int)net->layers.size();
   if (early_start) HIP_THROW(hipStreamWaitEvent(net->stream, net->pred->ev_convs, 0));
   for (int m = 0; m < n; ++m) {
-    if (!early_start && members[m]->ev_logits) HIP_THROW(hipStreamWaitEvent(net->stream, members[m]->ev_logits, 0));
-    members[m]->prepare_unit(data[m], data_on_device, H[m], W[m], net->stream);
+    if (!shared && !early_start && members[m]->ev_logits)
+      HIP_THROW(hipStreamWaitEvent(net->stream, members[m]->ev_logits, 0));
+    members[m]->prepare_unit(data[m], data_on_device, H[m], W[m], cs);
   }
+  if (shared) HIP_THROW(hipMemsetAsync(net->range_flag.p, 0, 4, cs));  // (detect_begin zeroes it on the head's stream)
   if (per_member_lists) HIP_THROW(hipMemsetAsync(net->range_flag.p, 0, 4, net->stream));  // no detect_begin on this path
   struct FlagScope {  // one range flag per pass: the head's
     shf_net** mb; int n;
@@ -1615,7 +1656,7 @@ int shf_detect_add_levels(shf_net* net, int n, shf_net** members, const float* c
       double fl = 0, by = 4.0 * L.params[0]->count();
       for (int m = 0; m < n; ++m) {
         shf_net* mb = members[m];
-        mb->forward_ops(true, (float)im_h[m], (float)im_w[m], im_scale[m], net->stream, &net->prof, (int)li,
+        mb->forward_ops(true, (float)im_h[m], (float)im_w[m], im_scale[m], cs, &net->prof, (int)li,
                         &group[m]);
         fl += conv_flops(mb->layers[li], mb->blobs[mb->layers[li].bottoms[0]].shape,
                          mb->blobs[mb->layers[li].tops[0]].shape);
@@ -1629,16 +1670,31 @@ int shf_detect_add_levels(shf_net* net, int n, shf_net** members, const float* c
             fl += conv_flops(F, mb->blobs[F.bottoms[0]].shape, mb->blobs[F.tops[0]].shape);
           }
         }
-        ProfScope ps(net->prof, net->stream,
-                     f16x3_prof_class(group[0], L.nout), fl,
-                     by);
-        CHECK_RC(launch_conv_f16x3_group(group.data(), n, net->stream));
+        ProfScope ps(net->prof, cs, f16x3_prof_class(group[0], L.nout), fl, by);
+        CHECK_RC(launch_conv_f16x3_group(group.data(), n, cs));
       } else {
         const int pc = conv_prof_class(L.k, L.dil, L.nout);
-        ProfScope ps(net->prof, net->stream, pc, fl, by);
-        CHECK_RC(launch_conv_mfma_group(group.data(), n, net->stream));
+        ProfScope ps(net->prof, cs, pc, fl, by);
+        CHECK_RC(launch_conv_mfma_group(group.data(), n, cs));
       }
-    } else if (L.op == OP_TAIL && n > 1) {
+    } else if (L.op == OP_TAIL && shared) {
+      // the members' tail workspaces were last used by the predecessor head's tails (its own stream)
+      if (net->pred && net->pred->ev_mark) HIP_THROW(hipStreamWaitEvent(cs, net->pred->ev_mark, 0));
+      for (int phase = 1; phase <= 2; ++phase) {
+        for (int m = 0; m < n; ++m) {
+          members[m]->tail_phase = phase;
+          members[m]->forward_ops(true, (float)im_h[m], (float)im_w[m], im_scale[m], phase == 1 ? cs : net->stream,
+                                  &net->prof, (int)li, nullptr);
+          members[m]->tail_phase = 0;
+        }
+        if (phase == 1) {  // the feature maps are consumed: the conv stream is free for the next image
+          if (!net->ev_convs) HIP_THROW(hipEventCreateWithFlags(&net->ev_convs, hipEventDisableTiming));
+          HIP_THROW(hipEventRecord(net->ev_convs, cs));
+          HIP_THROW(hipStreamWaitEvent(net->stream, net->ev_convs, 0));
+        }
+      }
+    } else if (L.op == OP_TAIL) {
+      // (every n: a one-unit pass over two heads needs the same hand-over as a ten-unit one)
       if (!net->ev_convs) HIP_THROW(hipEventCreateWithFlags(&net->ev_convs, hipEventDisableTiming));
       HIP_THROW(hipEventRecord(net->ev_convs, net->stream));
       if (net->pred && net->pred->ev_mark) HIP_THROW(hipStreamWaitEvent(net->stream, net->pred->ev_mark, 0));
@@ -1652,7 +1708,7 @@ int shf_detect_add_levels(shf_net* net, int n, shf_net** members, const float* c
       // the OTHER head's queue serialises the pipeline).  N > 0 = fan out over N streams owned by this head
       // (default 3 without a predecessor: shortest latency for one image); -1 = the member lanes' own streams.
       static const int tail_env = getenv("SHF_TAIL_STREAMS") ? atoi(getenv("SHF_TAIL_STREAMS")) : -2;
-      const int tail_streams = tail_env != -2 ? tail_env : (net->pred ? 0 : 3);
+      const int tail_streams = n == 1 ? 0 : tail_env != -2 ? tail_env : (net->pred ? 0 : 3);
       if (tail_streams == 0) {
         for (int phase = 1; phase <= 2; ++phase)
           for (int m = 0; m < n; ++m) {
@@ -1709,8 +1765,7 @@ int shf_detect_add_levels(shf_net* net, int n, shf_net** members, const float* c
       }
     } else {
       for (int m = 0; m < n; ++m)
-        members[m]->forward_ops(true, (float)im_h[m], (float)im_w[m], im_scale[m], net->stream, &net->prof, (int)li,
-                                nullptr);
+        members[m]->forward_ops(true, (float)im_h[m], (float)im_w[m], im_scale[m], cs, &net->prof, (int)li, nullptr);
     }
   }
   for (int m = 0; m < n; ++m) {

@@ -253,6 +253,11 @@ class FusedDetector(object):
             else:
                 self._heads[0].set_predecessor(self._heads[1])
                 self._heads[1].set_predecessor(self._heads[0])
+                if os.environ.get("SHF_PIPE_SHARED_CONV_STREAM", "1") != "0":
+                    # convolutions of consecutive images on one in-order stream, tails + merge on the heads' own
+                    # high-priority streams: does not depend on how the runtime maps streams to hardware queues
+                    for h in self._heads:
+                        h.set_pipeline(True)
             self._turn = 0
             self._inflight = []
         return self._heads[self._turn]

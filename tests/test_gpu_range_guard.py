@@ -70,8 +70,8 @@ def test_fused_detector_redoes_out_of_range_images_in_fp32():
     gnet, _ = H.make_pair(H.detector_msg(True), cls_bias=1.0)
     ims = [np.random.default_rng(40 + i).integers(0, 256, (96, 128, 3)).astype(np.uint8) for i in range(3)]
     units = [list(T.pyramid_units(im)) for im in ims]
-    # image 1: blobs x 2000 -> conv1_1 outputs ~1e5..1e6
-    units[1] = [(u[0] * np.float32(2000.0),) + tuple(u[1:]) for u in units[1]]
+    # image 1: blobs x 2e5 -> conv1_1 outputs far beyond 65504 (the synthetic first layer has a gain of ~0.1)
+    units[1] = [(u[0] * np.float32(2.0e5),) + tuple(u[1:]) for u in units[1]]
     gnet.set_conv_mode("fp32")
     ref = [T.FusedDetector(gnet, n_lanes=4, mode="group").detect(u, thresh=0.05)[0] for u in units]
     gnet.set_conv_mode("f16x3")
