@@ -421,12 +421,9 @@ struct shf_net {
   shf_net* clone_src = nullptr;     // lanes share the parameter tensors of the net they were cloned from
   std::shared_ptr<int> wgen = std::make_shared<int>(0);  // bumped by every param commit
   int tail_gen = -1;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_mark = nullptr;
+  hipEvent_t ev_mark = nullptr;
   hipEvent_t ev_logits = nullptr;  // recorded by every fused tail pass right after its logits kernel
   hipEvent_t ev_convs = nullptr;   // group pass: recorded on the head's stream after the last layer before the tails
-  int tail_phase = 0;  // group pass: 1 = logits kernels only, 2 = the rest of the tail (launch_tail)
-  std::vector<hipStream_t> tail_pool;  // head-owned streams the detection tails of a group pass fan out over
-  std::vector<hipEvent_t> tail_pool_ev;
   shf_net* pred = nullptr;         // shf_net_set_predecessor: the head lane whose image precedes this one's
   bool pipelined = false;   // shf_net_set_pipeline: convolutions go to sh->conv_stream, the rest stays on `stream`
   hipStream_t cstream() { return pipelined && sh->conv_stream ? sh->conv_stream : stream; }
@@ -439,17 +436,14 @@ struct shf_net {
   // fused per-image path
   DevBuf img_dets, img_keys, img_count;
   int img_cap = 0, img_units = 0;
+  int img_pass = 0;  // append passes since detect_begin: img_count[img_pass & 1] is the current list length
   MergeCtx merge;
   float cur_im_info[3] = {0, 0, 1};
   bool use_blob_im_info = true;
 
   ~shf_net() {
-    if (ev_fork) (void)hipEventDestroy(ev_fork);
-    if (ev_join) (void)hipEventDestroy(ev_join);
     if (ev_logits) (void)hipEventDestroy(ev_logits);
     if (ev_convs) (void)hipEventDestroy(ev_convs);
-    for (auto e : tail_pool_ev) (void)hipEventDestroy(e);
-    for (auto t : tail_pool) (void)hipStreamDestroy(t);
     if (ev_mark) (void)hipEventDestroy(ev_mark);
     if (stream) {
       (void)hipStreamSynchronize(stream);
@@ -486,6 +480,8 @@ struct shf_net {
   void ensure_tail_workspace(size_t total_anchors);
   void commit_params(int li);
   void build_tail_weights();
+  TailArgs tail_args(float im_h, float im_w, float im_scale, bool fused_path);
+  float* probs_out() { return prob_blob >= 0 ? (float*)blobs[prob_blob].dev.p : (float*)tw_rec.p; }
   void forward_ops(bool fused_path, float im_h, float im_w, float im_scale, hipStream_t s_override = nullptr,
                    Prof* prof_override = nullptr, int only_layer = -1, ConvArgs* collect = nullptr);
   void prepare_unit(const float* data, int data_on_device, int H, int W, hipStream_t st);
@@ -1065,6 +1061,29 @@ static double conv_flops(const Layer& L, const std::vector<int>& in, const std::
   return 2.0 * out[0] * out[2] * out[3] * (double)L.nout * in[1] * L.k * L.k;
 }
 
+// the proposal stage's arguments for the current shapes (also sizes the workspace: pre_nms_topN is shared with the
+// other lanes and may have grown)
+TailArgs shf_net::tail_args(float im_h, float im_w, float im_scale, bool fused_path) {
+  TailArgs t;
+  t.A = tail_A; t.heads = tail_heads; t.Cf = tail_Cf;
+  for (int i = 0; i < tail_heads; ++i) t.feat[i] = view_of(tail_feat_blobs[i]);
+  t.wcls[0] = (const float*)tail_W.p;
+  t.bcls[0] = (const float*)tail_b.p;
+  t.h = blobs[tail_feat_blobs[0]].shape[2];
+  t.w = blobs[tail_feat_blobs[0]].shape[3];
+  for (int i = 0; i < tail_A * 4; ++i) t.anchors[i] = (float)anchors[i];
+  for (int i = 0; i < tail_A; ++i) t.sub_stride[i] = sub_stride[i];
+  t.feat_stride = feat_stride;
+  t.im_h = im_h; t.im_w = im_w; t.im_scale = im_scale;
+  t.min_size = min_size; t.score_thresh = score_thresh; t.pre_nms_topN = pre_nms_topN;
+  if (materialize_tail && !fused_path) {
+    t.cls_prob_reshape_nchw = (float*)blobs[tail_cls_blob].dev.p;
+    t.bbox_pred_nchw = (float*)blobs[tail_box_blob].dev.p;
+  }
+  ensure_tail_workspace((size_t)t.h * t.w * tail_A);
+  return t;
+}
+
 void shf_net::forward_ops(bool fused_path, float im_h, float im_w, float im_scale, hipStream_t s_override,
                           Prof* prof_override, int only_layer, ConvArgs* collect) {
   if (tail_w_dirty || tail_gen != *wgen) build_tail_weights();
@@ -1150,30 +1169,14 @@ void shf_net::forward_ops(bool fused_path, float im_h, float im_w, float im_scal
         break;
       }
       case OP_TAIL: {
-        TailArgs t;
-        t.A = tail_A; t.heads = tail_heads; t.Cf = tail_Cf;
-        for (int i = 0; i < tail_heads; ++i) t.feat[i] = view_of(tail_feat_blobs[i]);
-        t.wcls[0] = (const float*)tail_W.p;
-        t.bcls[0] = (const float*)tail_b.p;
-        t.h = blobs[tail_feat_blobs[0]].shape[2];
-        t.w = blobs[tail_feat_blobs[0]].shape[3];
-        for (int i = 0; i < tail_A * 4; ++i) t.anchors[i] = (float)anchors[i];
-        for (int i = 0; i < tail_A; ++i) t.sub_stride[i] = sub_stride[i];
-        t.feat_stride = feat_stride;
-        t.im_h = im_h; t.im_w = im_w; t.im_scale = im_scale;
-        t.min_size = min_size; t.score_thresh = score_thresh; t.pre_nms_topN = pre_nms_topN;
-        if (materialize_tail && !fused_path) {
-          t.cls_prob_reshape_nchw = (float*)blobs[tail_cls_blob].dev.p;
-          t.bbox_pred_nchw = (float*)blobs[tail_box_blob].dev.p;
-        }
-        ensure_tail_workspace((size_t)t.h * t.w * tail_A);  // pre_nms_topN is shared with the other lanes and may have grown
+        TailArgs t = tail_args(im_h, im_w, im_scale, fused_path);
         const double K = (double)t.h * t.w;
         ProfScope ps(pf, st, PC_TAIL, 2.0 * K * tail_A * 6 * tail_Cf,
                      4.0 * K * (tail_heads * tail_Cf + tail_A * 18));
         if (fused_path && !ev_logits) HIP_THROW(hipEventCreateWithFlags(&ev_logits, hipEventDisableTiming));
         CHECK_RC(launch_tail(t, tw, (float*)blobs[boxes_blob].dev.p,
                              prob_blob >= 0 ? (float*)blobs[prob_blob].dev.p : (float*)tw_rec.p, st,
-                             fused_path ? ev_logits : nullptr, tail_phase));
+                             fused_path ? ev_logits : nullptr, 0));
         break;
       }
     }
@@ -1510,6 +1513,7 @@ int shf_detect_begin(shf_net* net) {
   net->img_count.ensure(64);
   HIP_THROW(hipMemsetAsync(net->img_count.p, 0, 64, net->stream));
   net->img_units = 0;
+  net->img_pass = 0;
   return 0;
   API_END(-1)
 }
@@ -1552,19 +1556,41 @@ void shf_net::ensure_img_cap(int units_after) {
   img_cap = ncap;
 }
 
-// append one finished unit (whose proposals sit in `src`'s output blobs) to `net`'s image list
-static void append_unit(shf_net* net, shf_net* src, int im_w, float im_scale, int flip, float thresh,
-                        hipStream_t st = nullptr, Prof* pf = nullptr) {
-  net->ensure_img_cap(net->img_units + 1);
-  const int rmax = src->pre_nms_topN > 0 ? src->pre_nms_topN : (int)src->tw.cap_anchors;
+constexpr int kMaxGroup = 16;  // units per grouped pass (conv_common.h MAX_GROUP, tail.hip TG)
+
+// append a group of finished units (their proposals sit in the members' output blobs) to `net`'s image list -- or,
+// per_member, to each member's own (reset) list -- in ONE launch
+static void append_units(shf_net* net, shf_net* const* srcs, int n, const int* im_w, const float* im_scale,
+                         const int* flip, float thresh, bool per_member, hipStream_t st = nullptr, Prof* pf = nullptr) {
   if (!st) st = net->stream;
+  if (!per_member) net->ensure_img_cap(net->img_units + n);
+  AppendUnit us[kMaxGroup];
+  for (int m = 0; m < n; ++m) {
+    shf_net* src = srcs[m];
+    shf_net* dst = per_member ? src : net;
+    if (per_member) {
+      dst->img_count.ensure(64);
+      dst->ensure_img_cap(1);
+      dst->img_units = 1;
+      dst->img_pass = 1;  // the kernel writes count[0] = 0, count[1] = rows
+    }
+    AppendUnit& u = us[m];
+    u.boxes5 = (const float*)src->blobs[src->boxes_blob].dev.p;
+    u.probs2 = src->probs_out();
+    u.counters = src->tw.counters;
+    u.r_max = src->pre_nms_topN > 0 ? src->pre_nms_topN : (int)src->tw.cap_anchors;
+    u.im_w = (float)im_w[m]; u.im_scale = im_scale[m]; u.flip = flip[m];
+    u.dets5 = (float*)dst->img_dets.p;
+    u.keys = (unsigned long long*)dst->img_keys.p;
+    u.count = (int*)dst->img_count.p;
+    u.cap = dst->img_cap;
+  }
   ProfScope ps(pf ? *pf : net->prof, st, PC_TAIL, 0, 0);
-  CHECK_RC(launch_append_dets((float*)src->blobs[src->boxes_blob].dev.p,
-                              src->prob_blob >= 0 ? (float*)src->blobs[src->prob_blob].dev.p : (float*)src->tw_rec.p,
-                              src->tw.counters + 2, rmax, (float)im_w, im_scale, flip, thresh, net->img_units,
-                              (float*)net->img_dets.p, (unsigned long long*)net->img_keys.p,
-                              (int*)net->img_count.p, net->img_cap, st));
-  net->img_units++;
+  CHECK_RC(launch_append_dets_group(us, n, srcs[0]->pre_nms_topN, thresh, net->img_pass, per_member ? 1 : 0, st));
+  if (!per_member) {
+    net->img_units += n;
+    net->img_pass++;
+  }
 }
 
 int shf_pyramid_level_shape(int im_h, int im_w, double scale, int max_resolution, int* lvl_h, int* lvl_w, int* H,
@@ -1599,7 +1625,7 @@ int shf_detect_add_level(shf_net* net, const float* data, int data_on_device, in
   net->prepare_unit(data, data_on_device, H, W, net->stream);
   net->forward_ops(true, (float)im_h, (float)im_w, im_scale);
   net->blobs[net->data_blob].ext_dev = nullptr;
-  append_unit(net, net, im_w, im_scale, flip, thresh);
+  append_units(net, &net, 1, &im_w, &im_scale, &flip, thresh, false);
   return 0;
   API_END(-1)
 }
@@ -1677,110 +1703,62 @@ int shf_detect_add_levels(shf_net* net, int n, shf_net** members, const float* c
         ProfScope ps(net->prof, cs, pc, fl, by);
         CHECK_RC(launch_conv_mfma_group(group.data(), n, cs));
       }
-    } else if (L.op == OP_TAIL && shared) {
-      // the members' tail workspaces were last used by the predecessor head's tails (its own stream)
-      if (net->pred && net->pred->ev_mark) HIP_THROW(hipStreamWaitEvent(cs, net->pred->ev_mark, 0));
-      for (int phase = 1; phase <= 2; ++phase) {
-        for (int m = 0; m < n; ++m) {
-          members[m]->tail_phase = phase;
-          members[m]->forward_ops(true, (float)im_h[m], (float)im_w[m], im_scale[m], phase == 1 ? cs : net->stream,
-                                  &net->prof, (int)li, nullptr);
-          members[m]->tail_phase = 0;
-        }
-        if (phase == 1) {  // the feature maps are consumed: the conv stream is free for the next image
-          if (!net->ev_convs) HIP_THROW(hipEventCreateWithFlags(&net->ev_convs, hipEventDisableTiming));
-          HIP_THROW(hipEventRecord(net->ev_convs, cs));
-          HIP_THROW(hipStreamWaitEvent(net->stream, net->ev_convs, 0));
-        }
-      }
     } else if (L.op == OP_TAIL) {
-      // (every n: a one-unit pass over two heads needs the same hand-over as a ten-unit one)
-      if (!net->ev_convs) HIP_THROW(hipEventCreateWithFlags(&net->ev_convs, hipEventDisableTiming));
-      HIP_THROW(hipEventRecord(net->ev_convs, net->stream));
-      if (net->pred && net->pred->ev_mark) HIP_THROW(hipStreamWaitEvent(net->stream, net->pred->ev_mark, 0));
-      // The detection tail of a unit is a chain of ~8 tiny dependent launches (logits, decode, sort
-      // stages, gather): latency-bound.  Fan the units out over their lanes' own streams so the
-      // chains overlap, and join back on the primary stream.
-      // Where the tails run (SHF_TAIL_STREAMS overrides): 0 = on this head's stream, logits kernels of all
-      // units first -- the default when the head has a predecessor, i.e. images are pipelined over two heads:
-      // the serial chain then hides under the next image's convolutions, and only the two head streams are
-      // ever active (the runtime multiplexes HIP streams onto ~4 hardware queues; a tail stream that lands on
-      // the OTHER head's queue serialises the pipeline).  N > 0 = fan out over N streams owned by this head
-      // (default 3 without a predecessor: shortest latency for one image); -1 = the member lanes' own streams.
-      static const int tail_env = getenv("SHF_TAIL_STREAMS") ? atoi(getenv("SHF_TAIL_STREAMS")) : -2;
-      const int tail_streams = n == 1 ? 0 : tail_env != -2 ? tail_env : (net->pred ? 0 : 3);
-      if (tail_streams == 0) {
-        for (int phase = 1; phase <= 2; ++phase)
-          for (int m = 0; m < n; ++m) {
-            members[m]->tail_phase = phase;
-            members[m]->forward_ops(true, (float)im_h[m], (float)im_w[m], im_scale[m], net->stream, &net->prof, (int)li,
-                                    nullptr);
-            members[m]->tail_phase = 0;
-          }
-        continue;
-      }
-      if (!net->ev_fork) HIP_THROW(hipEventCreateWithFlags(&net->ev_fork, hipEventDisableTiming));
-      HIP_THROW(hipEventRecord(net->ev_fork, net->stream));
-      if (tail_streams > 0) {
-        while ((int)net->tail_pool.size() < tail_streams) {
-          hipStream_t ts;
-          hipEvent_t te;
-          HIP_THROW(hipStreamCreateWithFlags(&ts, hipStreamNonBlocking));
-          HIP_THROW(hipEventCreateWithFlags(&te, hipEventDisableTiming));
-          net->tail_pool.push_back(ts);
-          net->tail_pool_ev.push_back(te);
-        }
-        // longest chains first, round-robin: the big levels' sorts dominate
-        std::vector<int> order(n);
-        for (int m = 0; m < n; ++m) order[m] = m;
-        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return (long long)H[a] * W[a] > (long long)H[b] * W[b]; });
-        for (int t = 0; t < tail_streams; ++t) HIP_THROW(hipStreamWaitEvent(net->tail_pool[t], net->ev_fork, 0));
-        // every unit's logits kernel goes first: once they have run, the member lanes' feature maps are
-        // free and the next image's convolutions start under the sorts / gathers of this one
-        for (int phase = 1; phase <= 2; ++phase)
-          for (int q = 0; q < n; ++q) {
-            const int m = order[q];
-            shf_net* mb = members[m];
-            mb->tail_phase = phase;
-            mb->forward_ops(true, (float)im_h[m], (float)im_w[m], im_scale[m], net->tail_pool[q % tail_streams],
-                            &mb->prof, (int)li, nullptr);
-            mb->tail_phase = 0;
-          }
-        for (int t = 0; t < tail_streams; ++t) {
-          HIP_THROW(hipEventRecord(net->tail_pool_ev[t], net->tail_pool[t]));
-          HIP_THROW(hipStreamWaitEvent(net->stream, net->tail_pool_ev[t], 0));
-        }
-        continue;
-      }
+      // The detection tails of all units as ONE launch per stage (counters reset, logits, decode, sort stages,
+      // gather): ~15 launches per image instead of ~100.  Phase 1 (reset + logits) is what reads the head feature
+      // maps; phase 2 works on the members' tail workspaces only.
+      TailArgs targs[kMaxGroup];
+      TailWork* tws[kMaxGroup];
+      float* tb[kMaxGroup];
+      float* tp[kMaxGroup];
+      double tfl = 0, tby = 0;
       for (int m = 0; m < n; ++m) {
         shf_net* mb = members[m];
-        if (mb->stream != net->stream) HIP_THROW(hipStreamWaitEvent(mb->stream, net->ev_fork, 0));
-        mb->forward_ops(true, (float)im_h[m], (float)im_w[m], im_scale[m], mb->stream,
-                        mb->stream == net->stream ? &net->prof : &mb->prof, (int)li, nullptr);
-        if (mb->stream != net->stream) {
-          if (!mb->ev_join) HIP_THROW(hipEventCreateWithFlags(&mb->ev_join, hipEventDisableTiming));
-          HIP_THROW(hipEventRecord(mb->ev_join, mb->stream));
-          HIP_THROW(hipStreamWaitEvent(net->stream, mb->ev_join, 0));
+        if (mb->tail_w_dirty || mb->tail_gen != *mb->wgen) mb->build_tail_weights();
+        targs[m] = mb->tail_args((float)im_h[m], (float)im_w[m], im_scale[m], true);
+        tws[m] = &mb->tw;
+        tb[m] = (float*)mb->blobs[mb->boxes_blob].dev.p;
+        tp[m] = mb->probs_out();
+        const double K = (double)targs[m].h * targs[m].w;
+        tfl += 2.0 * K * mb->tail_A * 6 * mb->tail_Cf;
+        tby += 4.0 * K * (mb->tail_heads * mb->tail_Cf + mb->tail_A * 18);
+      }
+      for (int m = 1; m < n; ++m) targs[m].wcls[0] = targs[0].wcls[0], targs[m].bcls[0] = targs[0].bcls[0];  // lanes hold identical copies
+      if (!net->ev_convs) HIP_THROW(hipEventCreateWithFlags(&net->ev_convs, hipEventDisableTiming));
+      if (shared) {
+        // the members' tail workspaces were last used by the predecessor head's tails (its own stream)
+        if (net->pred && net->pred->ev_mark) HIP_THROW(hipStreamWaitEvent(cs, net->pred->ev_mark, 0));
+        {
+          ProfScope ps(net->prof, cs, PC_TAIL, tfl, tby);
+          CHECK_RC(launch_tail_group(targs, tws, tb, tp, n, cs, nullptr, 1));
         }
+        // the feature maps are consumed: the conv stream is free for the next image
+        HIP_THROW(hipEventRecord(net->ev_convs, cs));
+        HIP_THROW(hipStreamWaitEvent(net->stream, net->ev_convs, 0));
+      } else {
+        // (every n: a one-unit pass over two heads needs the same hand-over as a ten-unit one)
+        HIP_THROW(hipEventRecord(net->ev_convs, net->stream));
+        if (net->pred && net->pred->ev_mark) HIP_THROW(hipStreamWaitEvent(net->stream, net->pred->ev_mark, 0));
+        ProfScope ps(net->prof, net->stream, PC_TAIL, tfl, tby);
+        CHECK_RC(launch_tail_group(targs, tws, tb, tp, n, net->stream, nullptr, 1));
+      }
+      for (int m = 0; m < n; ++m) {  // hand-over mark for passes issued from another head without a pipeline
+        shf_net* mb = members[m];
+        if (!mb->ev_logits) HIP_THROW(hipEventCreateWithFlags(&mb->ev_logits, hipEventDisableTiming));
+        HIP_THROW(hipEventRecord(mb->ev_logits, shared ? cs : net->stream));
+      }
+      {
+        ProfScope ps(net->prof, net->stream, PC_TAIL, 0, 0);
+        CHECK_RC(launch_tail_group(targs, tws, tb, tp, n, net->stream, nullptr, 2));
       }
     } else {
       for (int m = 0; m < n; ++m)
         members[m]->forward_ops(true, (float)im_h[m], (float)im_w[m], im_scale[m], cs, &net->prof, (int)li, nullptr);
     }
   }
-  for (int m = 0; m < n; ++m) {
-    shf_net* mb = members[m];
-    mb->blobs[mb->data_blob].ext_dev = nullptr;
-    if (per_member_lists) {
-      // units of different images: each member keeps its own list (reset + append on net's stream)
-      mb->img_count.ensure(64);
-      HIP_THROW(hipMemsetAsync(mb->img_count.p, 0, 64, net->stream));
-      mb->img_units = 0;
-      append_unit(mb, mb, im_w[m], im_scale[m], flip[m], thresh, net->stream, &net->prof);
-    } else {
-      append_unit(net, mb, im_w[m], im_scale[m], flip[m], thresh);
-    }
-  }
+  for (int m = 0; m < n; ++m) members[m]->blobs[members[m]->data_blob].ext_dev = nullptr;
+  // units of different images (per_member_lists): each member keeps its own list
+  append_units(net, members, n, im_w, im_scale, flip, thresh, per_member_lists != 0, net->stream, &net->prof);
   return 0;
   API_END(-1)
 }
@@ -1793,7 +1771,7 @@ static int detect_count_checked(shf_net* net, bool check_range) {
     HIP_THROW(hipMemcpyAsync(&flag, net->range_flag.p, 4, hipMemcpyDeviceToHost, net->stream));
   HIP_THROW(hipStreamSynchronize(net->stream));
   if (flag) throw std::runtime_error(kRangeMsg);
-  return c[net->img_units & 1];
+  return c[net->img_pass & 1];
 }
 
 int shf_detect_count(shf_net* net) {
@@ -1825,7 +1803,7 @@ int shf_detect_export_many(shf_net* net, int n, shf_net** members, float* const*
     int c[2] = {0, 0};
     HIP_THROW(hipMemcpyAsync(c, members[m]->img_count.p, 8, hipMemcpyDeviceToHost, net->stream));
     HIP_THROW(hipStreamSynchronize(net->stream));
-    n_rows[m] = c[members[m]->img_units & 1];
+    n_rows[m] = c[members[m]->img_pass & 1];
   }
   for (int m = 0; m < n; ++m) {
     const int w = std::min(n_rows[m], cap_rows);
@@ -2039,12 +2017,13 @@ int shf_debug_append(shf_net* net, const float* boxes5, const float* probs2, int
     HIP_THROW(hipMemcpyAsync(bb.dev.p, boxes5, (size_t)R * 5 * 4, hipMemcpyHostToDevice, st));
     HIP_THROW(hipMemcpyAsync(probs, probs2, (size_t)R * 2 * 4, hipMemcpyHostToDevice, st));
   }
-  HIP_THROW(hipMemcpyAsync(net->tw.counters + 2, &R, 4, hipMemcpyHostToDevice, st));
+  const int cnt[8] = {R, 0, R, 0, 0, 0, 0, 0};  // C candidates (all kept: topN is raised below), published R
+  HIP_THROW(hipMemcpyAsync(net->tw.counters, cnt, sizeof(cnt), hipMemcpyHostToDevice, st));
   HIP_THROW(hipStreamSynchronize(st));
   const int saved = net->pre_nms_topN;
   net->pre_nms_topN = std::max(R, 1);  // append_unit sizes its launch and the list growth from it
   try {
-    append_unit(net, net, im_w, im_scale, flip, thresh);
+    append_units(net, &net, 1, &im_w, &im_scale, &flip, thresh, false);
   } catch (...) {
     net->pre_nms_topN = saved;
     throw;

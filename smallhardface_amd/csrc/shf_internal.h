@@ -121,14 +121,34 @@ int launch_tail_inject(const TailArgs& a, TailWork& ws, const float* scores_nchw
                        hipStream_t s);
 // after_logits: recorded once the feature maps are consumed; phase 1 = only up to there, 2 = only the rest
 
+// the same for a GROUP of independent units (the units of an image's pyramid): ONE launch per stage.  phase 0:
+// everything; 1: counters reset + logits kernel (after_logits recorded behind it); 2: decode -> sort -> gather
+int launch_tail_group(const TailArgs* as, TailWork* const* wss, float* const* out_boxes5, float* const* out_probs2,
+                      int n, hipStream_t s, hipEvent_t after_logits = nullptr, int phase = 0);
+
 // generic device sort of u64 keys, descending; n_dev points at the element count on the device,
 // n_max is a host-known upper bound (sizes the launch sequence)
 int launch_sort_desc_u64(unsigned long long* keys, const int* n_dev, size_t n_max, hipStream_t s);
+int launch_sort_desc_u64_group(unsigned long long* const* keys, const int* const* n_dev, const size_t* n_max, int n,
+                               hipStream_t s);
 
-// append >thresh detections of one unit to the image list (test.py:52-66,163-167)
-int launch_append_dets(const float* boxes5, const float* probs2, const int* R_dev, int r_max, float im_w,
-                       float im_scale, int flip, float thresh, int unit, float* img_dets5,
-                       unsigned long long* img_keys, int* img_count, int img_cap, hipStream_t s);
+// append the >thresh detections of a group of finished units to an image list (test.py:52-66,163-167): flip fix,
+// unscale, threshold cut.  count[pass & 1] = list length before the pass, count[(pass + 1) & 1] after it; with
+// per_member != 0 every unit has its own (reset) list and count[1] receives its length.
+struct AppendUnit {
+  const float* boxes5;
+  const float* probs2;
+  const int* counters;  // the unit's tail counters (TailWork::counters)
+  int r_max;            // host-side bound of the unit's rows (sizes the launch)
+  float im_w, im_scale;
+  int flip;
+  float* dets5;
+  unsigned long long* keys;
+  int* count;
+  int cap;
+};
+int launch_append_dets_group(const AppendUnit* us, int n, int topN, float thresh, int pass, int per_member,
+                             hipStream_t s);
 
 // ---- box merging ----------------------------------------------------------------
 struct MergeWork {

@@ -8,6 +8,8 @@
 // Compiled with -ffp-contract=off: the box arithmetic keeps numpy's unfused fp32 op order.
 #include <math.h>
 
+#include <algorithm>
+
 #include "shf_internal.h"
 
 namespace shf {
@@ -19,16 +21,15 @@ static inline unsigned grid_for(long long n, int block = 256) {
   return (unsigned)g;
 }
 
-struct TailK {
-  const float* feat[8];
-  int fstride[8];
-  const float* Wt;  // [A][6][Cf]  rows: cls0, cls1, dx, dy, dw, dh
-  const float* bt;  // [A][6]
-  float* logits;    // [K][A][6]
-  int K, A, Cf, w;
-  float aw[8], ah[8];  // base anchor widths / heights (x2-x1+1)
-  int* counters;       // [1] = overflow flag
-};
+constexpr int TG = 16;  // members per grouped launch (the units of an image's pyramid)
+
+// which member does block `b` belong to?  blk_start[q] = first block of member q (unused entries INT_MAX)
+__device__ __forceinline__ int tail_find_member(const int* blk_start, int b) {
+  int mi = 0;
+#pragma unroll
+  for (int q = 1; q < TG; ++q) mi += (b >= blk_start[q]) ? 1 : 0;
+  return mi;
+}
 
 // np.seterr(over='raise') around exp(dw) * widths (bbox_transform.py:9,52-56): does this delta overflow fp32?
 __device__ __forceinline__ bool delta_overflows(float v, float anchor_extent) {
@@ -38,25 +39,55 @@ __device__ __forceinline__ bool delta_overflows(float v, float anchor_extent) {
   return isinf(e) || isinf(pw);
 }
 
+// ---- every kernel of the tail takes a GROUP of independent units (the 10 (level, flip) units of an image): one
+//      launch per stage instead of one per unit and stage (~100 five-microsecond launches per image) --------------
+struct TailResetK {
+  int* counters[TG];
+  int n;
+};
+__global__ void tail_reset_kernel(TailResetK p) {
+  const int m = threadIdx.x >> 3, j = threadIdx.x & 7;
+  if (m < p.n) p.counters[m][j] = 0;
+}
+
+struct TailGM {  // per member
+  const float* feat[8];
+  int fstride[8];
+  float* logits;    // [K][A][6]
+  int* counters;    // [1] = overflow flag
+  int K, w;
+};
+struct TailGK {
+  const float* Wt;  // [A][6][Cf]  rows: cls0, cls1, dx, dy, dw, dh
+  const float* bt;  // [A][6]
+  int A, Cf;
+  float aw[8], ah[8];  // base anchor widths / heights (x2-x1+1)
+  int blk_start[TG + 1];
+  TailGM m[TG];
+};
+
 // ---- 1x1 cls/reg convs: wave handles two pixels, 32 lanes x float4 per pixel -------------
-__global__ __launch_bounds__(256) void tail_logits_kernel(TailK p) {
+__global__ __launch_bounds__(256) void tail_logits_kernel(TailGK g) {
+  const int mi = tail_find_member(g.blk_start, blockIdx.x);
+  const TailGM& p = g.m[mi];
+  const int lb = blockIdx.x - g.blk_start[mi], lgrid = g.blk_start[mi + 1] - g.blk_start[mi];
   const int lane = threadIdx.x & 63;
   const int sub = lane >> 5, q = lane & 31;
-  const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+  const long long wave = ((long long)lb * blockDim.x + threadIdx.x) >> 6;
+  const long long nwaves = ((long long)lgrid * blockDim.x) >> 6;
   const long long npairs = ((long long)p.K + 1) / 2;
-  for (int a = 0; a < p.A; ++a) {
+  for (int a = 0; a < g.A; ++a) {
     const float* f = p.feat[a];
     const int fs = p.fstride[a];
     for (long long pr = wave; pr < npairs; pr += nwaves) {
       const long long k = pr * 2 + sub;
       float part[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       if (k < p.K) {
-        for (int c0 = 0; c0 < p.Cf; c0 += 128) {
+        for (int c0 = 0; c0 < g.Cf; c0 += 128) {
           const float4 x = *(const float4*)(f + (size_t)k * fs + c0 + q * 4);
 #pragma unroll
           for (int o = 0; o < 6; ++o) {
-            const float4 wv = *(const float4*)(p.Wt + ((size_t)a * 6 + o) * p.Cf + c0 + q * 4);
+            const float4 wv = *(const float4*)(g.Wt + ((size_t)a * 6 + o) * g.Cf + c0 + q * 4);
             part[o] += x.x * wv.x + x.y * wv.y + x.z * wv.z + x.w * wv.w;
           }
         }
@@ -67,13 +98,13 @@ __global__ __launch_bounds__(256) void tail_logits_kernel(TailK p) {
         for (int m = 16; m >= 1; m >>= 1) part[o] += __shfl_xor(part[o], m, 64);
       }
       if (q == 0 && k < p.K) {
-        float* L = p.logits + ((size_t)k * p.A + a) * 6;
+        float* L = p.logits + ((size_t)k * g.A + a) * 6;
         bool of = false;
 #pragma unroll
         for (int o = 0; o < 6; ++o) {
-          const float v = part[o] + p.bt[a * 6 + o];
+          const float v = part[o] + g.bt[a * 6 + o];
           L[o] = v;
-          if (o >= 4) of |= delta_overflows(v, o == 4 ? p.aw[a] : p.ah[a]);
+          if (o >= 4) of |= delta_overflows(v, o == 4 ? g.aw[a] : g.ah[a]);
         }
         if (of) atomicOr(&p.counters[1], 1);
       }
@@ -81,25 +112,10 @@ __global__ __launch_bounds__(256) void tail_logits_kernel(TailK p) {
   }
 }
 
-struct DecodeK {
-  const float* logits;  // [K][A][6]
-  float* rec;           // [K*A][6] bg, fg, x1, y1, x2, y2
-  unsigned long long* keys;
-  int* counters;        // 0: n candidates, 1: overflow flag ; [4..5] as u64: best key
-  int K, A, w;
-  float anchors[32];
-  int sub_stride[8];
-  int feat_stride;
-  float im_h, im_w, min_size_scaled, score_thresh;
-  float* cls_nchw;   // optional (1,2A,h,w)
-  float* bbox_nchw;  // optional (1,4A,h,w)
-  int probs_given;   // diagnostics (shf_debug_proposal): L[0..1] already hold bg/fg probabilities
-};
-
 // diagnostics: (1,2A,h,w) probabilities + (1,4A,h,w) deltas in the blobs' NCHW layout -> the tail's
 // [K][A][6] records, raising the same overflow flag the logits kernel raises
 __global__ void tail_inject_kernel(const float* __restrict__ scores, const float* __restrict__ deltas,
-                                   float* __restrict__ logits, int K, int A, TailK p) {
+                                   float* __restrict__ logits, int K, int A, TailGK g, int* counters) {
   const long long total = (long long)K * A;
   for (long long n = (long long)blockIdx.x * blockDim.x + threadIdx.x; n < total;
        n += (long long)gridDim.x * blockDim.x) {
@@ -113,27 +129,51 @@ __global__ void tail_inject_kernel(const float* __restrict__ scores, const float
     for (int j = 0; j < 4; ++j) {
       const float v = deltas[(size_t)(a * 4 + j) * K + k];
       L[2 + j] = v;
-      if (j >= 2) of |= delta_overflows(v, j == 2 ? p.aw[a] : p.ah[a]);
+      if (j >= 2) of |= delta_overflows(v, j == 2 ? g.aw[a] : g.ah[a]);
     }
-    if (of) atomicOr(&p.counters[1], 1);
+    if (of) atomicOr(&counters[1], 1);
   }
 }
 
-__global__ __launch_bounds__(256) void tail_decode_kernel(DecodeK p) {
-  const long long total = (long long)p.K * p.A;
+struct DecodeGM {  // per member
+  const float* logits;  // [K][A][6]
+  float* rec;           // [K*A][6] bg, fg, x1, y1, x2, y2
+  unsigned long long* keys;
+  int* counters;        // 0: n candidates, 1: overflow flag ; [4..5] as u64: best key
+  int K, w;
+  float im_h, im_w, min_size_scaled;
+  float* cls_nchw;   // optional (1,2A,h,w)
+  float* bbox_nchw;  // optional (1,4A,h,w)
+};
+struct DecodeGK {
+  int A;
+  float anchors[32];
+  int sub_stride[8];
+  int feat_stride;
+  float score_thresh;
+  int probs_given;   // diagnostics (shf_debug_proposal): L[0..1] already hold bg/fg probabilities
+  int blk_start[TG + 1];
+  DecodeGM m[TG];
+};
+
+__global__ __launch_bounds__(256) void tail_decode_kernel(DecodeGK g) {
+  const int mi = tail_find_member(g.blk_start, blockIdx.x);
+  const DecodeGM& p = g.m[mi];
+  const int lb = blockIdx.x - g.blk_start[mi], lgrid = g.blk_start[mi + 1] - g.blk_start[mi];
+  const long long total = (long long)p.K * g.A;
   const bool clamp = p.counters[1] != 0;
   const int lane = threadIdx.x & 63;
-  const long long step = (long long)gridDim.x * blockDim.x;
+  const long long step = (long long)lgrid * blockDim.x;
   unsigned long long best = 0;
   // every lane runs the same number of iterations so the ballots below are wave-complete
   const long long iters = (total + step - 1) / step;
-  long long n = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long n = (long long)lb * blockDim.x + threadIdx.x;
   for (long long it = 0; it < iters; ++it, n += step) {
     bool cand = false;
     unsigned long long key = 0;
     if (n < total) {
-      const int a = (int)(n % p.A);
-      const int k = (int)(n / p.A);
+      const int a = (int)(n % g.A);
+      const int k = (int)(n / g.A);
       const int y = k / p.w, x = k - y * p.w;
       const float* L = p.logits + n * 6;
       const float c0 = L[0], c1 = L[1];
@@ -141,11 +181,11 @@ __global__ __launch_bounds__(256) void tail_decode_kernel(DecodeK p) {
       const float m = fmaxf(c0, c1);
       const float e0 = expf(c0 - m), e1 = expf(c1 - m);
       const float sum = e0 + e1;
-      const float bg = p.probs_given ? c0 : e0 / sum, fg = p.probs_given ? c1 : e1 / sum;
+      const float bg = g.probs_given ? c0 : e0 / sum, fg = g.probs_given ? c1 : e1 / sum;
       float dx = L[2], dy = L[3], dw = L[4], dh = L[5];
       if (p.cls_nchw) {
         p.cls_nchw[(size_t)a * p.K + k] = bg;
-        p.cls_nchw[(size_t)(p.A + a) * p.K + k] = fg;
+        p.cls_nchw[(size_t)(g.A + a) * p.K + k] = fg;
       }
       if (p.bbox_nchw) {
         p.bbox_nchw[(size_t)(a * 4 + 0) * p.K + k] = dx;
@@ -157,9 +197,9 @@ __global__ __launch_bounds__(256) void tail_decode_kernel(DecodeK p) {
         if (dw > 50.f) dw = 5.f;
         if (dh > 50.f) dh = 5.f;
       }
-      const float sx = (float)(x * p.feat_stride), sy = (float)(y * p.feat_stride);
-      const float ax1 = p.anchors[a * 4 + 0] + sx, ay1 = p.anchors[a * 4 + 1] + sy;
-      const float ax2 = p.anchors[a * 4 + 2] + sx, ay2 = p.anchors[a * 4 + 3] + sy;
+      const float sx = (float)(x * g.feat_stride), sy = (float)(y * g.feat_stride);
+      const float ax1 = g.anchors[a * 4 + 0] + sx, ay1 = g.anchors[a * 4 + 1] + sy;
+      const float ax2 = g.anchors[a * 4 + 2] + sx, ay2 = g.anchors[a * 4 + 3] + sy;
       // bbox_transform_inv (bbox_transform.py:39-75), fp32, unfused
       const float widths = ax2 - ax1 + 1.0f, heights = ay2 - ay1 + 1.0f;
       const float ctr_x = ax1 + 0.5f * widths, ctr_y = ay1 + 0.5f * heights;
@@ -176,14 +216,14 @@ __global__ __launch_bounds__(256) void tail_decode_kernel(DecodeK p) {
       float* r = p.rec + n * 6;
       r[0] = bg; r[1] = fg; r[2] = x1; r[3] = y1; r[4] = x2; r[5] = y2;
       // anchor subsampling map + _filter_boxes (proposal_layer.py:160-175,231-236)
-      const int ss = p.sub_stride[a];
+      const int ss = g.sub_stride[a];
       bool valid = (y % ss == 0) && (x % ss == 0);
       const float ws = x2 - x1 + 1.f, hs = y2 - y1 + 1.f;
       valid = valid && (ws >= p.min_size_scaled) && (hs >= p.min_size_scaled);
       if (valid) {
         key = ((unsigned long long)__float_as_uint(fg) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)n);
         best = key > best ? key : best;
-        cand = fg >= p.score_thresh;
+        cand = fg >= g.score_thresh;
       }
     }
     // wave-aggregated append of candidate keys
@@ -206,43 +246,57 @@ __global__ __launch_bounds__(256) void tail_decode_kernel(DecodeK p) {
 
 // after the sort: R = min(C, topN), or the single best valid anchor when nothing reaches the
 // threshold (proposal_layer.py:182-188)
-__global__ void tail_finalize_kernel(unsigned long long* keys, int* counters, int topN) {
+__device__ __forceinline__ int tail_rows(const int* counters, int topN, unsigned long long* best_out) {
   const int C = counters[0];
-  const unsigned long long best = *(unsigned long long*)(counters + 4);
-  int R;
-  if (C > 0) {
-    R = (topN > 0 && C > topN) ? topN : C;
-  } else if (best) {
-    keys[0] = best;
-    R = 1;
-  } else {
-    R = 0;
-  }
-  counters[2] = R;
+  const unsigned long long best = *(const unsigned long long*)(counters + 4);
+  if (best_out) *best_out = best;
+  if (C > 0) return (topN > 0 && C > topN) ? topN : C;
+  return best ? 1 : 0;
 }
 
-__global__ void tail_gather_kernel(const unsigned long long* __restrict__ keys, const float* __restrict__ rec,
-                                   const int* __restrict__ counters, float* __restrict__ boxes5,
-                                   float* __restrict__ probs2) {
-  const int R = counters[2];
-  if (R == 0 && blockIdx.x == 0 && threadIdx.x == 0) {  // dummy roi, proposal_layer.py:207-208
-    boxes5[0] = 0.f; boxes5[1] = 0.f; boxes5[2] = 0.f; boxes5[3] = 16.f; boxes5[4] = 16.f;
+struct GatherGM {
+  const unsigned long long* keys;
+  const float* rec;
+  int* counters;
+  float* boxes5;
+  float* probs2;
+};
+struct GatherGK {
+  int topN;
+  int blk_start[TG + 1];
+  GatherGM m[TG];
+};
+// finalize + gather in one: every block derives R from the counters (block 0 of the member publishes it in
+// counters[2] for the host / the append stage)
+__global__ void tail_gather_kernel(GatherGK g) {
+  const int mi = tail_find_member(g.blk_start, blockIdx.x);
+  const GatherGM& p = g.m[mi];
+  const int lb = blockIdx.x - g.blk_start[mi], lgrid = g.blk_start[mi + 1] - g.blk_start[mi];
+  unsigned long long best;
+  const int R = tail_rows(p.counters, g.topN, &best);
+  const bool only_best = p.counters[0] <= 0;  // nothing reached the threshold: the row is the best valid anchor
+  if (lb == 0 && threadIdx.x == 0) {
+    p.counters[2] = R;
+    if (R == 0) {  // dummy roi, proposal_layer.py:207-208
+      p.boxes5[0] = 0.f; p.boxes5[1] = 0.f; p.boxes5[2] = 0.f; p.boxes5[3] = 16.f; p.boxes5[4] = 16.f;
+    }
   }
-  for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < R; r += gridDim.x * blockDim.x) {
-    const unsigned n = 0xFFFFFFFFu - (unsigned)(keys[r] & 0xFFFFFFFFull);
-    const float* q = rec + (size_t)n * 6;
-    boxes5[r * 5 + 0] = 0.f;
-    boxes5[r * 5 + 1] = q[2];
-    boxes5[r * 5 + 2] = q[3];
-    boxes5[r * 5 + 3] = q[4];
-    boxes5[r * 5 + 4] = q[5];
-    probs2[r * 2 + 0] = q[0];
-    probs2[r * 2 + 1] = q[1];
+  for (int r = lb * blockDim.x + threadIdx.x; r < R; r += lgrid * blockDim.x) {
+    const unsigned long long key = only_best ? best : p.keys[r];
+    const unsigned n = 0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull);
+    const float* q = p.rec + (size_t)n * 6;
+    p.boxes5[r * 5 + 0] = 0.f;
+    p.boxes5[r * 5 + 1] = q[2];
+    p.boxes5[r * 5 + 2] = q[3];
+    p.boxes5[r * 5 + 3] = q[4];
+    p.boxes5[r * 5 + 4] = q[5];
+    p.probs2[r * 2 + 0] = q[0];
+    p.probs2[r * 2 + 1] = q[1];
   }
 }
 
 // ---------------------------------------------------------------------------
-// bitonic sort, descending, u64 keys, element count on the device.
+// bitonic sort, descending, u64 keys, element count on the device; a GROUP of independent arrays per launch.
 // Chunks of 16384 keys are sorted / merged inside one CU's LDS (128 KiB of the 160).
 // ---------------------------------------------------------------------------
 constexpr int SORT_CH = 16384;
@@ -253,13 +307,21 @@ __device__ __forceinline__ unsigned next_pow2(unsigned v) {
   return p;
 }
 
+struct SortGK {
+  unsigned long long* keys[TG];
+  const int* n_dev[TG];
+  int blk_start[TG + 1];  // in chunks (local kernels) or in 256-thread blocks (global step)
+};
+
 // all (k,j) stages with k <= chunk: full sort of each chunk in its network direction
-__global__ __launch_bounds__(1024) void bitonic_local_sort_kernel(unsigned long long* keys, const int* n_dev) {
+__global__ __launch_bounds__(1024) void bitonic_local_sort_kernel(SortGK g) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long sk[];
-  const unsigned n = (unsigned)max(*n_dev, 0);
+  const int mi = tail_find_member(g.blk_start, blockIdx.x);
+  unsigned long long* keys = g.keys[mi];
+  const unsigned n = (unsigned)max(*g.n_dev[mi], 0);
   const unsigned npad = next_pow2(n < 1 ? 1 : n);
   const unsigned m = npad < (unsigned)SORT_CH ? npad : (unsigned)SORT_CH;
-  const unsigned start = blockIdx.x * (unsigned)SORT_CH;
+  const unsigned start = (unsigned)(blockIdx.x - g.blk_start[mi]) * (unsigned)SORT_CH;
   if (start >= npad) return;
   for (unsigned t = threadIdx.x; t < m; t += 1024) sk[t] = (start + t < n) ? keys[start + t] : 0ull;
   __syncthreads();
@@ -279,11 +341,14 @@ __global__ __launch_bounds__(1024) void bitonic_local_sort_kernel(unsigned long 
 }
 
 // one global compare-exchange stage (k, j) with j >= chunk
-__global__ void bitonic_global_step_kernel(unsigned long long* keys, const int* n_dev, unsigned k, unsigned j) {
-  const unsigned n = (unsigned)max(*n_dev, 0);
+__global__ void bitonic_global_step_kernel(SortGK g, unsigned k, unsigned j) {
+  const int mi = tail_find_member(g.blk_start, blockIdx.x);
+  unsigned long long* keys = g.keys[mi];
+  const unsigned n = (unsigned)max(*g.n_dev[mi], 0);
   const unsigned npad = next_pow2(n < 1 ? 1 : n);
   if (k > npad) return;
-  for (unsigned t = blockIdx.x * blockDim.x + threadIdx.x; t < (npad >> 1); t += gridDim.x * blockDim.x) {
+  const unsigned lb = blockIdx.x - g.blk_start[mi], lgrid = g.blk_start[mi + 1] - g.blk_start[mi];
+  for (unsigned t = lb * blockDim.x + threadIdx.x; t < (npad >> 1); t += lgrid * blockDim.x) {
     const unsigned i = ((t / j) * 2 * j) + (t % j);
     const unsigned l = i + j;
     const bool desc = ((i & k) == 0);
@@ -293,13 +358,14 @@ __global__ void bitonic_global_step_kernel(unsigned long long* keys, const int* 
 }
 
 // remaining stages j = chunk/2 .. 1 of merge level k (> chunk), inside LDS
-__global__ __launch_bounds__(1024) void bitonic_local_merge_kernel(unsigned long long* keys, const int* n_dev,
-                                                                   unsigned k) {
+__global__ __launch_bounds__(1024) void bitonic_local_merge_kernel(SortGK g, unsigned k) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long sk[];
-  const unsigned n = (unsigned)max(*n_dev, 0);
+  const int mi = tail_find_member(g.blk_start, blockIdx.x);
+  unsigned long long* keys = g.keys[mi];
+  const unsigned n = (unsigned)max(*g.n_dev[mi], 0);
   const unsigned npad = next_pow2(n < 1 ? 1 : n);
   if (k > npad) return;
-  const unsigned start = blockIdx.x * (unsigned)SORT_CH;
+  const unsigned start = (unsigned)(blockIdx.x - g.blk_start[mi]) * (unsigned)SORT_CH;
   if (start >= npad) return;
   for (unsigned t = threadIdx.x; t < (unsigned)SORT_CH; t += 1024) sk[t] = keys[start + t];
   __syncthreads();
@@ -318,7 +384,11 @@ __global__ __launch_bounds__(1024) void bitonic_local_merge_kernel(unsigned long
 
 static bool g_sort_attr_done = false;
 
-int launch_sort_desc_u64(unsigned long long* keys, const int* n_dev, size_t n_max, hipStream_t s) {
+// keys[m] beyond n inside [n, npad) are treated as 0 by the local sort; for npad > chunk the caller's
+// buffers must hold npad entries (the tail workspace / merge context allocate pow2 capacity).
+int launch_sort_desc_u64_group(unsigned long long* const* keys, const int* const* n_dev, const size_t* n_max, int n,
+                               hipStream_t s) {
+  if (n < 1 || n > TG) { set_error("sort group: 1..16 arrays"); return -1; }
   if (!g_sort_attr_done) {
     SHF_HIP_OK(hipFuncSetAttribute((const void*)bitonic_local_sort_kernel,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, SORT_CH * 8));
@@ -326,71 +396,146 @@ int launch_sort_desc_u64(unsigned long long* keys, const int* n_dev, size_t n_ma
                                    hipFuncAttributeMaxDynamicSharedMemorySize, SORT_CH * 8));
     g_sort_attr_done = true;
   }
-  size_t npad = 1;
-  while (npad < n_max) npad <<= 1;
-  const unsigned nchunks = (unsigned)((npad + SORT_CH - 1) / SORT_CH);
-  // keys beyond n inside [n, npad) are treated as 0 by the local sort; for npad > chunk the
-  // caller's buffer must hold npad entries (launch_tail / merge allocate pow2 capacity).
-  hipLaunchKernelGGL(bitonic_local_sort_kernel, dim3(nchunks), dim3(1024), SORT_CH * 8, s, keys, n_dev);
-  for (size_t k = (size_t)SORT_CH * 2; k <= npad; k <<= 1) {
+  SortGK loc, glo;
+  size_t npad_max = 1;
+  int nchunks = 0, gblocks = 0;
+  for (int q = 0; q <= TG; ++q) loc.blk_start[q] = glo.blk_start[q] = 0x7fffffff;
+  for (int m = 0; m < n; ++m) {
+    size_t npad = 1;
+    while (npad < n_max[m]) npad <<= 1;
+    npad_max = std::max(npad_max, npad);
+    loc.keys[m] = glo.keys[m] = keys[m];
+    loc.n_dev[m] = glo.n_dev[m] = n_dev[m];
+    loc.blk_start[m] = nchunks;
+    glo.blk_start[m] = gblocks;
+    nchunks += (int)((npad + SORT_CH - 1) / SORT_CH);
+    gblocks += (int)grid_for((long long)(npad >> 1));
+  }
+  loc.blk_start[n] = nchunks;
+  glo.blk_start[n] = gblocks;
+  hipLaunchKernelGGL(bitonic_local_sort_kernel, dim3(nchunks), dim3(1024), SORT_CH * 8, s, loc);
+  for (size_t k = (size_t)SORT_CH * 2; k <= npad_max; k <<= 1) {
     for (size_t j = k >> 1; j >= (size_t)SORT_CH; j >>= 1)
-      hipLaunchKernelGGL(bitonic_global_step_kernel, dim3(grid_for((long long)(npad >> 1))), dim3(256), 0, s, keys,
-                         n_dev, (unsigned)k, (unsigned)j);
-    hipLaunchKernelGGL(bitonic_local_merge_kernel, dim3(nchunks), dim3(1024), SORT_CH * 8, s, keys, n_dev,
-                       (unsigned)k);
+      hipLaunchKernelGGL(bitonic_global_step_kernel, dim3(gblocks), dim3(256), 0, s, glo, (unsigned)k, (unsigned)j);
+    hipLaunchKernelGGL(bitonic_local_merge_kernel, dim3(nchunks), dim3(1024), SORT_CH * 8, s, loc, (unsigned)k);
   }
   SHF_HIP_OK(hipGetLastError());
   return 0;
 }
 
+int launch_sort_desc_u64(unsigned long long* keys, const int* n_dev, size_t n_max, hipStream_t s) {
+  return launch_sort_desc_u64_group(&keys, &n_dev, &n_max, 1, s);
+}
+
 // ---------------------------------------------------------------------------
-int launch_tail(const TailArgs& a, TailWork& ws, float* out_boxes5, float* out_probs2, hipStream_t s,
-                hipEvent_t after_logits, int phase) {
-  const int K = a.h * a.w;
-  const long long total = (long long)K * a.A;
-  if ((size_t)total > ws.cap_anchors) { set_error("tail: workspace too small"); return -1; }
-  if (a.Cf % 128) { set_error("tail: head feature width must be a multiple of 128"); return -1; }
-  if (phase != 2) {
-    SHF_HIP_OK(hipMemsetAsync(ws.counters, 0, 8 * sizeof(int), s));
-    TailK lk;
-    for (int i = 0; i < a.A; ++i) {
-      const View& f = a.feat[a.heads == 1 ? 0 : i];
-      lk.feat[i] = f.p + f.coff;
-      lk.fstride[i] = f.cstride;
-      lk.aw[i] = a.anchors[i * 4 + 2] - a.anchors[i * 4 + 0] + 1.0f;
-      lk.ah[i] = a.anchors[i * 4 + 3] - a.anchors[i * 4 + 1] + 1.0f;
+static void fill_logits_shared(const TailArgs& a, TailGK& lk) {
+  lk.Wt = a.wcls[0];  // combined [A][6][Cf] matrix prepared by the net (see net.cpp: build_tail_weights)
+  lk.bt = a.bcls[0];
+  lk.A = a.A; lk.Cf = a.Cf;
+  for (int i = 0; i < a.A; ++i) {
+    lk.aw[i] = a.anchors[i * 4 + 2] - a.anchors[i * 4 + 0] + 1.0f;
+    lk.ah[i] = a.anchors[i * 4 + 3] - a.anchors[i * 4 + 1] + 1.0f;
+  }
+}
+
+// A group of units through the proposal stage.  phase 0: everything; 1: reset + logits (the kernels that read the
+// head feature maps: `after_logits` is recorded behind them); 2: decode -> sort -> gather.
+int launch_tail_group(const TailArgs* as, TailWork* const* wss, float* const* out_boxes5, float* const* out_probs2,
+                      int n, hipStream_t s, hipEvent_t after_logits, int phase) {
+  if (n < 1 || n > TG) { set_error("tail group: 1..16 units"); return -1; }
+  const TailArgs& a0 = as[0];
+  if (a0.A > 8) { set_error("tail: at most 8 anchors per cell"); return -1; }
+  for (int m = 0; m < n; ++m) {
+    const long long total = (long long)as[m].h * as[m].w * as[m].A;
+    if ((size_t)total > wss[m]->cap_anchors) { set_error("tail: workspace too small"); return -1; }
+    if (as[m].Cf % 128) { set_error("tail: head feature width must be a multiple of 128"); return -1; }
+    if (as[m].A != a0.A || as[m].Cf != a0.Cf || as[m].wcls[0] != a0.wcls[0]) {
+      set_error("tail group: members must share the proposal layer");
+      return -1;
     }
-    lk.Wt = a.wcls[0];  // combined [A][6][Cf] matrix prepared by the net (see net.cpp: build_tail_weights)
-    lk.bt = a.bcls[0];
-    lk.logits = ws.logits;
-    lk.K = K; lk.A = a.A; lk.Cf = a.Cf; lk.w = a.w;
-    lk.counters = ws.counters;
-    hipLaunchKernelGGL(tail_logits_kernel, dim3(grid_for(((long long)K + 1) / 2 * 64)), dim3(256), 0, s, lk);
-    // from here on the tail only touches its own workspace: the head feature maps may be overwritten
+  }
+  if (phase != 2) {
+    TailResetK rk;
+    rk.n = n;
+    for (int m = 0; m < n; ++m) rk.counters[m] = wss[m]->counters;
+    hipLaunchKernelGGL(tail_reset_kernel, dim3(1), dim3(TG * 8), 0, s, rk);
+    TailGK lk;
+    fill_logits_shared(a0, lk);
+    int blocks = 0;
+    for (int q = 0; q <= TG; ++q) lk.blk_start[q] = 0x7fffffff;
+    for (int m = 0; m < n; ++m) {
+      const TailArgs& a = as[m];
+      TailGM& g = lk.m[m];
+      for (int i = 0; i < a.A; ++i) {
+        const View& f = a.feat[a.heads == 1 ? 0 : i];
+        g.feat[i] = f.p + f.coff;
+        g.fstride[i] = f.cstride;
+      }
+      g.logits = wss[m]->logits;
+      g.counters = wss[m]->counters;
+      g.K = a.h * a.w;
+      g.w = a.w;
+      lk.blk_start[m] = blocks;
+      blocks += (int)grid_for(((long long)g.K + 1) / 2 * 64);
+    }
+    lk.blk_start[n] = blocks;
+    hipLaunchKernelGGL(tail_logits_kernel, dim3(blocks), dim3(256), 0, s, lk);
+    // from here on the tails only touch their own workspaces: the head feature maps may be overwritten
     if (after_logits) SHF_HIP_OK(hipEventRecord(after_logits, s));
   }
-  if (phase == 1) return 0;
-
-  DecodeK dk;
-  dk.logits = ws.logits; dk.rec = ws.rec; dk.keys = ws.keys; dk.counters = ws.counters;
-  dk.K = K; dk.A = a.A; dk.w = a.w;
-  for (int i = 0; i < a.A * 4; ++i) dk.anchors[i] = a.anchors[i];
-  for (int i = 0; i < a.A; ++i) dk.sub_stride[i] = a.sub_stride[i] < 1 ? 1 : a.sub_stride[i];
-  dk.feat_stride = a.feat_stride;
-  dk.im_h = a.im_h; dk.im_w = a.im_w;
-  dk.min_size_scaled = a.min_size * a.im_scale;
-  dk.score_thresh = a.score_thresh;
-  dk.cls_nchw = a.cls_prob_reshape_nchw;
-  dk.bbox_nchw = a.bbox_pred_nchw;
-  dk.probs_given = a.probs_given;
-  hipLaunchKernelGGL(tail_decode_kernel, dim3(grid_for(total)), dim3(256), 0, s, dk);
-  if (launch_sort_desc_u64(ws.keys, ws.counters, (size_t)total, s)) return -1;
-  hipLaunchKernelGGL(tail_finalize_kernel, dim3(1), dim3(1), 0, s, ws.keys, ws.counters, a.pre_nms_topN);
-  const long long rmax = (a.pre_nms_topN > 0 && a.pre_nms_topN < total) ? a.pre_nms_topN : total;
-  hipLaunchKernelGGL(tail_gather_kernel, dim3(grid_for(rmax)), dim3(256), 0, s, ws.keys, ws.rec, ws.counters,
-                     out_boxes5, out_probs2);
+  if (phase == 1) {
+    SHF_HIP_OK(hipGetLastError());
+    return 0;
+  }
+  DecodeGK dk;
+  dk.A = a0.A;
+  for (int i = 0; i < a0.A * 4; ++i) dk.anchors[i] = a0.anchors[i];
+  for (int i = 0; i < a0.A; ++i) dk.sub_stride[i] = a0.sub_stride[i] < 1 ? 1 : a0.sub_stride[i];
+  dk.feat_stride = a0.feat_stride;
+  dk.score_thresh = a0.score_thresh;
+  dk.probs_given = a0.probs_given;
+  GatherGK gk;
+  gk.topN = a0.pre_nms_topN;
+  unsigned long long* keys[TG];
+  const int* n_dev[TG];
+  size_t n_max[TG];
+  int dblocks = 0, gblocks = 0;
+  for (int q = 0; q <= TG; ++q) dk.blk_start[q] = gk.blk_start[q] = 0x7fffffff;
+  for (int m = 0; m < n; ++m) {
+    const TailArgs& a = as[m];
+    const long long total = (long long)a.h * a.w * a.A;
+    DecodeGM& d = dk.m[m];
+    d.logits = wss[m]->logits; d.rec = wss[m]->rec; d.keys = wss[m]->keys; d.counters = wss[m]->counters;
+    d.K = a.h * a.w; d.w = a.w;
+    d.im_h = a.im_h; d.im_w = a.im_w;
+    d.min_size_scaled = a.min_size * a.im_scale;
+    d.cls_nchw = a.cls_prob_reshape_nchw;
+    d.bbox_nchw = a.bbox_pred_nchw;
+    dk.blk_start[m] = dblocks;
+    dblocks += (int)grid_for(total);
+    GatherGM& q = gk.m[m];
+    q.keys = wss[m]->keys; q.rec = wss[m]->rec; q.counters = wss[m]->counters;
+    q.boxes5 = out_boxes5[m]; q.probs2 = out_probs2[m];
+    const long long rmax = (a.pre_nms_topN > 0 && a.pre_nms_topN < total) ? a.pre_nms_topN : total;
+    gk.blk_start[m] = gblocks;
+    gblocks += (int)grid_for(rmax);
+    keys[m] = wss[m]->keys;
+    n_dev[m] = wss[m]->counters;
+    n_max[m] = (size_t)total;
+  }
+  dk.blk_start[n] = dblocks;
+  gk.blk_start[n] = gblocks;
+  hipLaunchKernelGGL(tail_decode_kernel, dim3(dblocks), dim3(256), 0, s, dk);
+  if (launch_sort_desc_u64_group(keys, n_dev, n_max, n, s)) return -1;
+  hipLaunchKernelGGL(tail_gather_kernel, dim3(gblocks), dim3(256), 0, s, gk);
   SHF_HIP_OK(hipGetLastError());
   return 0;
+}
+
+int launch_tail(const TailArgs& a, TailWork& ws, float* out_boxes5, float* out_probs2, hipStream_t s,
+                hipEvent_t after_logits, int phase) {
+  TailWork* w = &ws;
+  return launch_tail_group(&a, &w, &out_boxes5, &out_probs2, 1, s, after_logits, phase);
 }
 
 int launch_tail_inject(const TailArgs& a, TailWork& ws, const float* scores_nchw, const float* deltas_nchw,
@@ -399,56 +544,98 @@ int launch_tail_inject(const TailArgs& a, TailWork& ws, const float* scores_nchw
   const long long total = (long long)K * a.A;
   if ((size_t)total > ws.cap_anchors) { set_error("tail: workspace too small"); return -1; }
   SHF_HIP_OK(hipMemsetAsync(ws.counters, 0, 8 * sizeof(int), s));
-  TailK lk = {};
-  for (int i = 0; i < a.A; ++i) {
-    lk.aw[i] = a.anchors[i * 4 + 2] - a.anchors[i * 4 + 0] + 1.0f;
-    lk.ah[i] = a.anchors[i * 4 + 3] - a.anchors[i * 4 + 1] + 1.0f;
-  }
-  lk.counters = ws.counters;
+  TailGK lk = {};
+  fill_logits_shared(a, lk);
   hipLaunchKernelGGL(tail_inject_kernel, dim3(grid_for(total)), dim3(256), 0, s, scores_nchw, deltas_nchw, ws.logits,
-                     K, a.A, lk);
+                     K, a.A, lk, ws.counters);
   SHF_HIP_OK(hipGetLastError());
   return 0;
 }
 
 // ---------------------------------------------------------------------------
 // forward_net post-processing + the >thresh cut of detect() on the device
-// (lib/test.py:52-54 flip fix, :59-66 unscale, :163-167 threshold).  Rows of a unit are
-// score-descending, so the survivors are a prefix and land at base+r: the image list is
-// in the reference's concatenation order.
-// counters: [0] = base read by unit u when u is even / written when odd, [1] the other
+// (lib/test.py:52-54 flip fix, :59-66 unscale, :163-167 threshold), for a GROUP of units in one launch.  Rows of a
+// unit are score-descending, so its survivors are a prefix (found by bisection) and unit u lands behind the
+// survivors of units 0..u-1: the image list is in the reference's concatenation order.
+// dst->count: slot (pass & 1) holds the list length before this pass, slot ((pass + 1) & 1) receives the length
+// after it (two slots: no block of this launch reads what another one writes).
 // ---------------------------------------------------------------------------
-__global__ void append_dets_kernel(const float* __restrict__ boxes5, const float* __restrict__ probs2,
-                                   const int* __restrict__ R_dev, float im_w, float im_scale, int flip,
-                                   float thresh, int unit, float* __restrict__ img_dets5,
-                                   unsigned long long* __restrict__ img_keys, int* img_count, int img_cap) {
-  const int R = *R_dev;
-  const int base = img_count[unit & 1];
-  int* next = &img_count[(unit + 1) & 1];
-  if (blockIdx.x == 0 && threadIdx.x == 0 && (R == 0 || !(probs2[1] > thresh))) *next = base;
-  for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < R; r += gridDim.x * blockDim.x) {
-    const float fg = probs2[r * 2 + 1];
-    if (!(fg > thresh)) continue;
-    if (r == R - 1 || !(probs2[(r + 1) * 2 + 1] > thresh)) *next = min(base + r + 1, img_cap);
+struct AppendGM {
+  const float* boxes5;
+  const float* probs2;
+  const int* counters;  // the unit's tail counters (rows R derived like the gather stage does)
+  float im_w, im_scale;
+  int flip;
+  // destination list (per member in per-member-list mode, else the same for all)
+  float* dets5;
+  unsigned long long* keys;
+  int* count;
+  int cap;
+};
+struct AppendGK {
+  int n, topN, pass, per_member;
+  float thresh;
+  int blk_start[TG + 1];
+  AppendGM m[TG];
+};
+
+__device__ __forceinline__ int survivors(const float* probs2, int R, float thresh) {
+  int lo = 0, hi = R;  // first r with !(fg > thresh)
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (probs2[mid * 2 + 1] > thresh) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+__global__ void append_dets_kernel(AppendGK g) {
+  const int mi = tail_find_member(g.blk_start, blockIdx.x);
+  const AppendGM& p = g.m[mi];
+  const int lb = blockIdx.x - g.blk_start[mi], lgrid = g.blk_start[mi + 1] - g.blk_start[mi];
+  int base, ns;
+  if (g.per_member) {
+    base = 0;
+    ns = survivors(p.probs2, tail_rows(p.counters, g.topN, nullptr), g.thresh);
+    if (lb == 0 && threadIdx.x == 0) { p.count[0] = 0; p.count[1] = min(ns, p.cap); }
+  } else {
+    base = p.count[g.pass & 1];
+    for (int v = 0; v < mi; ++v) base += survivors(g.m[v].probs2, tail_rows(g.m[v].counters, g.topN, nullptr), g.thresh);
+    ns = survivors(p.probs2, tail_rows(p.counters, g.topN, nullptr), g.thresh);
+    if (mi == g.n - 1 && lb == 0 && threadIdx.x == 0) p.count[(g.pass + 1) & 1] = min(base + ns, p.cap);
+  }
+  for (int r = lb * blockDim.x + threadIdx.x; r < ns; r += lgrid * blockDim.x) {
     const int pos = base + r;
-    if (pos >= img_cap) continue;
-    float x1 = boxes5[r * 5 + 1], y1 = boxes5[r * 5 + 2], x2 = boxes5[r * 5 + 3], y2 = boxes5[r * 5 + 4];
-    if (flip) {  // boxes[:, [1,3]] = w - boxes[:, [3,1]]
-      const float nx1 = im_w - x2, nx2 = im_w - x1;
+    if (pos >= p.cap) continue;
+    const float fg = p.probs2[r * 2 + 1];
+    float x1 = p.boxes5[r * 5 + 1], y1 = p.boxes5[r * 5 + 2], x2 = p.boxes5[r * 5 + 3], y2 = p.boxes5[r * 5 + 4];
+    if (p.flip) {  // boxes[:, [1,3]] = w - boxes[:, [3,1]]
+      const float nx1 = p.im_w - x2, nx2 = p.im_w - x1;
       x1 = nx1;
       x2 = nx2;
     }
-    float* d = img_dets5 + (size_t)pos * 5;
-    d[0] = x1 / im_scale; d[1] = y1 / im_scale; d[2] = x2 / im_scale; d[3] = y2 / im_scale; d[4] = fg;
-    img_keys[pos] = ((unsigned long long)__float_as_uint(fg) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)pos);
+    float* d = p.dets5 + (size_t)pos * 5;
+    d[0] = x1 / p.im_scale; d[1] = y1 / p.im_scale; d[2] = x2 / p.im_scale; d[3] = y2 / p.im_scale; d[4] = fg;
+    p.keys[pos] = ((unsigned long long)__float_as_uint(fg) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)pos);
   }
 }
 
-int launch_append_dets(const float* boxes5, const float* probs2, const int* R_dev, int r_max, float im_w,
-                       float im_scale, int flip, float thresh, int unit, float* img_dets5,
-                       unsigned long long* img_keys, int* img_count, int img_cap, hipStream_t s) {
-  hipLaunchKernelGGL(append_dets_kernel, dim3(grid_for(r_max < 1 ? 1 : r_max)), dim3(256), 0, s, boxes5, probs2,
-                     R_dev, im_w, im_scale, flip, thresh, unit, img_dets5, img_keys, img_count, img_cap);
+int launch_append_dets_group(const AppendUnit* us, int n, int topN, float thresh, int pass, int per_member,
+                             hipStream_t s) {
+  if (n < 1 || n > TG) { set_error("append group: 1..16 units"); return -1; }
+  AppendGK g;
+  g.n = n; g.topN = topN; g.pass = pass; g.per_member = per_member; g.thresh = thresh;
+  int blocks = 0;
+  for (int q = 0; q <= TG; ++q) g.blk_start[q] = 0x7fffffff;
+  for (int m = 0; m < n; ++m) {
+    AppendGM& d = g.m[m];
+    d.boxes5 = us[m].boxes5; d.probs2 = us[m].probs2; d.counters = us[m].counters;
+    d.im_w = us[m].im_w; d.im_scale = us[m].im_scale; d.flip = us[m].flip;
+    d.dets5 = us[m].dets5; d.keys = us[m].keys; d.count = us[m].count; d.cap = us[m].cap;
+    g.blk_start[m] = blocks;
+    blocks += (int)grid_for(us[m].r_max < 1 ? 1 : us[m].r_max);
+  }
+  g.blk_start[n] = blocks;
+  hipLaunchKernelGGL(append_dets_kernel, dim3(blocks), dim3(256), 0, s, g);
   SHF_HIP_OK(hipGetLastError());
   return 0;
 }
