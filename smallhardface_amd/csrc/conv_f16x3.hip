@@ -883,7 +883,9 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
       const int ci = idx / (PH * PW), r = idx - ci * (PH * PW);
       const int py = r / PW, pxx = r - py * PW;
       const int gy = ty0 - 2 + py, gx = tx0 - 2 + pxx;
-      patch[idx] = ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) ? img[((size_t)ci * H + gy) * W + gx] : 0.f;
+      const float pv = ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) ? img[((size_t)ci * H + gy) * W + gx] : 0.f;
+      patch[idx] = pv;
+      amax1 = fmaxf(amax1, fabsf(pv));  // the image itself is split to fp16 hi/lo for conv1_1's MFMAs
     }
     if (tid < HPP) {
       const int qy = tid / HTW, qx = tid - qy * HTW;
@@ -947,8 +949,9 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
         for (int r = 0; r < 16; ++r) {
           const int hq = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh1;
           // valid[]: 0 outside the image (conv1_2's zero padding, not conv1_1 evaluated out there)
-          const float v = ok[r] ? fmaxf(cm[r] + cc[r] * LO_INV + bias, 0.f) : 0.f;
-          amax1 = fmaxf(amax1, v);
+          const float pre = cm[r] + cc[r] * LO_INV + bias;
+          const float v = ok[r] ? fmaxf(pre, 0.f) : 0.f;
+          amax1 = fmaxf(amax1, pre != pre ? __builtin_inff() : v);  // (fmaxf would swallow a NaN)
           const _Float16 h = (_Float16)v;
           *(_Float16*)(At + hq * ROWB) = h;
           *(_Float16*)(At + hq * ROWB + 64) = (_Float16)((v - (float)h) * LO_SCALE);

@@ -1,0 +1,187 @@
+"""Per-kernel and per-layer roofline evidence from the rocprofv3 passes of tools/make_profiles.sh.
+
+    python tools/layer_table.py <prof_dir> <dst_dir> <tag>
+
+Reads <prof_dir>/trace (kernel trace) and <prof_dir>/pmc_N (one counter set each), all runs of the same command
+(bench.py --steps 2 --warmup 1 ...): the dispatch sequence is deterministic, so dispatch k of one run is dispatch k
+of another.  Writes
+  <tag>_pmc.json    per kernel name: launches, avg µs, counters per launch, derived HBM bytes / MFMA-busy
+  <tag>_layers.csv  one row per convolution launch of ONE image (the last complete one), in graph order
+Counter arithmetic (MI355X_MICROARCH.md): HBM bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (gfx950 FETCH_SIZE counts
+128-B requests as 64 B; both are reported in KiB); SQ_VALU_MFMA_BUSY_CYCLES counts cycles per SIMD-issued MFMA
+(32 per v_mfma_f32_32x32x16_f16), so mfma_busy = MFMA_BUSY / (GRBM_GUI_ACTIVE x 4 SIMDs x 256 CUs) with
+GRBM_GUI_ACTIVE the chip-active cycles of the dispatch (max over XCDs).
+"""
+import csv
+import glob
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+N_CU, N_SIMD = 256, 4
+PEAK_F16 = 2500.0
+
+
+def load_trace(d):
+    f = sorted(glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True))[-1]
+    rows = list(csv.DictReader(open(f)))
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    return rows
+
+
+def load_counters(d):
+    """{counter: [value per dispatch in start order]} (+ 'names'), summed / maxed over the XCD dimension rows."""
+    files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+    per = {}
+    order = {}
+    for f in files:
+        for r in csv.DictReader(open(f)):
+            did = int(r["Dispatch_Id"])
+            order[did] = (int(r.get("Start_Timestamp", 0) or 0), r["Kernel_Name"])
+            c = r["Counter_Name"]
+            v = float(r["Counter_Value"])
+            a = per.setdefault(c, {}).setdefault(did, [0.0, 0.0])
+            a[0] += v
+            a[1] = max(a[1], v)
+    dids = sorted(order, key=lambda k: (order[k][0], k))
+    out = {"names": [order[k][1] for k in dids]}
+    for c, dd in per.items():
+        out[c] = [dd.get(k, [0.0, 0.0])[0] for k in dids]
+        out[c + "#max"] = [dd.get(k, [0.0, 0.0])[1] for k in dids]
+    return out
+
+
+def short(name):
+    n = name.split("(")[0]
+    for p in ("void ", "shf::"):
+        n = n.replace(p, "")
+    return n.strip()
+
+
+def conv_layers_of_the_bench_image():
+    """(name, cin, cout, k, pixels summed over the 10 units) for every MFMA conv launch of an image, in launch order."""
+    from smallhardface_amd import prototxt as P
+    msg = P._add_dimension_reduction(P.build_test_template(True))
+    sides = [112, 304, 608, 1008, 1408]
+    layers, down, cin_of = [], {"data": 1}, {"data": 3}
+    for L in msg.getall("layer"):
+        t, name = L.get("type"), L.get("name")
+        bot = L.getall("bottom")
+        top = L.getall("top")
+        if t == "Convolution":
+            cp = L.get("convolution_param")
+            cout, k = int(cp.get("num_output")), int(cp.get("kernel_size"))
+            d = down[bot[0]]
+            px = 2 * sum((s // d) ** 2 for s in sides)
+            layers.append((name, cin_of[bot[0]], cout, k, px))
+            down[top[0]], cin_of[top[0]] = d, cout
+        elif t == "Pooling":
+            down[top[0]], cin_of[top[0]] = down[bot[0]] * 2, cin_of[bot[0]]
+        elif t == "Deconvolution":
+            down[top[0]], cin_of[top[0]] = down[bot[0]] // 2, cin_of[bot[0]]
+        elif t == "Concat":
+            down[top[0]], cin_of[top[0]] = down[bot[0]], sum(cin_of[b] for b in bot)
+        else:
+            for tp in top:
+                if bot:
+                    down[tp], cin_of[tp] = down.get(bot[0], 1), cin_of.get(bot[0], 0)
+    # launches: conv1_1 rides inside conv1_2's launch; cls/bbox 1x1s are part of the tail (not MFMA launches)
+    out = []
+    for name, cin, cout, k, px in layers:
+        if name.startswith("cls_score") or name.startswith("bbox_pred"):
+            continue
+        out.append([name, cin, cout, k, px, 2.0 * px * cin * cout * k * k])
+    assert out[0][0] == "conv1_1" and out[1][0] == "conv1_2"
+    out[1][0] = "conv1_1+conv1_2"
+    out[1][5] += out[0][5]
+    return out[1:]
+
+
+def main():
+    prof, dst, tag = sys.argv[1], sys.argv[2], sys.argv[3]
+    from tools.kernel_hash import kernel_source_hash
+    trace = load_trace(os.path.join(prof, "trace"))
+    passes = [load_counters(p) for p in sorted(glob.glob(os.path.join(prof, "pmc_*"))) if os.path.isdir(p)]
+    counters = {}
+    for p in passes:
+        for k, v in p.items():
+            if k != "names":
+                counters[k] = (p["names"], v)
+    names = [r["Kernel_Name"] for r in trace]
+    dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in trace]
+    # sanity: every pass saw the same dispatch sequence
+    for c, (nm, v) in counters.items():
+        if len(nm) != len(names) or any(short(a) != short(b) for a, b in zip(nm, names)):
+            print("WARNING: dispatch sequence of counter %s differs from the trace (%d vs %d)" % (c, len(nm), len(names)))
+
+    def cval(c, i):
+        nm, v = counters.get(c, (None, None))
+        return v[i] if v is not None and i < len(v) else None
+
+    # ---- per kernel name
+    per = {}
+    for i, n in enumerate(names):
+        k = short(n)
+        if not ("conv" in k or "tail" in k or "bitonic" in k or "append" in k or "scan" in k or "vote" in k or "iou" in k):
+            continue
+        a = per.setdefault(k, {"launches": 0, "us": 0.0})
+        a["launches"] += 1
+        a["us"] += dur[i]
+        for c in counters:
+            if cval(c, i) is not None:
+                a[c] = a.get(c, 0.0) + cval(c, i)
+    kernels = {}
+    for k, a in per.items():
+        n = a["launches"]
+        e = {"launches": n, "avg_us": a["us"] / n}
+        for c in counters:
+            if c in a:
+                e[c + "_per_launch"] = a[c] / n
+        if "FETCH_SIZE" in a and "WRITE_SIZE" in a:
+            e["hbm_bytes_per_launch"] = (2.0 * a["FETCH_SIZE"] + a["WRITE_SIZE"]) * 1024.0 / n
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in a and a.get("GRBM_GUI_ACTIVE#max"):
+            e["mfma_busy"] = a["SQ_VALU_MFMA_BUSY_CYCLES"] / (a["GRBM_GUI_ACTIVE#max"] * N_SIMD * N_CU)
+            e["effective_clock_ghz"] = a["GRBM_GUI_ACTIVE#max"] / (a["us"] * 1e3)
+        if "SQ_LDS_BANK_CONFLICT" in a and a.get("SQ_LDS_IDX_ACTIVE"):
+            e["lds_bank_conflict_frac"] = a["SQ_LDS_BANK_CONFLICT"] / a["SQ_LDS_IDX_ACTIVE"]
+        kernels[k] = e
+    json.dump({"kernel_source_hash": kernel_source_hash(), "command": "bench.py --steps 2 --warmup 1 --no-events",
+               "note": "profiled passes clock lower than un-profiled runs (DVFS): compare ratios, not absolute µs",
+               "kernels": kernels}, open(os.path.join(dst, tag + "_pmc.json"), "w"), indent=1, sort_keys=True)
+
+    # ---- per layer of the last complete image
+    pcs = [i for i, n in enumerate(names) if "f16x3_pc_kernel" in n]
+    a = pcs[-1]
+    conv_idx = [i for i in range(a, len(names)) if "conv_mfma" in names[i]]
+    layers = conv_layers_of_the_bench_image()
+    conv_idx = conv_idx[:len(layers)]
+    rows = []
+    for (lname, cin, cout, k, px, fl), i in zip(layers, conv_idx):
+        us = dur[i]
+        tf = fl / (us * 1e-6) / 1e12
+        alg_bytes = 4.0 * px * (cin + cout)   # input + output once, 4 B per element (weights: < 10 MB, L2-resident)
+        hbm = None
+        if cval("FETCH_SIZE", i) is not None and cval("WRITE_SIZE", i) is not None:
+            hbm = (2.0 * cval("FETCH_SIZE", i) + cval("WRITE_SIZE", i)) * 1024.0
+        busy = None
+        if cval("SQ_VALU_MFMA_BUSY_CYCLES", i) is not None and cval("GRBM_GUI_ACTIVE#max", i):
+            busy = cval("SQ_VALU_MFMA_BUSY_CYCLES", i) / (cval("GRBM_GUI_ACTIVE#max", i) * N_SIMD * N_CU)
+        rows.append({"layer": lname, "kernel": short(names[i]), "cin": cin, "cout": cout, "k": k, "pixels": px,
+                     "us": round(us, 1), "algorithmic_gflop": round(fl / 1e9, 2), "algorithmic_tflops": round(tf, 1),
+                     "frac_of_fp16_peak": round(tf / PEAK_F16, 4), "frac_issued": round(3.0 * tf / PEAK_F16, 4),
+                     "mfma_busy": None if busy is None else round(busy, 4),
+                     "hbm_bytes": None if hbm is None else int(hbm), "algorithmic_bytes": int(alg_bytes),
+                     "hbm_over_algorithmic": None if hbm is None else round(hbm / alg_bytes, 2)})
+    with open(os.path.join(dst, tag + "_layers.csv"), "w", newline="") as f:
+        w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
+        w.writeheader()
+        w.writerows(rows)
+    for r in rows:
+        print(r)
+    print("sum of conv µs of one image: %.1f; algorithmic GFLOP %.1f" % (sum(r["us"] for r in rows), sum(r["algorithmic_gflop"] for r in rows)))
+
+
+if __name__ == "__main__":
+    main()
