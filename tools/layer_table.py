@@ -9,8 +9,10 @@ of another.  Writes
   <tag>_layers.csv  one row per convolution launch of ONE image (the last complete one), in graph order
 Counter arithmetic (MI355X_MICROARCH.md): HBM bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (gfx950 FETCH_SIZE counts
 128-B requests as 64 B; both are reported in KiB); SQ_VALU_MFMA_BUSY_CYCLES counts cycles per SIMD-issued MFMA
-(32 per v_mfma_f32_32x32x16_f16), so mfma_busy = MFMA_BUSY / (GRBM_GUI_ACTIVE x 4 SIMDs x 256 CUs) with
-GRBM_GUI_ACTIVE the chip-active cycles of the dispatch (max over XCDs).
+(32 per v_mfma_f32_32x32x16_f16) summed over all SIMDs (checked: the value equals 32 x the MFMA count of the launch),
+GRBM_GUI_ACTIVE is reported summed over the 8 XCDs, so the dispatch lasted GRBM_GUI_ACTIVE / 8 cycles and
+mfma_busy = MFMA_BUSY / (GRBM_GUI_ACTIVE / 8 x 4 SIMDs x 256 CUs); effective clock = GRBM_GUI_ACTIVE / 8 / duration.
+mfma_busy is utilisation AT THE SUSTAINED CLOCK; x effective_clock / 2.4 GHz gives the fraction of the nominal peak.
 """
 import csv
 import glob
@@ -20,7 +22,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-N_CU, N_SIMD = 256, 4
+N_CU, N_SIMD, N_XCD = 256, 4, 8
 PEAK_F16 = 2500.0
 
 
@@ -63,6 +65,8 @@ def short(name):
 def conv_layers_of_the_bench_image():
     """(name, cin, cout, k, pixels summed over the 10 units) for every MFMA conv launch of an image, in launch order."""
     from smallhardface_amd import prototxt as P
+    from smallhardface_amd.config import cfg_from_file
+    cfg_from_file(os.path.join(ROOT, "configs", "smallhardface.toml"))   # different_dilation + dim_red, like bench.py
     msg = P._add_dimension_reduction(P.build_test_template(True))
     sides = [112, 304, 608, 1008, 1408]
     layers, down, cin_of = [], {"data": 1}, {"data": 3}
@@ -111,14 +115,25 @@ def main():
                 counters[k] = (p["names"], v)
     names = [r["Kernel_Name"] for r in trace]
     dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in trace]
-    # sanity: every pass saw the same dispatch sequence
+    # Dispatch k of kernel NAME in one run is dispatch k of that name in another (launches of one kernel are in
+    # stream order; kernels of different streams may interleave differently from run to run).
+    def occurrence_index(nm):
+        seen, out = {}, []
+        for n in nm:
+            k = short(n)
+            out.append((k, seen.get(k, 0)))
+            seen[k] = seen.get(k, 0) + 1
+        return out
+    trace_occ = occurrence_index(names)
+    cmap = {}
     for c, (nm, v) in counters.items():
-        if len(nm) != len(names) or any(short(a) != short(b) for a, b in zip(nm, names)):
-            print("WARNING: dispatch sequence of counter %s differs from the trace (%d vs %d)" % (c, len(nm), len(names)))
+        occ = occurrence_index(nm)
+        cmap[c] = {o: v[i] for i, o in enumerate(occ)}
+        if sorted(occ) != sorted(trace_occ):
+            print("WARNING: counter pass %s saw a different set of dispatches than the trace (%d vs %d)" % (c, len(occ), len(names)))
 
     def cval(c, i):
-        nm, v = counters.get(c, (None, None))
-        return v[i] if v is not None and i < len(v) else None
+        return cmap.get(c, {}).get(trace_occ[i])
 
     # ---- per kernel name
     per = {}
@@ -142,8 +157,10 @@ def main():
         if "FETCH_SIZE" in a and "WRITE_SIZE" in a:
             e["hbm_bytes_per_launch"] = (2.0 * a["FETCH_SIZE"] + a["WRITE_SIZE"]) * 1024.0 / n
         if "SQ_VALU_MFMA_BUSY_CYCLES" in a and a.get("GRBM_GUI_ACTIVE#max"):
-            e["mfma_busy"] = a["SQ_VALU_MFMA_BUSY_CYCLES"] / (a["GRBM_GUI_ACTIVE#max"] * N_SIMD * N_CU)
-            e["effective_clock_ghz"] = a["GRBM_GUI_ACTIVE#max"] / (a["us"] * 1e3)
+            cyc = a["GRBM_GUI_ACTIVE"] / N_XCD
+            e["mfma_busy"] = a["SQ_VALU_MFMA_BUSY_CYCLES"] / (cyc * N_SIMD * N_CU)
+            e["effective_clock_ghz"] = cyc / (a["us"] * 1e3)
+            e["mfma_busy_x_clock_over_2p4"] = e["mfma_busy"] * e["effective_clock_ghz"] / 2.4
         if "SQ_LDS_BANK_CONFLICT" in a and a.get("SQ_LDS_IDX_ACTIVE"):
             e["lds_bank_conflict_frac"] = a["SQ_LDS_BANK_CONFLICT"] / a["SQ_LDS_IDX_ACTIVE"]
         kernels[k] = e
@@ -166,8 +183,8 @@ def main():
         if cval("FETCH_SIZE", i) is not None and cval("WRITE_SIZE", i) is not None:
             hbm = (2.0 * cval("FETCH_SIZE", i) + cval("WRITE_SIZE", i)) * 1024.0
         busy = None
-        if cval("SQ_VALU_MFMA_BUSY_CYCLES", i) is not None and cval("GRBM_GUI_ACTIVE#max", i):
-            busy = cval("SQ_VALU_MFMA_BUSY_CYCLES", i) / (cval("GRBM_GUI_ACTIVE#max", i) * N_SIMD * N_CU)
+        if cval("SQ_VALU_MFMA_BUSY_CYCLES", i) is not None and cval("GRBM_GUI_ACTIVE", i):
+            busy = cval("SQ_VALU_MFMA_BUSY_CYCLES", i) / (cval("GRBM_GUI_ACTIVE", i) / N_XCD * N_SIMD * N_CU)
         rows.append({"layer": lname, "kernel": short(names[i]), "cin": cin, "cout": cout, "k": k, "pixels": px,
                      "us": round(us, 1), "algorithmic_gflop": round(fl / 1e9, 2), "algorithmic_tflops": round(tf, 1),
                      "frac_of_fp16_peak": round(tf / PEAK_F16, 4), "frac_issued": round(3.0 * tf / PEAK_F16, 4),
