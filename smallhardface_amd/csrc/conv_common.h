@@ -162,7 +162,7 @@ __device__ __forceinline__ void conv_store_split4(float* __restrict__ pixel, int
   *(float2*)(d + 64) = make_float2(__builtin_bit_cast(float, l01), __builtin_bit_cast(float, l23));
 }
 
-template <int BN, int NT>
+template <int BN, int NT, int ROWS = 16>
 __device__ __forceinline__ void conv_flush_tile(const float* __restrict__ Cs, int tid, int ty0, int tx0, int H, int W,
                                                 int b, int cout0, float* __restrict__ gout, int out_stride,
                                                 float* __restrict__ gpool, int pool_stride, bool write_main,
@@ -179,7 +179,7 @@ __device__ __forceinline__ void conv_flush_tile(const float* __restrict__ Cs, in
     float* g = gout + ((size_t)(b * H + y0) * W + x0) * out_stride + cout0 + cg * 4;
     const size_t row_pitch = (size_t)W * out_stride;
 #pragma unroll
-    for (int r = 0; r < 16 / YS; ++r) {
+    for (int r = 0; r < ROWS / YS; ++r) {
 #pragma unroll
       for (int c = 0; c < XS; ++c) {
         const int y = y0 + r * YS, x = x0 + c * PPI;
@@ -197,11 +197,11 @@ __device__ __forceinline__ void conv_flush_tile(const float* __restrict__ Cs, in
   if (gpool) {
     const int Hp = (H + 1) >> 1, Wp = (W + 1) >> 1;
 #pragma unroll
-    for (int k = 0; k < (64 + PPI - 1) / PPI; ++k) {
+    for (int k = 0; k < (ROWS * 4 + PPI - 1) / PPI; ++k) {
       const int pp = p0 + k * PPI;
       const int ly = (pp >> 3) * 2, lx = (pp & 7) * 2;
       const int y = ty0 + ly, x = tx0 + lx;
-      if (pp < 64 && y < H && x < W) {
+      if (pp < ROWS * 4 && y < H && x < W) {
         // windows on a ragged edge are clipped like Caffe's (pooling_layer.cu:24-27)
         const float* c0 = Cs + (ly * 16 + lx) * (BN + CS_PAD) + cg * 4;
         float4 m = make_float4(-3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f);

@@ -44,6 +44,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef F16X3_W4_PIN
 #define F16X3_W4_PIN 0       // 1: pin the fp16 split inside its k-step (fewer cycles, but measured SLOWER end to end: see below)
 #endif
+#ifndef F16X3_W4_ROWPAD
+#define F16X3_W4_ROWPAD 96   // 4-wave kernel: extra bytes per halo-tile ROW in LDS (0 = contiguous pixels).  A fragment's two
+                             // pixel rows (dy = 0 / 1) are 18 pixels = 162 sixteen-byte groups apart: 2 (mod 16), and the
+                             // 16 lanes of a ds_read_b128 group then share banks two by two (SQ_LDS_BANK_CONFLICT: 37 % of
+                             // the LDS cycles, profiles/r02_pmc.json).  +96 B makes the row distance 8 (mod 16): conflict-free.
+#endif
 #ifndef F16X3_CONV_MID
 #define F16X3_CONV_MID 1   // 1: split the next halo tile to fp16 hi/lo in the middle of the last stage's MFMAs
 #endif
@@ -446,17 +452,22 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_kernel(ConvK p) {
 // of slack), the next chunk's halo tile is fetched, split and parked in registers under the last stage.
 // IN_SPLIT: the input blob is in the split-fp16 activation format (written by the producer's epilogue): the
 // halo pieces are already [hi | lo] fp16 and go to LDS as they are -- no conversion anywhere in the K loop.
-template <bool IN_SPLIT>
+// MT_: 2x16-pixel MFMA row tiles per wave.  4 = the 16x16-pixel block tile above; 2 = an 8x16-pixel tile (wave 64 px x
+// 64 couts, half the accumulators) for launches whose block count quantises badly on 256 CUs -- conv5_x on the bench
+// pyramid is 528 blocks = 2.06 rounds of 16x16 tiles but 960 half-size blocks = 3.75 rounds (launcher: w4_pick_mt).
+template <bool IN_SPLIT, int MT_>
 __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4_kernel(ConvK p) {
   using namespace f16x3;
+  constexpr int TH = 4 * MT_, HTH = TH + 2, HP = HTH * HTW;  // (shadow the 16-row constants of namespace f16x3)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 #ifdef SHF_CONV_TIMING
   const unsigned long long t_entry = __builtin_amdgcn_s_memtime(), r_entry = __builtin_amdgcn_s_memrealtime();
 #endif
-  constexpr int BN = 128, MT = 4, NT = 256;
+  constexpr int BN = 128, MT = MT_, NT = 256;
   constexpr int ALD = (HP * 8 + NT - 1) / NT;  // float4 halo pieces per thread: 11
-  unsigned char* As = smem;                    // [HP][ROWB]
-  unsigned char* Bs = smem + HP * ROWB;        // [2][3][BN][ROWB]
+  constexpr int HPITCH = HTW * ROWB + F16X3_W4_ROWPAD;  // bytes per halo-tile row
+  unsigned char* As = smem;                    // [HTH][HPITCH]: pixel (hy, hx) at hy * HPITCH + hx * ROWB
+  unsigned char* Bs = smem + HTH * HPITCH;     // [2][3][BN][ROWB]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wn = wave & 1, wm = wave >> 1;
@@ -522,11 +533,12 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4_kernel(ConvK p) {
     v = make_float4(x0, x1, x2, x3);
   };
   auto store_piece = [&](const float4& v, int j) {
+    const int rowpad = (((tid >> 3) + 32 * j) / HTW) * F16X3_W4_ROWPAD;  // halo pixel hp = tid/8 + 32 j sits in row hp / 18
     if constexpr (IN_SPLIT) {  // 16-B piece q of the pixel's 128 B: hi pieces 0..3, lo pieces 4..7 = row offset q * 16
-      *(float4*)(As + (tid >> 3) * ROWB + (tid & 7) * 16 + j * 32 * ROWB) = v;
+      *(float4*)(As + (tid >> 3) * ROWB + (tid & 7) * 16 + j * 32 * ROWB + rowpad) = v;
     } else {
-      *(float2*)(As + a_loff0 + j * 32 * ROWB) = make_float2(v.x, v.y);
-      *(float2*)(As + a_loff0 + j * 32 * ROWB + 64) = make_float2(v.z, v.w);
+      *(float2*)(As + a_loff0 + j * 32 * ROWB + rowpad) = make_float2(v.x, v.y);
+      *(float2*)(As + a_loff0 + j * 32 * ROWB + rowpad + 64) = make_float2(v.z, v.w);
     }
   };
   constexpr int SLAB_B = BN * ROWB;
@@ -568,7 +580,7 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4_kernel(ConvK p) {
   row_to_pixel(i, dy, px);
   int a_off[MT], b_off[2];
 #pragma unroll
-  for (int t = 0; t < MT; ++t) a_off[t] = ((wm * 2 * MT + t * 2 + dy) * HTW + px) * ROWB + kh * 16;
+  for (int t = 0; t < MT; ++t) a_off[t] = (wm * 2 * MT + t * 2 + dy) * HPITCH + px * ROWB + kh * 16;
 #pragma unroll
   for (int t = 0; t < 2; ++t) b_off[t] = (wn * 64 + t * 32 + i) * ROWB + kh * 16;
   f32x16 accm[MT][2], accc[MT][2];
@@ -608,7 +620,7 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4_kernel(ConvK p) {
     const int st_next = st + 1 < NST ? st + 1 : st;  // the last stage re-fetches itself (unused) instead of branching
     const int buf_next = (st + 1) & 1;
     const float* inc_ = gin + (c + 1) * KC;
-    const unsigned char* Arow = As + (ky * HTW) * ROWB;
+    const unsigned char* Arow = As + ky * HPITCH;
     const unsigned char* Bst = Bs + (st & 1) * (3 * BN * ROWB);
     half8 fa[2][2 * MT], fb[2][4];
     auto load_frag = [&](int s_, half8* a, half8* bf) {
@@ -685,12 +697,12 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4_kernel(ConvK p) {
         // next step's 12 fragment reads go out under the first 12 MFMAs (12 more to land), the VMEM
         // issues are spread over the second half
 #pragma unroll
-        for (int g = 0; g < 12; ++g) {
+        for (int g = 0; g < 2 * MT + 4; ++g) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
           __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
 #pragma unroll
-        for (int g = 0; g < 9; ++g) {
+        for (int g = 0; g < 6 * MT - (2 * MT + 4) - 3; ++g) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
           if (g < n_vmem) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
         }
@@ -759,7 +771,7 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4_kernel(ConvK p) {
 #ifdef SHF_CONV_TIMING_STEPS
     const unsigned long long te2 = __builtin_amdgcn_s_memtime();
 #endif
-    conv_flush_tile<BN, NT>(Cs, tid, ty0, tx0, H, W, b, ct * BN, gout, p.out_stride, mem.pool, p.pool_stride,
+    conv_flush_tile<BN, NT, TH>(Cs, tid, ty0, tx0, H, W, b, ct * BN, gout, p.out_stride, mem.pool, p.pool_stride,
                             !(p.relu & 8), (p.relu & 32) != 0, (p.relu & 64) != 0);
 #ifdef SHF_CONV_TIMING_STEPS
     const unsigned long long te3 = __builtin_amdgcn_s_memtime();
@@ -1131,6 +1143,30 @@ bool conv_f16x3_eligible(int Cin, int Cout, int k, int pad, int dil) {
   return k == 3 && dil_ok && pad == dil && Cin % 32 == 0 && Cout % 64 == 0;
 }
 
+// 4-wave kernel: 16-row tiles (MT 4) or 8-row tiles (MT 2)?  A launch runs in ceil(blocks / CUs) rounds of one block
+// per CU; an 8-row block costs ~0.56 of a 16-row one (half the MFMAs, the same weight traffic per stage and the same
+// prologue / epilogue latencies).  SHF_F16X3_W4_MT = 2 / 4 forces the choice (experiments).
+static int w4_pick_mt(const ConvArgs* as, int n, int nct) {
+  static const int forced = getenv("SHF_F16X3_W4_MT") ? atoi(getenv("SHF_F16X3_W4_MT")) : 0;
+  if (forced == 2 || forced == 4) return forced;
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
+      cus = 256;
+  }
+  long long t4 = 0, t2 = 0;
+  for (int i = 0; i < n; ++i) {
+    const long long tx = (as[i].in.W + f16x3::TW - 1) / f16x3::TW, B = as[i].in.B;
+    t4 += B * tx * ((as[i].in.H + 15) / 16);
+    t2 += B * tx * ((as[i].in.H + 7) / 8);
+  }
+  const double c4 = (double)((t4 * nct + cus - 1) / cus), c2 = 0.56 * (double)((t2 * nct + cus - 1) / cus);
+  return c2 < c4 ? 2 : 4;
+}
+
+int conv_f16x3_w4_mt(const ConvArgs* as, int n) { return w4_pick_mt(as, n, as[0].out.C / 128); }
+
 template <int BN, bool FUSE1, int DIL = 1, int KS = 3>
 static int launch_f16x3_t(const ConvArgs* as, int n, hipStream_t s) {
   using namespace f16x3;
@@ -1154,6 +1190,10 @@ static int launch_f16x3_t(const ConvArgs* as, int n, hipStream_t s) {
   p.b1 = a.b1;
   long long tiles = 0;
   bool vec_ok = !(getenv("SHF_CONV_SCALAR_EPILOGUE") && atoi(getenv("SHF_CONV_SCALAR_EPILOGUE")));
+  // tile height: 16 rows, or 8 for the 4-wave kernel when that quantises better on this chip (w4_pick_mt)
+  const bool w4_path = BN == 128 && !FUSE1 && DIL == 1 && KS == 3 && conv_f16x3_uses_w4(p.Cin);
+  const int mt = w4_path ? w4_pick_mt(as, n, p.nct) : 4;
+  const int th = 4 * mt;
   for (int i = 0; i < n; ++i) {
     const ConvArgs& q = as[i];
     vec_ok = vec_ok && (q.out.cstride % 4 == 0) && (q.out.coff % 4 == 0) && (((uintptr_t)q.out.p & 15) == 0) &&
@@ -1172,7 +1212,7 @@ static int launch_f16x3_t(const ConvArgs* as, int n, hipStream_t s) {
     m.img = q.img;
     m.B = q.in.B; m.H = q.in.H; m.W = q.in.W;
     m.tiles_x = (m.W + TW - 1) / TW;
-    m.tiles_per_img = m.tiles_x * ((m.H + TH - 1) / TH);
+    m.tiles_per_img = m.tiles_x * ((m.H + th - 1) / th);
     m.tile_start = (int)tiles;
     p.tile_starts[i] = (int)tiles;
     tiles += (long long)m.tiles_per_img * m.B;
@@ -1200,11 +1240,14 @@ static int launch_f16x3_t(const ConvArgs* as, int n, hipStream_t s) {
     const size_t lds_pc = 2 * HPP * ROWB + 2 * 3 * (size_t)BN * ROWB + 3 * (TH + 4) * (TW + 4) * sizeof(float) + HPP;
     hipLaunchKernelGGL(conv_mfma_f16x3_pc_kernel, dim3((unsigned)tiles), dim3(512), lds_pc, s, p);
   }
-  else if (BN == 128 && !FUSE1 && DIL == 1 && KS == 3 && conv_f16x3_uses_w4(p.Cin)) {
-    if (a.in_split)
-      hipLaunchKernelGGL(conv_mfma_f16x3_w4_kernel<true>, dim3((unsigned)(tiles * p.nct)), dim3(256), lds, s, p);
-    else
-      hipLaunchKernelGGL(conv_mfma_f16x3_w4_kernel<false>, dim3((unsigned)(tiles * p.nct)), dim3(256), lds, s, p);
+  else if (w4_path) {
+    const size_t lds4 = std::max((size_t)(th + 2) * ((TW + 2) * ROWB + F16X3_W4_ROWPAD) + 2 * 3 * (size_t)BN * ROWB,
+                                 (size_t)16 * th * (BN + CS_PAD) * sizeof(float));
+    const dim3 grid((unsigned)(tiles * p.nct));
+    if (mt == 4 && a.in_split) hipLaunchKernelGGL((conv_mfma_f16x3_w4_kernel<true, 4>), grid, dim3(256), lds4, s, p);
+    else if (mt == 4) hipLaunchKernelGGL((conv_mfma_f16x3_w4_kernel<false, 4>), grid, dim3(256), lds4, s, p);
+    else if (a.in_split) hipLaunchKernelGGL((conv_mfma_f16x3_w4_kernel<true, 2>), grid, dim3(256), lds4, s, p);
+    else hipLaunchKernelGGL((conv_mfma_f16x3_w4_kernel<false, 2>), grid, dim3(256), lds4, s, p);
   } else if (a.in_split) {
     set_error("conv f16x3: split-format input reached a kernel other than the 4-wave one");
     return -1;
@@ -1246,9 +1289,13 @@ int conv_f16x3_init_attributes() {
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   SHF_HIP_OK(hipFuncSetAttribute((const void*)conv_mfma_f16x3_kernel<64, false, 4, 3>,
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  SHF_HIP_OK(hipFuncSetAttribute((const void*)conv_mfma_f16x3_w4_kernel<false>,
+  SHF_HIP_OK(hipFuncSetAttribute((const void*)conv_mfma_f16x3_w4_kernel<false, 4>,
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  SHF_HIP_OK(hipFuncSetAttribute((const void*)conv_mfma_f16x3_w4_kernel<true>,
+  SHF_HIP_OK(hipFuncSetAttribute((const void*)conv_mfma_f16x3_w4_kernel<true, 4>,
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  SHF_HIP_OK(hipFuncSetAttribute((const void*)conv_mfma_f16x3_w4_kernel<false, 2>,
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  SHF_HIP_OK(hipFuncSetAttribute((const void*)conv_mfma_f16x3_w4_kernel<true, 2>,
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   SHF_HIP_OK(hipFuncSetAttribute((const void*)conv_mfma_f16x3_pc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                  160 * 1024));

@@ -135,13 +135,14 @@ struct Layer {
 };
 
 // the first 8 classes are the instantiations of conv_mfma_f32_kernel, named like rocprofv3 prints them
-enum ProfClass { PC_CONV_MFMA, PC_CONV_MFMA_1 = 1, PC_CONV_MFMA_7 = 7, PC_CONV_F16X3_128, PC_CONV_F16X3_W4, PC_CONV_F16X3_W4_SPLIT, PC_CONV_F16X3_64, PC_CONV_F16X3_64_FUSE1, PC_CONV_F16X3_64_D2, PC_CONV_F16X3_64_D4, PC_CONV_F16X3_128_K1, PC_CONV_F16X3_64_K1, PC_CONV_F16X3_PC, PC_CONV_FIRST, PC_CONV_DIRECT, PC_POOL, PC_DECONV, PC_TAIL, PC_MERGE, PC_LAYOUT, PC_COUNT };
+enum ProfClass { PC_CONV_MFMA, PC_CONV_MFMA_1 = 1, PC_CONV_MFMA_7 = 7, PC_CONV_F16X3_128, PC_CONV_F16X3_W4, PC_CONV_F16X3_W4_SPLIT, PC_CONV_F16X3_W4_MT2, PC_CONV_F16X3_W4_SPLIT_MT2, PC_CONV_F16X3_64, PC_CONV_F16X3_64_FUSE1, PC_CONV_F16X3_64_D2, PC_CONV_F16X3_64_D4, PC_CONV_F16X3_128_K1, PC_CONV_F16X3_64_K1, PC_CONV_F16X3_PC, PC_CONV_FIRST, PC_CONV_DIRECT, PC_POOL, PC_DECONV, PC_TAIL, PC_MERGE, PC_LAYOUT, PC_COUNT };
 static const char* kProfNames[PC_COUNT] = {"conv_mfma_f32_kernel<3, 1, 128, 8, 16>", "conv_mfma_f32_kernel<3, 2, 128, 8, 16>",
                                            "conv_mfma_f32_kernel<3, 4, 128, 8, 16>", "conv_mfma_f32_kernel<3, 1, 64, 16, 16>",
                                            "conv_mfma_f32_kernel<3, 2, 64, 16, 16>", "conv_mfma_f32_kernel<3, 4, 64, 16, 16>",
                                            "conv_mfma_f32_kernel<1, 0, 128, 8, 16>", "conv_mfma_f32_kernel<1, 0, 64, 16, 16>",
-                                           "conv_mfma_f16x3_kernel<128, false, 1, 3>", "conv_mfma_f16x3_w4_kernel<false>",
-                                           "conv_mfma_f16x3_w4_kernel<true>",
+                                           "conv_mfma_f16x3_kernel<128, false, 1, 3>", "conv_mfma_f16x3_w4_kernel<false, 4>",
+                                           "conv_mfma_f16x3_w4_kernel<true, 4>", "conv_mfma_f16x3_w4_kernel<false, 2>",
+                                           "conv_mfma_f16x3_w4_kernel<true, 2>",
                                            "conv_mfma_f16x3_kernel<64, false, 1, 3>",
                                            "conv_mfma_f16x3_kernel<64, true, 1, 3>", "conv_mfma_f16x3_kernel<64, false, 2, 3>",
                                            "conv_mfma_f16x3_kernel<64, false, 4, 3>", "conv_mfma_f16x3_kernel<128, false, 1, 1>",
@@ -186,13 +187,15 @@ struct Prof {
   }
 };
 
-static int f16x3_prof_class(const ConvArgs& a, int nout) {  // which split-fp16 kernel launch_conv_f16x3_group picks
+static int f16x3_prof_class(const ConvArgs& a, int nout, const ConvArgs* group = nullptr, int n = 1) {  // which split-fp16 kernel launch_conv_f16x3_group picks
   if (a.img) return conv_f16x3_uses_pc() && a.in.C == 64 && nout == 64 ? PC_CONV_F16X3_PC : PC_CONV_F16X3_64_FUSE1;
   if (a.k == 1) return nout % 128 ? PC_CONV_F16X3_64_K1 : PC_CONV_F16X3_128_K1;
   if (a.dil == 2) return PC_CONV_F16X3_64_D2;
   if (a.dil == 4) return PC_CONV_F16X3_64_D4;
   if (nout % 128) return PC_CONV_F16X3_64;
-  return conv_f16x3_uses_w4(a.in.C) ? (a.in_split ? PC_CONV_F16X3_W4_SPLIT : PC_CONV_F16X3_W4) : PC_CONV_F16X3_128;
+  if (!conv_f16x3_uses_w4(a.in.C)) return PC_CONV_F16X3_128;
+  const bool mt2 = conv_f16x3_w4_mt(group ? group : &a, group ? n : 1) == 2;
+  return a.in_split ? (mt2 ? PC_CONV_F16X3_W4_SPLIT_MT2 : PC_CONV_F16X3_W4_SPLIT) : (mt2 ? PC_CONV_F16X3_W4_MT2 : PC_CONV_F16X3_W4);
 }
 
 static int conv_prof_class(int k, int dil, int nout) {
@@ -1696,7 +1699,7 @@ int shf_detect_add_levels(shf_net* net, int n, shf_net** members, const float* c
             fl += conv_flops(F, mb->blobs[F.bottoms[0]].shape, mb->blobs[F.tops[0]].shape);
           }
         }
-        ProfScope ps(net->prof, cs, f16x3_prof_class(group[0], L.nout), fl, by);
+        ProfScope ps(net->prof, cs, f16x3_prof_class(group[0], L.nout, group.data(), n), fl, by);
         CHECK_RC(launch_conv_f16x3_group(group.data(), n, cs));
       } else {
         const int pc = conv_prof_class(L.k, L.dil, L.nout);
