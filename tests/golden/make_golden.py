@@ -27,6 +27,8 @@ Reference entry points exercised (file:line in /root/reference):
   lib/utils/test_utils.py:8           _compute_scaling_factor (+ test.py:131-137)
   lib/utils/get_config.py:134,140     cfg_from_file / cfg_from_list
   lib/datasets/wider.py:143           write_detections line format
+  lib/datasets/{wider,fddb,afw,pascalface}.py   write_detections of the four imdbs (files as text)
+  lib/wider_eval_tools/wider_eval.py:180   wider_eval on a synthetic ground truth (.mat) + detection files
   models/test_*template.prototxt      structural digest of both inference templates
 """
 import io
@@ -215,6 +217,8 @@ def clustered_dets(rng, n_centers, per, jitter, size=(20, 120), extent=900.0, qu
 
 
 def main():
+    import numpy.ma  # noqa: F401  (before the np.bool alias below: numpy.ma's import trips over it)
+    import scipy.io  # noqa: F401
     tmp = tempfile.mkdtemp(prefix="shf_ref_py3_")
     convert_reference(tmp)
 
@@ -438,6 +442,122 @@ def main():
     # format pin (the wider imdb class itself needs datasets on disk to construct)
     json.dump({"rows": rows.tolist(), "lines": lines},
               open(os.path.join(OUT, "write_detections.json"), "w"), indent=1)
+
+    # ---------------- detection writers of the four imdbs ------------------
+    # lib/datasets/{wider,fddb,afw,pascalface}.py write_detections, called unbound on a stand-in `self` (the
+    # constructors need the datasets on disk); the files they write are stored as text.
+    import datasets.wider as ref_wider
+    import datasets.fddb as ref_fddb
+    import datasets.afw as ref_afw
+    import datasets.pascalface as ref_pascal
+    rngw = np.random.default_rng(77)
+    wpaths = ["0--Parade/0_Parade_marchingband_1_5.jpg", "1--Handshaking/1_Handshaking_Handshaking_1_35.jpg",
+              "2--Demonstration/2_Demonstration_Political_Rally_2_9.jpg"]
+    wboxes = []
+    for n in (4, 0, 7):
+        xy = rngw.uniform(0, 600, (n, 2))
+        wh = rngw.uniform(3, 200, (n, 2))
+        sc = rngw.uniform(0.05, 1.0, (n, 1))
+        wboxes.append(np.hstack([xy, xy + wh, sc]))
+    all_boxes = [[[] for _ in wpaths], wboxes]
+    written = {}
+    for key, mod, cls in (("wider", ref_wider, "wider"), ("fddb", ref_fddb, "fddb"), ("afw", ref_afw, "afw"),
+                          ("pascal", ref_pascal, "pascalface")):
+        outd = os.path.join(tmp, "written_" + key)
+        os.makedirs(outd)
+        fake_self = types.SimpleNamespace(_image_paths=list(wpaths))
+        klass = getattr(mod, cls)
+        (klass.write_detections_rect if key == "fddb" else klass.write_detections)(fake_self, all_boxes, outd)
+        files = {}
+        for root, _, fns in os.walk(outd):
+            for fn in fns:
+                files[os.path.relpath(os.path.join(root, fn), outd)] = open(os.path.join(root, fn)).read()
+        written[key] = files
+    json.dump({"image_paths": wpaths, "boxes": [b.tolist() for b in wboxes], "written": written},
+              open(os.path.join(OUT, "writers.json"), "w"), indent=1, sort_keys=True)
+
+    # ---------------- WIDER evaluator --------------------------------------
+    # lib/wider_eval_tools/wider_eval.py on a synthetic ground truth in the official toolbox's .mat layout
+    # (61 events -- the evaluator hard-codes that number -- two images each) and synthetic detection files.
+    from scipy import io as sio
+    import wider_eval_tools.wider_eval as ref_eval
+    rnge = np.random.default_rng(2024)
+    gt_dir = os.path.join(tmp, "ground_truth")
+    pred_dir = os.path.join(tmp, "pred")
+    os.makedirs(gt_dir)
+    n_ev, per_ev = 61, 2
+    ev_names, file_names, gt_boxes, subsets, preds = [], [], [], {"easy": [], "medium": [], "hard": []}, []
+    for e in range(n_ev):
+        ev = "%d--Event%d" % (e, e)
+        ev_names.append(ev)
+        os.makedirs(os.path.join(pred_dir, ev))
+        for j in range(per_ev):
+            name = "%d_Event%d_img_%d" % (e, e, j)
+            file_names.append(name)
+            g = int(rnge.integers(0, 6))
+            xy = rnge.uniform(0, 400, (g, 2))
+            wh = rnge.uniform(8, 120, (g, 2))
+            gb = np.round(np.hstack([xy, wh]))
+            gt_boxes.append(gb)
+            big = np.where(wh.min(axis=1) > 60)[0] if g else np.zeros(0, int)
+            mid = np.where(wh.min(axis=1) > 25)[0] if g else np.zeros(0, int)
+            subsets["easy"].append(big + 1)
+            subsets["medium"].append(mid + 1)
+            subsets["hard"].append(np.arange(g) + 1)
+            # detections: jittered copies of some faces (a few duplicates on one face), plus clutter
+            rows = []
+            for k in range(g):
+                for _ in range(int(rnge.integers(0, 3))):
+                    jit = rnge.normal(0, 0.12, 4) * np.array([gb[k, 2], gb[k, 3], gb[k, 2], gb[k, 3]])
+                    rows.append(np.concatenate([gb[k] + jit, [rnge.uniform(0.3, 1.0)]]))
+            for _ in range(int(rnge.integers(0, 4))):
+                rows.append(np.concatenate([rnge.uniform(0, 400, 2), rnge.uniform(8, 120, 2), [rnge.uniform(0.05, 0.6)]]))
+            if e == 7 and j == 1:
+                rows = []      # an image without detections
+            pr = np.array(rows, dtype=np.float64).reshape(-1, 5)
+            pr[:, 2:4] = np.maximum(pr[:, 2:4], 2.0)
+            pr[:, 4] = np.round(pr[:, 4], 4) + 1e-6 * np.arange(len(pr))     # distinct scores: no tie-order ambiguity
+            with open(os.path.join(pred_dir, ev, name + ".txt"), "w") as f:
+                f.write("%s/%s.jpg\n%d\n" % (ev, name, len(pr)))
+                for r in pr:
+                    f.write("%d %d %d %d %g \n" % (int(r[0]), int(r[1]), int(r[2]), int(r[3]), r[4]))
+            # what the evaluator parses back from that text
+            preds.append(np.array([[float(v) for v in ("%d %d %d %d %g" % (int(r[0]), int(r[1]), int(r[2]), int(r[3]), r[4])).split()]
+                                   for r in pr], dtype=np.float64).reshape(-1, 5))
+
+    def cell(rows):       # MATLAB cell column
+        c = np.empty((len(rows), 1), dtype=object)
+        for i, r in enumerate(rows):
+            c[i, 0] = r
+        return c
+
+    def mat_for(subset):
+        fl, bl, gl = [], [], []
+        for e in range(n_ev):
+            sl = slice(e * per_ev, (e + 1) * per_ev)
+            fl.append(cell([np.array([nm], dtype=object).reshape(1, 1) if False else nm for nm in file_names[sl]]))
+            bl.append(cell([gt_boxes[i] for i in range(sl.start, sl.stop)]))
+            gl.append(cell([np.asarray(subset[i], dtype=np.int32).reshape(-1, 1) for i in range(sl.start, sl.stop)]))
+        return {"event_list": cell(ev_names), "file_list": cell(fl), "face_bbx_list": cell(bl), "gt_list": cell(gl)}
+
+    sio.savemat(os.path.join(gt_dir, "wider_face_val.mat"), mat_for(subsets["hard"]))
+    for sname in ("easy", "medium", "hard"):
+        sio.savemat(os.path.join(gt_dir, "wider_%s_val.mat" % sname), mat_for(subsets[sname]))
+    ev_out = {}
+    for bug in (True, False):
+        ap, pr_curve = ref_eval.wider_eval(pred_dir, gt_dir, parallel=False, mimic_eval_bug=bug, IoU_thresh=0.5)
+        ev_out["ap_bug%d" % int(bug)] = np.array(ap, dtype=np.float64)
+        ev_out["pr_bug%d" % int(bug)] = np.array(pr_curve, dtype=np.float64)
+    ev_out["n_images"] = np.array([len(file_names)])
+    ev_out["gt_count"] = np.array([len(b) for b in gt_boxes])
+    ev_out["gt_boxes"] = np.concatenate([b.reshape(-1, 4) for b in gt_boxes])
+    for sname in ("easy", "medium", "hard"):
+        ev_out["sub_%s_count" % sname] = np.array([len(v) for v in subsets[sname]])
+        ev_out["sub_%s" % sname] = np.concatenate([np.asarray(v, dtype=np.int64).reshape(-1) for v in subsets[sname]])
+    ev_out["pred_count"] = np.array([len(p_) for p_ in preds])
+    ev_out["preds"] = np.concatenate([p_.reshape(-1, 5) for p_ in preds])
+    np.savez_compressed(os.path.join(OUT, "wider_eval.npz"), **ev_out)
+    json.dump({"events": ev_names, "files": file_names}, open(os.path.join(OUT, "wider_eval_names.json"), "w"))
 
     # ---------------- inference templates: structural digest -------------
     # models/test_template.prototxt and models/test_different_dilation_template.prototxt parsed with the

@@ -324,3 +324,54 @@ def test_c5_two_and_four_ranks_equal_one_rank(tmp_path):
     d4, j4 = _run_bench(tmp_path, 4, ["--shard", "strict"], "c5_n4_strict")
     np.testing.assert_array_equal(d1, d4)
     assert j4["config"]["shard"] == "strict"
+
+
+# ------------------------------------------------------------------------------------------------------------
+# the other datasets' test pyramids (configs/smallhardface-{afw,fddb,pascal}.toml)
+# ------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name,n_units", [("afw", 10), ("fddb", 6), ("pascal", 2)])
+def test_dataset_scale_sets(name, n_units):
+    """Each dataset's scale set x flip through the grouped device path: == one unit at a time, the small levels
+    against the oracle net, range / order properties for the whole image."""
+    import torch
+    from smallhardface_amd import caffe, test as T, weights
+    cfg_from_file(os.path.join(ROOT, "configs", "smallhardface-%s.toml" % name))
+    msg = P._add_dimension_reduction(P.build_test_template(True))
+    params = weights.synth_params(msg, seed=1234)
+    gnet = caffe.Net(None, prototxt_text=P.dumps(msg))
+    H.load_params(gnet, params)
+    gnet.set_conv_mode("f16x3")
+    onet = O.OracleNet(msg, params=params)
+    im = np.random.default_rng(55).integers(0, 256, (300, 400, 3)).astype(np.uint8)
+    units = list(T.pyramid_units(im))
+    assert len(units) == n_units
+    fd = T.FusedDetector(gnet, n_lanes=n_units, mode="group")
+    a = fd.detect(units, thresh=0.05)[0]
+    b = T.detect_fused(gnet, units, thresh=0.05)[0]
+    np.testing.assert_array_equal(a, b)
+    assert len(a) > 0 and np.all(np.diff(a[:, 4]) <= 0) and np.all(a[:, 4] > 0.05)
+    assert a[:, [0, 2]].max() <= 400 and a[:, [1, 3]].max() <= 300 and a[:, :4].min() >= -1e-3
+    buf = torch.empty((10000, 5), dtype=torch.float32, device="cuda")
+    checked = 0
+    for u in units:
+        data, Hh, Ww, ih, iw, s, flip = u
+        if Hh * Ww > 160 * 224 or checked >= 3:
+            continue
+        info = np.array([[ih, iw, s]], np.float32)
+        onet.blobs['data'].reshape(*data.shape)
+        onet.blobs['im_info'].reshape(1, 3)
+        oo = onet.forward(data=data, im_info=info)
+        ob = oo["boxes"].copy()
+        if flip:
+            ob[:, [1, 3]] = iw - ob[:, [3, 1]]
+        k = oo["cls_prob"][:, 1] > 0.05
+        want = np.hstack([ob[k, 1:5] / np.float32(s), oo["cls_prob"][k, 1:2]])
+        gnet.detect_begin()
+        gnet.detect_add_level(data, Hh, Ww, ih, iw, s, flip, 0.05)
+        n = gnet.detect_export(buf.data_ptr(), 10000)
+        if len(want):
+            compare_detection_lists("%s_unit_%dx%d_flip%d" % (name, Hh, Ww, int(flip)), buf[:n].cpu().numpy(), want)
+        else:
+            assert n == 0
+        checked += 1
+    assert checked >= 1

@@ -48,7 +48,7 @@ def get_imdb(name):
         paths = [osp.relpath(p, cfg.DATA_DIR) for p in paths]
     if not paths:
         raise IOError('no image list {} and no jpgs under {}/images'.format(lst, cfg.DATA_DIR))
-    return ImageList(name, paths, root=cfg.DATA_DIR)
+    return ImageList(name, paths, root=cfg.DATA_DIR, ground_truth=osp.join(cfg.DATA_DIR, 'ground_truth'))
 
 
 if __name__ == '__main__':
