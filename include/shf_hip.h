@@ -80,11 +80,19 @@ int shf_net_forward(shf_net* net);
 int shf_net_set_proposal_cfg(shf_net* net, int pre_nms_topN, float score_thresh, float min_size);
 
 /* Arithmetic of the MFMA convolutions (3x3 at any dilation and 1x1): 0 = exact fp32 matrix cores
- * (v_mfma_f32_32x32x2_f32, bit-for-bit an fmaf chain); 1 = split-fp16: x = hi + lo*2^-11 with
+ * (v_mfma_f32_32x32x2_f32, bit-for-bit an fmaf chain); 1 = split-fp16 (2, 3: see the ladder below): x = hi + lo*2^-11 with
  * three fp16 MFMAs per product, fp32 accumulate (2^-22 relative per product: fp32-class, 5.3x
  * the fp32 MFMA rate).  Default 0, or the SHF_CONV_MODE environment variable at creation.  The mode is shared by
  * a net and all lanes cloned from it (like the proposal configuration above). */
 int shf_net_set_conv_mode(shf_net* net, int mode);
+int shf_net_get_conv_mode(shf_net* net);
+/* The reduced-precision ladder (BASELINE configs C3 / C5 name bf16): modes 2 and 3 of shf_net_set_conv_mode form two
+ * (a_hi*b_hi + a_hi*b_lo: activations rounded to fp16, weights still split) or one (plain fp16 operands) of the three
+ * fp16 products, at 2/3 and 1/3 of the matrix-core work; their score drift against the fp32 reference is measured,
+ * not assumed (tools/precision_ladder.py -> profiles/).  shf_net_set_layer_products overrides the count for ONE
+ * layer by name (1..3; 0 clears), so a mode can be relaxed only where the measured contribution to the score error is
+ * negligible.  Shared by a net and its lanes.  Kernels without a reduced instantiation keep three products. */
+int shf_net_set_layer_products(shf_net* net, const char* layer, int nprod);
 /* fp16 range guard of mode 1 (the reference is fp32 everywhere, caffe/python/caffe/_caffe.cpp:46-48): hi = fp16(x)
  * overflows above 65504.  Weights are checked when they are packed (shf_net_param_commit / shf_net_set_conv_mode
  * fail with a message).  Every split-fp16 convolution raises a device flag when one of its outputs leaves the range:

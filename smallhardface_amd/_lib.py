@@ -86,7 +86,9 @@ def _declare(lib):
         "shf_net_forward": (ci, [vp]),
         "shf_net_set_proposal_cfg": (ci, [vp, ci, cf, cf]),
         "shf_net_set_conv_mode": (ci, [vp, ci]),
+        "shf_net_get_conv_mode": (ci, [vp]),
         "shf_net_range_fallbacks": (C.c_longlong, [vp]),
+        "shf_net_set_layer_products": (ci, [vp, C.c_char_p, ci]),
         "shf_net_record_event": (ci, [vp]),
         "shf_net_wait_event": (ci, [vp, vp]),
         "shf_detect_begin": (ci, [vp]),

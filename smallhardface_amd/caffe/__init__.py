@@ -37,6 +37,11 @@ def set_device(device_id):
     _lib.check(_lib.load().shf_set_device(int(device_id)), "set_device")
 
 
+# arithmetic of the MFMA convolutions (C ABI shf_net_set_conv_mode): exact fp32; split-fp16 with three products
+# (fp32-class: the mode every parity test runs); the reduced ladder with two / one product (drift-labelled)
+CONV_MODES = {"fp32": 0, "f16x3": 1, "f16x2": 2, "f16": 3, 0: 0, 1: 1, 2: 2, 3: 3}
+
+
 class Layer(object):
     """Base class of Python layers (kept for source compatibility: the proposal
     layer runs natively inside the runtime, nothing is called back)."""
@@ -164,9 +169,19 @@ class Net(object):
 
     def set_conv_mode(self, mode):
         """"fp32" (exact fp32 MFMA) or "f16x3" (split-fp16 MFMA, fp32-class accuracy) for the 3x3 convs."""
-        m = {"fp32": 0, "f16x3": 1, 0: 0, 1: 1}[mode]
+        m = CONV_MODES[mode]
         self.commit_params()
         _lib.check(self._lib.shf_net_set_conv_mode(self._h, m), "set_conv_mode")
+
+    @property
+    def conv_mode(self):
+        return {0: "fp32", 1: "f16x3", 2: "f16x2", 3: "f16"}[int(self._lib.shf_net_get_conv_mode(self._h))]
+
+    def set_layer_products(self, table):
+        """{layer name: 1 | 2 | 3 (0 clears)}: fp16 products per fp32 product for single layers of a split-fp16 mode
+        (C ABI shf_net_set_layer_products)."""
+        for name, n in dict(table).items():
+            _lib.check(self._lib.shf_net_set_layer_products(self._h, str(name).encode(), int(n)), "set_layer_products")
 
     @property
     def range_fallbacks(self):

@@ -455,7 +455,8 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_kernel(ConvK p) {
 // MT_: 2x16-pixel MFMA row tiles per wave.  4 = the 16x16-pixel block tile above; 2 = an 8x16-pixel tile (wave 64 px x
 // 64 couts, half the accumulators) for launches whose block count quantises badly on 256 CUs -- conv5_x on the bench
 // pyramid is 528 blocks = 2.06 rounds of 16x16 tiles but 960 half-size blocks = 3.75 rounds (launcher: w4_pick_mt).
-template <bool IN_SPLIT, int MT_>
+// NP: fp16 products per fp32 product -- 3 (fp32-class), 2 (a_lo * b_hi dropped: activations act as fp16) or 1 (hi * hi).
+template <bool IN_SPLIT, int MT_, int NP = 3>
 __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4_kernel(ConvK p) {
   using namespace f16x3;
   constexpr int TH = 4 * MT_, HTH = TH + 2, HP = HTH * HTW;  // (shadow the 16-row constants of namespace f16x3)
@@ -683,16 +684,20 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4_kernel(ConvK p) {
 #pragma unroll
         for (int tn = 0; tn < 2; ++tn)
           accm[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[2 * tm], bf[2 * tn], accm[tm][tn], 0, 0, 0);
+      if constexpr (NP >= 2) {
 #pragma unroll
-      for (int tm = 0; tm < MT; ++tm)
+        for (int tm = 0; tm < MT; ++tm)
 #pragma unroll
-        for (int tn = 0; tn < 2; ++tn)
-          accc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[2 * tm], bf[2 * tn + 1], accc[tm][tn], 0, 0, 0);
+          for (int tn = 0; tn < 2; ++tn)
+            accc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[2 * tm], bf[2 * tn + 1], accc[tm][tn], 0, 0, 0);
+      }
+      if constexpr (NP >= 3) {
 #pragma unroll
-      for (int tm = 0; tm < MT; ++tm)
+        for (int tm = 0; tm < MT; ++tm)
 #pragma unroll
-        for (int tn = 0; tn < 2; ++tn)
-          accc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[2 * tm + 1], bf[2 * tn], accc[tm][tn], 0, 0, 0);
+          for (int tn = 0; tn < 2; ++tn)
+            accc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[2 * tm + 1], bf[2 * tn], accc[tm][tn], 0, 0, 0);
+      }
       if (s_ + 1 < 6) {
         // next step's 12 fragment reads go out under the first 12 MFMAs (12 more to land), the VMEM
         // issues are spread over the second half
@@ -702,7 +707,7 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4_kernel(ConvK p) {
           __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
 #pragma unroll
-        for (int g = 0; g < 6 * MT - (2 * MT + 4) - 3; ++g) {
+        for (int g = 0; g < 2 * NP * MT - (2 * MT + 4) - 3; ++g) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
           if (g < n_vmem) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
         }
@@ -1244,10 +1249,17 @@ static int launch_f16x3_t(const ConvArgs* as, int n, hipStream_t s) {
     const size_t lds4 = std::max((size_t)(th + 2) * ((TW + 2) * ROWB + F16X3_W4_ROWPAD) + 2 * 3 * (size_t)BN * ROWB,
                                  (size_t)16 * th * (BN + CS_PAD) * sizeof(float));
     const dim3 grid((unsigned)(tiles * p.nct));
-    if (mt == 4 && a.in_split) hipLaunchKernelGGL((conv_mfma_f16x3_w4_kernel<true, 4>), grid, dim3(256), lds4, s, p);
-    else if (mt == 4) hipLaunchKernelGGL((conv_mfma_f16x3_w4_kernel<false, 4>), grid, dim3(256), lds4, s, p);
-    else if (a.in_split) hipLaunchKernelGGL((conv_mfma_f16x3_w4_kernel<true, 2>), grid, dim3(256), lds4, s, p);
-    else hipLaunchKernelGGL((conv_mfma_f16x3_w4_kernel<false, 2>), grid, dim3(256), lds4, s, p);
+#define SHF_W4_LAUNCH(SPLIT, MTV)                                                                                      \
+    {                                                                                                                   \
+      if (a.nprod >= 3) hipLaunchKernelGGL((conv_mfma_f16x3_w4_kernel<SPLIT, MTV, 3>), grid, dim3(256), lds4, s, p);     \
+      else if (a.nprod == 2) hipLaunchKernelGGL((conv_mfma_f16x3_w4_kernel<SPLIT, MTV, 2>), grid, dim3(256), lds4, s, p); \
+      else hipLaunchKernelGGL((conv_mfma_f16x3_w4_kernel<SPLIT, MTV, 1>), grid, dim3(256), lds4, s, p);                   \
+    }
+    if (mt == 4 && a.in_split) SHF_W4_LAUNCH(true, 4)
+    else if (mt == 4) SHF_W4_LAUNCH(false, 4)
+    else if (a.in_split) SHF_W4_LAUNCH(true, 2)
+    else SHF_W4_LAUNCH(false, 2)
+#undef SHF_W4_LAUNCH
   } else if (a.in_split) {
     set_error("conv f16x3: split-format input reached a kernel other than the 4-wave one");
     return -1;
@@ -1289,14 +1301,13 @@ int conv_f16x3_init_attributes() {
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   SHF_HIP_OK(hipFuncSetAttribute((const void*)conv_mfma_f16x3_kernel<64, false, 4, 3>,
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  SHF_HIP_OK(hipFuncSetAttribute((const void*)conv_mfma_f16x3_w4_kernel<false, 4>,
+#define SHF_W4_ATTR(SPLIT, MTV, NPV)                                                                  \
+  SHF_HIP_OK(hipFuncSetAttribute((const void*)conv_mfma_f16x3_w4_kernel<SPLIT, MTV, NPV>,              \
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  SHF_HIP_OK(hipFuncSetAttribute((const void*)conv_mfma_f16x3_w4_kernel<true, 4>,
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  SHF_HIP_OK(hipFuncSetAttribute((const void*)conv_mfma_f16x3_w4_kernel<false, 2>,
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  SHF_HIP_OK(hipFuncSetAttribute((const void*)conv_mfma_f16x3_w4_kernel<true, 2>,
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  SHF_W4_ATTR(false, 4, 3) SHF_W4_ATTR(true, 4, 3) SHF_W4_ATTR(false, 2, 3) SHF_W4_ATTR(true, 2, 3)
+  SHF_W4_ATTR(false, 4, 2) SHF_W4_ATTR(true, 4, 2) SHF_W4_ATTR(false, 2, 2) SHF_W4_ATTR(true, 2, 2)
+  SHF_W4_ATTR(false, 4, 1) SHF_W4_ATTR(true, 4, 1) SHF_W4_ATTR(false, 2, 1) SHF_W4_ATTR(true, 2, 1)
+#undef SHF_W4_ATTR
   SHF_HIP_OK(hipFuncSetAttribute((const void*)conv_mfma_f16x3_pc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                  160 * 1024));
   SHF_HIP_OK(hipFuncSetAttribute((const void*)conv_mfma_f16x3_kernel<64, false, 1, 3>,

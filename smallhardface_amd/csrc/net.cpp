@@ -140,9 +140,9 @@ static const char* kProfNames[PC_COUNT] = {"conv_mfma_f32_kernel<3, 1, 128, 8, 1
                                            "conv_mfma_f32_kernel<3, 4, 128, 8, 16>", "conv_mfma_f32_kernel<3, 1, 64, 16, 16>",
                                            "conv_mfma_f32_kernel<3, 2, 64, 16, 16>", "conv_mfma_f32_kernel<3, 4, 64, 16, 16>",
                                            "conv_mfma_f32_kernel<1, 0, 128, 8, 16>", "conv_mfma_f32_kernel<1, 0, 64, 16, 16>",
-                                           "conv_mfma_f16x3_kernel<128, false, 1, 3>", "conv_mfma_f16x3_w4_kernel<false, 4>",
-                                           "conv_mfma_f16x3_w4_kernel<true, 4>", "conv_mfma_f16x3_w4_kernel<false, 2>",
-                                           "conv_mfma_f16x3_w4_kernel<true, 2>",
+                                           "conv_mfma_f16x3_kernel<128, false, 1, 3>", "conv_mfma_f16x3_w4_kernel<false, 4, 3>",
+                                           "conv_mfma_f16x3_w4_kernel<true, 4, 3>", "conv_mfma_f16x3_w4_kernel<false, 2, 3>",
+                                           "conv_mfma_f16x3_w4_kernel<true, 2, 3>",
                                            "conv_mfma_f16x3_kernel<64, false, 1, 3>",
                                            "conv_mfma_f16x3_kernel<64, true, 1, 3>", "conv_mfma_f16x3_kernel<64, false, 2, 3>",
                                            "conv_mfma_f16x3_kernel<64, false, 4, 3>", "conv_mfma_f16x3_kernel<128, false, 1, 1>",
@@ -375,7 +375,9 @@ using namespace shf;
 // configuration shared by a net and every lane cloned from it: the arithmetic mode and what the reference's Python
 // layer reads from the global cfg at every forward (lib/layers/proposal_layer.py:88-92)
 struct NetShared {
-  int conv_mode = 0;  // 0: exact fp32 MFMA everywhere; 1: split-fp16 MFMA (fp32-class accuracy)
+  int conv_mode = 0;  // 0: exact fp32 MFMA everywhere; 1: split-fp16, 3 products (fp32-class accuracy); 2 / 3: the
+                      // reduced ladder -- 2 products (activations rounded to fp16) / 1 product (plain fp16 operands)
+  std::map<std::string, int> layer_products;  // per-layer override of the number of fp16 products (shf_net_set_layer_products)
   int pre_nms_topN = 10000;
   float score_thresh = 0.002f, min_size = 0.f;
   bool weights_exceed_f16 = false;  // some conv weight is outside the fp16 range: split-fp16 mode refuses to run
@@ -1021,7 +1023,7 @@ void shf_net::commit_params(int li) {
       pack_conv_weights(p.host.data(), p.shape[0], p.shape[1], p.shape[2], packed.data());
       p.packed.ensure(packed.size() * 4);
       HIP_THROW(hipMemcpy(p.packed.p, packed.data(), packed.size() * 4, hipMemcpyHostToDevice));
-      if (conv_mode == 1 && conv_f16x3_eligible(p.shape[1], p.shape[0], L.k, L.pad, L.dil)) {
+      if (conv_mode >= 1 && conv_f16x3_eligible(p.shape[1], p.shape[0], L.k, L.pad, L.dil)) {
         // split-fp16 keeps hi = fp16(w): a weight beyond the fp16 range would become inf (the reference is fp32
         // everywhere, caffe/python/caffe/_caffe.cpp:46-48) -- refuse the mode instead of computing garbage
         for (float w : p.host)
@@ -1106,7 +1108,7 @@ void shf_net::forward_ops(bool fused_path, float im_h, float im_w, float im_scal
         a.wraw = (const float*)L.params[0]->raw.p;
         a.wpacked = (const float*)L.params[0]->packed.p;
         a.wfirst = (const float*)L.params[0]->first_t.p;
-        const bool split16 = conv_mode == 1 && L.kclass == 0 && L.params[0]->packed16.p &&
+        const bool split16 = conv_mode >= 1 && L.kclass == 0 && L.params[0]->packed16.p &&
                              conv_f16x3_eligible(ib.shape[1], L.nout, L.k, L.pad, L.dil);
         a.wsplit16 = split16 ? L.params[0]->packed16.p : nullptr;
         if (fused_path && L.fuse_pool >= 0) {
@@ -1115,7 +1117,12 @@ void shf_net::forward_ops(bool fused_path, float im_h, float im_w, float im_scal
           a.pool_split = split16 && blobs[layers[L.fuse_pool].tops[0]].split_fused;
         }
         // split-fp16 mode: every producer of a map that a split-fp16 conv may read guards the fp16 range
-        a.range_flag = conv_mode == 1 ? (flag_ptr ? flag_ptr : (int*)range_flag.p) : nullptr;
+        a.range_flag = conv_mode >= 1 ? (flag_ptr ? flag_ptr : (int*)range_flag.p) : nullptr;
+        if (split16) {  // how many of the three fp16 products this layer forms
+          a.nprod = conv_mode == 1 ? 3 : conv_mode == 2 ? 2 : 1;
+          auto it = sh->layer_products.find(L.name);
+          if (it != sh->layer_products.end()) a.nprod = it->second;
+        }
         if (fused_path && split16) {
           a.in_split = ib.split_fused;
           a.out_split = blobs[L.tops[0]].split_fused;
@@ -1128,7 +1135,7 @@ void shf_net::forward_ops(bool fused_path, float im_h, float im_w, float im_scal
           a.w1f = F.params[0]->first_frag.p;
           a.b1 = F.params.size() > 1 ? (const float*)F.params[1]->raw.p : nullptr;
         }
-        if (fused_path && conv_mode == 1 && L.first_dst >= 0 && layers[L.first_dst].params[0]->packed16.p)
+        if (fused_path && conv_mode >= 1 && L.first_dst >= 0 && layers[L.first_dst].params[0]->packed16.p)
           break;  // computed inside the next conv's halo staging
         const double fl = conv_flops(L, ib.shape, blobs[L.tops[0]].shape);
         const double by = 4.0 * (ib.count() + blobs[L.tops[0]].count() + L.params[0]->count());
@@ -1168,7 +1175,7 @@ void shf_net::forward_ops(bool fused_path, float im_h, float im_w, float im_scal
         CHECK_RC(launch_deconv_depthwise(view_of(L.bottoms[0]), view_of(L.tops[0]), (const float*)L.params[0]->raw.p,
                                          L.params.size() > 1 ? (const float*)L.params[1]->raw.p : nullptr, L.k,
                                          L.stride, L.pad, st,
-                                         conv_mode == 1 ? (flag_ptr ? flag_ptr : (int*)range_flag.p) : nullptr));
+                                         conv_mode >= 1 ? (flag_ptr ? flag_ptr : (int*)range_flag.p) : nullptr));
         break;
       }
       case OP_TAIL: {
@@ -1204,13 +1211,14 @@ void shf_net::forward() {
   if (im_info_blob >= 0 && blobs[im_info_blob].host.p && blobs[im_info_blob].count() >= 3)
     memcpy(ii, blobs[im_info_blob].host.p, 12);
   for (int attempt = 0; attempt < 2; ++attempt) {
-    if (conv_mode == 1) HIP_THROW(hipMemsetAsync(range_flag.p, 0, 4, stream));
+    if (conv_mode >= 1) HIP_THROW(hipMemsetAsync(range_flag.p, 0, 4, stream));
     forward_ops(false, ii[0], ii[1], ii[2]);
     int cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, flag = 0;
     if (tail_layer >= 0) HIP_THROW(hipMemcpyAsync(cnt, tw.counters, sizeof(cnt), hipMemcpyDeviceToHost, stream));
-    if (conv_mode == 1) HIP_THROW(hipMemcpyAsync(&flag, range_flag.p, 4, hipMemcpyDeviceToHost, stream));
+    if (conv_mode >= 1) HIP_THROW(hipMemcpyAsync(&flag, range_flag.p, 4, hipMemcpyDeviceToHost, stream));
     HIP_THROW(hipStreamSynchronize(stream));
-    if (flag && conv_mode == 1) {
+    if (flag && conv_mode >= 1) {
+      const int mode_was = conv_mode;
       // a convolution produced |x| > 65504: fp16(hi) of the split overflowed somewhere downstream.  The reference
       // computes in fp32 (_caffe.cpp:46-48): redo THIS forward on the exact fp32 matrix-core kernels.
       ++sh->range_fallbacks;
@@ -1220,10 +1228,10 @@ void shf_net::forward() {
         if (tail_layer >= 0) HIP_THROW(hipMemcpyAsync(cnt, tw.counters, sizeof(cnt), hipMemcpyDeviceToHost, stream));
         HIP_THROW(hipStreamSynchronize(stream));
       } catch (...) {
-        conv_mode = 1;
+        conv_mode = mode_was;
         throw;
       }
-      conv_mode = 1;
+      conv_mode = mode_was;
     }
     if (tail_layer >= 0) {
       const int R = cnt[2];
@@ -1428,11 +1436,12 @@ int shf_net_set_proposal_cfg(shf_net* net, int pre_nms_topN, float score_thresh,
 
 int shf_net_set_conv_mode(shf_net* net, int mode) {
   API_BEGIN
-  if (mode != 0 && mode != 1) throw std::runtime_error("conv mode must be 0 (fp32) or 1 (split-fp16)");
+  if (mode < 0 || mode > 3)
+    throw std::runtime_error("conv mode must be 0 (fp32), 1 (split-fp16 x3), 2 (x2) or 3 (plain fp16)");
   if (net->conv_mode == mode) return 0;
   HIP_THROW(hipDeviceSynchronize());  // the mode is shared with every lane: nothing may be in flight while it flips
   net->conv_mode = mode;
-  if (mode == 1) {
+  if (mode >= 1) {
     // the fp32 packs always exist; the split-fp16 packs are made on first use (and re-made by every commit)
     try {
       for (size_t li = 0; li < net->layers.size(); ++li) {
@@ -1446,6 +1455,25 @@ int shf_net_set_conv_mode(shf_net* net, int mode) {
       throw;
     }
   }
+  return 0;
+  API_END(-1)
+}
+
+int shf_net_get_conv_mode(shf_net* net) { return net->conv_mode; }
+
+int shf_net_set_layer_products(shf_net* net, const char* layer, int nprod) {
+  API_BEGIN
+  if (!layer) throw std::runtime_error("set_layer_products: null layer name");
+  if (nprod == 0) {
+    net->sh->layer_products.erase(layer);
+    return 0;
+  }
+  if (nprod < 1 || nprod > 3) throw std::runtime_error("set_layer_products: 1, 2 or 3 products (0 clears the override)");
+  bool found = false;
+  for (auto& L : net->layers) found = found || L.name == layer;
+  if (!found) throw std::runtime_error(std::string("set_layer_products: no layer named '") + layer + "'");
+  HIP_THROW(hipDeviceSynchronize());
+  net->sh->layer_products[layer] = nprod;
   return 0;
   API_END(-1)
 }
@@ -1502,7 +1530,7 @@ static const char* kRangeMsg =
     "split-fp16 range exceeded: a convolution output has |x| > 65504 (fp16 hi overflows); this image must be "
     "re-run with conv mode fp32";
 static void throw_if_out_of_range(shf_net* net) {
-  if (net->conv_mode != 1) return;
+  if (net->conv_mode < 1) return;
   int flag = 0;
   HIP_THROW(hipMemcpyAsync(&flag, net->range_flag.p, 4, hipMemcpyDeviceToHost, net->stream));
   HIP_THROW(hipStreamSynchronize(net->stream));
@@ -1770,7 +1798,7 @@ int shf_detect_add_levels(shf_net* net, int n, shf_net** members, const float* c
 static int detect_count_checked(shf_net* net, bool check_range) {
   int c[2] = {0, 0}, flag = 0;
   HIP_THROW(hipMemcpyAsync(c, net->img_count.p, 8, hipMemcpyDeviceToHost, net->stream));
-  if (check_range && net->conv_mode == 1)
+  if (check_range && net->conv_mode >= 1)
     HIP_THROW(hipMemcpyAsync(&flag, net->range_flag.p, 4, hipMemcpyDeviceToHost, net->stream));
   HIP_THROW(hipStreamSynchronize(net->stream));
   if (flag) throw std::runtime_error(kRangeMsg);

@@ -44,6 +44,8 @@ struct ConvArgs {
   // convs is stored as [pixel][32-channel chunk][hi 32 halfs | lo 32 halfs] -- the same 4 B per element, already
   // split, so the consumer's halo staging is a plain copy
   int in_split = 0, out_split = 0, pool_split = 0;
+  int nprod = 3;  // split-fp16 kernels: fp16 products formed per fp32 product -- 3 (hi*hi + hi*lo + lo*hi: fp32-class),
+                  // 2 (drops a_lo*b_hi: activations effectively fp16) or 1 (hi*hi only: plain fp16 operands)
   int* range_flag = nullptr;  // split-fp16 kernels raise it when an output leaves the fp16 range (net.cpp: fp32 re-run)
 };
 // which kernel class a conv will use: 0 = mfma implicit GEMM, 1 = first-layer direct (NCHW in), 2 = generic direct

@@ -274,11 +274,12 @@ class FusedDetector(object):
     def _redo_fp32(self, units, thresh, on_device):
         self.range_fallbacks += 1
         logger.warning("split-fp16 range exceeded: image redone on the exact fp32 kernels")
+        mode = self.net.conv_mode
         self.net.set_conv_mode("fp32")      # shared by every lane
         try:
             return self.detect(units, thresh, on_device=on_device)
         finally:
-            self.net.set_conv_mode("f16x3")
+            self.net.set_conv_mode(mode)
 
     def submit(self, units, thresh=0.05, on_device=False):
         units = list(units)
