@@ -103,9 +103,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-events", action="store_true", help="do not record per-launch HIP events")
     ap.add_argument("--method", default=None, help="BBOX_VOTE (default, the reference's) or NMS")
-    ap.add_argument("--conv-mode", default="f16x3", choices=["f16x3", "fp32"],
-                    help="f16x3: split-fp16 MFMA (3 fp16 products per fp32 product, fp32 accumulate; fp32-class "
-                         "accuracy, same parity bars); fp32: exact v_mfma_f32_32x32x2_f32 everywhere")
+    ap.add_argument("--conv-mode", default="f16x3", choices=["f16x3", "fp32", "f16x2", "f16"],
+                    help="f16x3 (headline): split-fp16 MFMA, 3 fp16 products per fp32 product, fp32 accumulate: fp32-class "
+                         "accuracy, passes every 1e-4 parity test; fp32: exact v_mfma_f32_32x32x2_f32 everywhere; f16x2 / "
+                         "f16: the reduced ladder (2 / 1 products in the 4-wave kernels) -- NOT parity modes, their "
+                         "measured score drift is in profiles/r02_precision_ladder.json (1.5e-3 / 2.5e-3 at C1)")
     ap.add_argument("--host-input", nargs="?", const="blobs", default=None, choices=["blobs", "image"],
                     help="N=1 only, PCIe-inclusive rates (never the headline value): 'blobs' hands the 10 HOST fp32 "
                          "blobs to the C ABI each step; 'image' uploads the raw uint8 image and builds the pyramid on "
@@ -336,7 +338,10 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32 via split-f16 MFMA (3x fp16 products, f32 accumulate)" if args.conv_mode == "f16x3" else "f32",
+            "dtype": {"f16x3": "f32 via split-f16 MFMA (3x fp16 products, f32 accumulate)", "fp32": "f32",
+                      "f16x2": "f16 activations x split-f16 weights (2 fp16 products, f32 accumulate): drift-labelled, "
+                               "max |dscore| 1.5e-3 vs the oracle at C1",
+                      "f16": "f16 operands (1 product, f32 accumulate): drift-labelled, max |dscore| 2.5e-3 at C1"}[args.conv_mode],
             "data": "synthetic",
             "config": {
                 "workload": ("C5: full smallhardface.toml test pyramid" if default_wl else "test pyramid") +
