@@ -162,11 +162,100 @@ __device__ __forceinline__ void conv_store_split4(float* __restrict__ pixel, int
   *(float2*)(d + 64) = make_float2(__builtin_bit_cast(float, l01), __builtin_bit_cast(float, l23));
 }
 
+// eight consecutive channels (c % 8 == 0): the hi and the lo halves are ONE 16-byte store each (the epilogue is
+// store-issue bound: half as many store instructions as two conv_store_split4)
+__device__ __forceinline__ void conv_store_split8(float* __restrict__ pixel, int c, const float4 v0, const float4 v1) {
+  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  const f2 x[4] = {{v0.x, v0.y}, {v0.z, v0.w}, {v1.x, v1.y}, {v1.z, v1.w}};
+  float hi[4], lo[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const h2 h = __builtin_convertvector(x[q], h2);
+    const h2 l = __builtin_convertvector((x[q] - __builtin_convertvector(h, f2)) * 2048.0f, h2);
+    hi[q] = __builtin_bit_cast(float, h);
+    lo[q] = __builtin_bit_cast(float, l);
+  }
+  unsigned char* d = (unsigned char*)(pixel + (c >> 5) * 32) + (c & 31) * 2;
+  *(float4*)d = make_float4(hi[0], hi[1], hi[2], hi[3]);
+  *(float4*)(d + 64) = make_float4(lo[0], lo[1], lo[2], lo[3]);
+}
+
+// split-format outputs: 8 channels per thread, NT / (BN / 8) pixels per block-wide round
+template <int BN, int NT, int ROWS>
+__device__ __forceinline__ void conv_flush_tile_split8(const float* __restrict__ Cs, int tid, int ty0, int tx0, int H,
+                                                       int W, int b, int cout0, float* __restrict__ gout,
+                                                       int out_stride, float* __restrict__ gpool, int pool_stride,
+                                                       bool write_main, bool pool_split) {
+  constexpr int CG = BN / 8;
+  constexpr int PPI = NT / CG;     // 16 (4 waves x BN 128), 32 or 64
+  static_assert(PPI >= 16 && PPI % 16 == 0, "whole tile rows per store round");
+  constexpr int YS = PPI / 16;     // tile rows per round
+  const int cg = tid % CG, p0 = tid / CG;
+  if (write_main) {
+    const int y0 = ty0 + (p0 >> 4), x = tx0 + (p0 & 15);
+    const float* cs = Cs + p0 * (BN + CS_PAD) + cg * 8;
+    float* g = gout + ((size_t)(b * H + y0) * W + x) * out_stride;   // the pixel's first channel
+    const size_t row_pitch = (size_t)W * out_stride;
+#pragma unroll
+    for (int r = 0; r < ROWS / YS; ++r) {
+      if (y0 + r * YS < H && x < W) {
+        const float* c = cs + r * YS * 16 * (BN + CS_PAD);
+        conv_store_split8(g + r * YS * row_pitch, cout0 + cg * 8, *(const float4*)c, *(const float4*)(c + 4));
+      }
+    }
+  }
+  if (gpool) {
+    const int Hp = (H + 1) >> 1, Wp = (W + 1) >> 1;
+#pragma unroll
+    for (int k = 0; k < (ROWS * 4 + PPI - 1) / PPI; ++k) {
+      const int pp = p0 + k * PPI;
+      const int ly = (pp >> 3) * 2, lx = (pp & 7) * 2;
+      const int y = ty0 + ly, x = tx0 + lx;
+      if (pp < ROWS * 4 && y < H && x < W) {
+        const float* c0 = Cs + (ly * 16 + lx) * (BN + CS_PAD) + cg * 8;
+        float m[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) m[j] = -3.402823466e+38f;
+        auto mx = [&](const float* q) {
+          const float4 a = *(const float4*)q, bq = *(const float4*)(q + 4);
+          const float v[8] = {a.x, a.y, a.z, a.w, bq.x, bq.y, bq.z, bq.w};
+#pragma unroll
+          for (int j = 0; j < 8; ++j) m[j] = v[j] > m[j] ? v[j] : m[j];
+        };
+        mx(c0);
+        if (x + 1 < W) mx(c0 + (BN + CS_PAD));
+        if (y + 1 < H) {
+          mx(c0 + 16 * (BN + CS_PAD));
+          if (x + 1 < W) mx(c0 + 17 * (BN + CS_PAD));
+        }
+        float* pq = gpool + ((size_t)(b * Hp + (y >> 1)) * Wp + (x >> 1)) * pool_stride;
+        if (pool_split) {
+          conv_store_split8(pq, cout0 + cg * 8, make_float4(m[0], m[1], m[2], m[3]), make_float4(m[4], m[5], m[6], m[7]));
+        } else {
+          *(float4*)(pq + cout0 + cg * 8) = make_float4(m[0], m[1], m[2], m[3]);
+          *(float4*)(pq + cout0 + cg * 8 + 4) = make_float4(m[4], m[5], m[6], m[7]);
+        }
+      }
+    }
+  }
+}
+
 template <int BN, int NT, int ROWS = 16>
 __device__ __forceinline__ void conv_flush_tile(const float* __restrict__ Cs, int tid, int ty0, int tx0, int H, int W,
                                                 int b, int cout0, float* __restrict__ gout, int out_stride,
                                                 float* __restrict__ gpool, int pool_stride, bool write_main,
                                                 bool main_split = false, bool pool_split = false) {
+#ifndef SHF_FLUSH_SPLIT8
+#define SHF_FLUSH_SPLIT8 1
+#endif
+  if constexpr (SHF_FLUSH_SPLIT8 && NT / (BN / 8) >= 16) {
+    if ((write_main && main_split) || (!write_main && gpool && pool_split)) {
+      conv_flush_tile_split8<BN, NT, ROWS>(Cs, tid, ty0, tx0, H, W, b, cout0, gout, out_stride, gpool, pool_stride,
+                                           write_main, pool_split);
+      return;
+    }
+  }
   constexpr int CG = BN / 4;       // float4 groups per pixel
   constexpr int PPI = NT / CG;     // pixels per block-wide store instruction: 8 (4 waves x BN 128), 16 or 32
   static_assert(PPI == 8 || PPI == 16 || PPI == 32, "tile walk assumes 8, 16 or 32 pixels per store round");
