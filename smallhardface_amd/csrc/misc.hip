@@ -4,6 +4,8 @@
 //   depthwise deconv    caffe/src/caffe/layers/deconv_layer.cu:8-23 (256 serial GEMMs + col2im in the reference)
 //   concat              caffe/src/caffe/layers/concat_layer.cu (zero-copy here: producers write channel slices)
 //   NCHW<->NHWC         the host-visible Blob.data layout (caffe/python/caffe/_caffe.cpp:222-242)
+#include <algorithm>
+
 #include "shf_internal.h"
 
 namespace shf {
@@ -90,6 +92,83 @@ __global__ void deconv_dw_kernel(const float* __restrict__ in, const float* __re
   // split-fp16 mode: the consumer of this map splits it to fp16 hi/lo -- raise the range flag beyond 65504
   if (range_flag && !(fmaxf(fmaxf(fabsf(acc[0]), fabsf(acc[1])), fmaxf(fabsf(acc[2]), fabsf(acc[3]))) <= 65504.0f))
     atomicOr(range_flag, 1);
+}
+
+// the same for a GROUP of maps sharing the layer (the units of an image's pyramid): one launch, the members stacked
+// along the output-row axis of the grid
+struct DeconvGM {
+  const float* in;
+  float* out;
+  int H, W, Ho, Wo, in_stride, out_stride, row_start;
+};
+struct DeconvGK {
+  int n, C, k, stride, pad;
+  const float* w;
+  const float* bias;
+  int* range_flag;
+  DeconvGM m[16];
+};
+__global__ void deconv_dw_group_kernel(DeconvGK g) {
+  int mi = 0;
+#pragma unroll
+  for (int q = 1; q < 16; ++q) mi += (q < g.n && (int)blockIdx.y >= g.m[q].row_start) ? 1 : 0;
+  const DeconvGM& p = g.m[mi];
+  const int oy = (int)blockIdx.y - p.row_start;
+  const unsigned C4 = (unsigned)g.C >> 2;
+  const unsigned n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= (unsigned)p.Wo * C4) return;
+  const int c4 = (int)(n % C4), ox = (int)(n / C4);
+  const int k = g.k, stride = g.stride, pad = g.pad;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int a = (oy + pad) % stride; a < k; a += stride) {
+    const int ty = oy + pad - a;
+    if (ty < 0) break;
+    const int iy = ty / stride;
+    if (iy >= p.H) continue;
+    for (int bb = (ox + pad) % stride; bb < k; bb += stride) {
+      const int tx = ox + pad - bb;
+      if (tx < 0) break;
+      const int ix = tx / stride;
+      if (ix >= p.W) continue;
+      const float4 v = *(const float4*)(p.in + ((size_t)iy * p.W + ix) * p.in_stride + c4 * 4);
+      const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] = fmaf(vv[j], g.w[((size_t)(c4 * 4 + j) * k + a) * k + bb], acc[j]);
+    }
+  }
+  if (g.bias)
+    for (int j = 0; j < 4; ++j) acc[j] += g.bias[c4 * 4 + j];
+  *(float4*)(p.out + ((size_t)oy * p.Wo + ox) * p.out_stride + c4 * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+  if (g.range_flag && !(fmaxf(fmaxf(fabsf(acc[0]), fabsf(acc[1])), fmaxf(fabsf(acc[2]), fabsf(acc[3]))) <= 65504.0f))
+    atomicOr(g.range_flag, 1);
+}
+
+int launch_deconv_depthwise_group(const View* ins, const View* outs, int n, const float* w, const float* bias, int k,
+                                  int stride, int pad, hipStream_t s, int* range_flag) {
+  if (n < 1 || n > 16) { set_error("deconv group: 1..16 members"); return -1; }
+  DeconvGK g;
+  g.n = n; g.C = ins[0].C; g.k = k; g.stride = stride; g.pad = pad;
+  g.w = w; g.bias = bias; g.range_flag = range_flag;
+  int rows = 0;
+  unsigned per_row_max = 1;
+  for (int i = 0; i < n; ++i) {
+    const View& in = ins[i];
+    const View& out = outs[i];
+    if (in.B != 1 || in.C != g.C || in.C % 4 || in.cstride % 4 || in.coff % 4 || out.cstride % 4 || out.coff % 4) {
+      set_error("deconv group: batch 1, shared channel count, views multiples of 4");
+      return -1;
+    }
+    DeconvGM& m = g.m[i];
+    m.in = in.p + in.coff; m.out = out.p + out.coff;
+    m.H = in.H; m.W = in.W; m.Ho = out.H; m.Wo = out.W;
+    m.in_stride = in.cstride; m.out_stride = out.cstride;
+    m.row_start = rows;
+    rows += out.H;
+    per_row_max = std::max(per_row_max, ((unsigned)out.W * (unsigned)(in.C / 4) + 255) / 256);
+  }
+  hipLaunchKernelGGL(deconv_dw_group_kernel, dim3(per_row_max, rows, 1), dim3(256), 0, s, g);
+  SHF_HIP_OK(hipGetLastError());
+  return 0;
 }
 
 int launch_deconv_depthwise(const View& in, const View& out, const float* w, const float* bias, int k, int stride,

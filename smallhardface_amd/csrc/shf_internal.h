@@ -78,6 +78,8 @@ int launch_maxpool(const View& in, const View& out, int k, int stride, int pad, 
 // depthwise transposed conv (group == C), weights (C,1,k,k) Caffe layout
 int launch_deconv_depthwise(const View& in, const View& out, const float* w, const float* bias, int k,
                             int stride, int pad, hipStream_t s, int* range_flag = nullptr);
+int launch_deconv_depthwise_group(const View* ins, const View* outs, int n, const float* w, const float* bias, int k,
+                                  int stride, int pad, hipStream_t s, int* range_flag = nullptr);
 int launch_copy_view(const View& in, const View& out, hipStream_t s);       // concat fallback
 int launch_nhwc_to_nchw(const View& in, float* out_nchw, hipStream_t s);    // blob.data read-back
 int launch_nchw_to_nhwc(const float* in_nchw, const View& out, hipStream_t s);
