@@ -115,7 +115,8 @@ int shf_detect_add_level(shf_net* net, const float* data, int data_on_device,
  * layer runs as ONE grid over all units (they share the layer's weights, not the spatial
  * size), so the small levels do not serialise latency-bound launches.  members[i] supplies
  * the activation buffers of unit i: `net` itself and/or lanes made with shf_net_clone, all
- * distinct; the work is enqueued on `net`'s stream and the detections land in `net`'s image
+ * distinct, at most 16 per call (one kernel-argument member table; more units = several calls, the lists
+ * concatenate); the work is enqueued on `net`'s stream and the detections land in `net`'s image
  * list in unit order -- or, with per_member_lists != 0 (units of DIFFERENT images, the multi-GPU
  * window), in each member's own list (reset first); synchronise `net` before exporting them. */
 int shf_detect_add_levels(shf_net* net, int n, shf_net** members, const float* const* data,

@@ -159,11 +159,17 @@ class Net(object):
         return lane
 
     def _apply_cfg(self):
-        # the reference's Python layer reads these from the global cfg at forward time
+        """The reference's Python layer reads cfg.TEST.* at EVERY forward (lib/layers/proposal_layer.py:88-92): called
+        from forward() / detect_begin(), pushed to the runtime (shared by all lanes) only when a value changed."""
         from ..config import cfg
-        self.set_proposal_cfg(cfg.TEST.N_DETS_PER_MODULE, cfg.TEST.SCORE_THRESH, cfg.TEST.ANCHOR_MIN_SIZE)
+        cur = (int(cfg.TEST.N_DETS_PER_MODULE), float(cfg.TEST.SCORE_THRESH), float(cfg.TEST.ANCHOR_MIN_SIZE))
+        root = getattr(self, "_parent", self)
+        if getattr(root, "_cfg_applied", None) != cur:
+            self.set_proposal_cfg(*cur)
+            root._cfg_applied = cur
 
     def set_proposal_cfg(self, pre_nms_topN, score_thresh, min_size):
+        getattr(self, "_parent", self)._cfg_applied = None   # an explicit override: re-read cfg at the next forward
         _lib.check(self._lib.shf_net_set_proposal_cfg(self._h, int(pre_nms_topN), float(score_thresh),
                                                       float(min_size)), "set_proposal_cfg")
 
@@ -227,6 +233,7 @@ class Net(object):
 
     def _forward(self, start=0, end=None):
         self.commit_params()
+        self._apply_cfg()
         _lib.check(self._lib.shf_net_forward(self._h), "Net.forward")
 
     def forward(self, blobs=None, start=None, end=None, **kwargs):
@@ -268,6 +275,7 @@ class Net(object):
     # -- fused per-image path (device-resident pyramid) ----------------------------
     def detect_begin(self):
         self.commit_params()
+        self._apply_cfg()
         _lib.check(self._lib.shf_detect_begin(self._h), "detect_begin")
 
     def detect_add_level(self, data, H, W, im_h, im_w, im_scale, flip, thresh, on_device=False):

@@ -8,16 +8,17 @@
 //      corr += a_hi * b_lo + a_lo * b_hi            (both carry the 2^11 scale)
 //      out   = main + corr * 2^-11                   (a_lo*b_lo ~ 2^-22 relative is dropped)
 // v_mfma_f32_32x32x16_f16 retires 16 k per 32 cycles against 2 k per 64 cycles for the exact
-// v_mfma_f32_32x32x2_f32, so three of them are 16/3 = 5.3x the fp32 MFMA rate.  Activations
-// stay fp32 in HBM (the split happens while the halo tile is staged into LDS); weights are
-// split once at load time.  Used for the 3x3 / dilation-1 layers (97 % of the FLOPs); the
-// dilated heads and the 1x1 convs stay on the exact fp32 kernel (conv.hip).
+// v_mfma_f32_32x32x2_f32, so three of them are 16/3 = 5.3x the fp32 MFMA rate.  Activations keep 4 B per
+// element in HBM -- fp32, split while the halo tile is staged into LDS, or already split by the producer's
+// epilogue (ConvArgs::in_split / out_split) -- and weights are split once at load time.  Every MFMA convolution
+// of the detector runs here in the split-fp16 modes: 3x3 at dilation 1, 2, 4 and the 1x1s.
 //
-// Structure: block = 512 threads (8 waves), tile 256 px (16x16) x BN couts; a STAGE is one
-// kernel row (3 taps) of one 32-channel chunk: its three BNx32 weight slabs are double-
-// buffered in LDS (fetched two stages ahead into registers, parked at the top of the stage);
-// the 18x18x32 halo tile is staged once per chunk and reused by all 9 taps.  LDS rows are
-// [hi: 32 halfs][lo: 32 halfs][16 B pad] = 144 B (conflict-free ds_read_b128).
+// Kernels: conv_mfma_f16x3_w4_kernel (4 waves, one per SIMD: Cin >= 128, Cout % 128 == 0 -- 70 % of the time),
+// conv_mfma_f16x3_pc_kernel (fused first pair conv1_1 -> conv1_2, producer/consumer waves) and the 8-wave
+// conv_mfma_f16x3_kernel below (Cin 64, dilated heads, 1x1).  Common structure: tile 256 px (16x16) x BN couts; a
+// STAGE is one kernel row (3 taps) of one 32-channel chunk: its three BNx32 weight slabs are double-buffered in
+// LDS and arrive by LDS DMA; the 18x18x32 halo tile is staged once per chunk and reused by all 9 taps.  LDS rows
+// are [hi: 32 halfs][lo: 32 halfs][16 B pad] = 144 B (conflict-free ds_read_b128 over consecutive rows).
 #include <algorithm>
 #include <cstdint>
 #include <cstdio>
