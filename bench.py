@@ -212,6 +212,11 @@ def main():
         while len(lanes) < 1 + 2 * len(mine):
             lanes.append(net.clone())
         lane_sets = [lanes[1:1 + len(mine)], lanes[1 + len(mine):1 + 2 * len(mine)]]
+        # both windows' convolutions on ONE in-order stream, the tails / exports on the set heads' own high-priority
+        # streams, the merges on the root net's (shf_net_set_pipeline): no dependence on how the runtime maps streams
+        # to hardware queues
+        for h in [ls[0] for ls in lane_sets if ls] + [net]:
+            h.set_pipeline(True)
         export_sets = [export, [torch.empty_like(e) for e in export]]
         mine_units = [(units[k][0].data_ptr(),) + units[k][1:] for k in mine]
     state = {"k": 0, "pending": None, "collectives": 0}

@@ -1693,7 +1693,7 @@ int shf_detect_add_levels(shf_net* net, int n, shf_net** members, const float* c
   // Pipelined heads (shf_net_set_pipeline): the convolutions and logits kernels of consecutive images share ONE
   // in-order stream, so no cross-stream hand-over is needed for the activation buffers; only the rest of the tails,
   // the appends and the merge run on this head's own stream, beside the next image's convolutions.
-  const bool shared = net->pipelined && net->sh->conv_stream && !per_member_lists;
+  const bool shared = net->pipelined && net->sh->conv_stream;
   hipStream_t cs = shared ? net->sh->conv_stream : net->stream;
   const bool early_start = !shared && net->pred && net->pred->ev_convs && first_feat_writer < (int)net->layers.size();
   if (early_start) HIP_THROW(hipStreamWaitEvent(net->stream, net->pred->ev_convs, 0));
@@ -1702,8 +1702,8 @@ int shf_detect_add_levels(shf_net* net, int n, shf_net** members, const float* c
       HIP_THROW(hipStreamWaitEvent(net->stream, members[m]->ev_logits, 0));
     members[m]->prepare_unit(data[m], data_on_device, H[m], W[m], cs);
   }
-  if (shared) HIP_THROW(hipMemsetAsync(net->range_flag.p, 0, 4, cs));  // (detect_begin zeroes it on the head's stream)
-  if (per_member_lists) HIP_THROW(hipMemsetAsync(net->range_flag.p, 0, 4, net->stream));  // no detect_begin on this path
+  if (shared && !per_member_lists) HIP_THROW(hipMemsetAsync(net->range_flag.p, 0, 4, cs));  // (detect_begin zeroes it on the head's stream)
+  if (per_member_lists) HIP_THROW(hipMemsetAsync(net->range_flag.p, 0, 4, cs));  // no detect_begin on this path
   struct FlagScope {  // one range flag per pass: the head's
     shf_net** mb; int n;
     FlagScope(shf_net** m, int n_, int* f) : mb(m), n(n_) { for (int i = 0; i < n; ++i) mb[i]->flag_ptr = f; }

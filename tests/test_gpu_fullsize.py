@@ -350,7 +350,8 @@ def test_dataset_scale_sets(name, n_units):
     b = T.detect_fused(gnet, units, thresh=0.05)[0]
     np.testing.assert_array_equal(a, b)
     assert len(a) > 0 and np.all(np.diff(a[:, 4]) <= 0) and np.all(a[:, 4] > 0.05)
-    assert a[:, [0, 2]].max() <= 400 and a[:, [1, 3]].max() <= 300 and a[:, :4].min() >= -1e-3
+    # (clipped at the scaled image, then divided by the scale in fp32: a last-ulp overshoot is the reference's too)
+    assert a[:, [0, 2]].max() <= 400 + 1e-3 and a[:, [1, 3]].max() <= 300 + 1e-3 and a[:, :4].min() >= -1e-3
     buf = torch.empty((10000, 5), dtype=torch.float32, device="cuda")
     checked = 0
     for u in units:
