@@ -30,6 +30,8 @@ tail -40 $out/layer_table.log
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --steps 10 --warmup 2 > $out/bench_under_rocprof.out 2> $out/bench_under_rocprof.log
 grep '^{"metric"' $out/bench_under_rocprof.out | tail -1 > $dst/${tag}_bench_under_rocprof.json
 cp $(ls $out/stats/*/*kernel_stats.csv | head -1) $dst/${tag}_bench_kernel_stats.csv
+# the bench line quotes traffic / MFMA-busy from the committed counter file: make this run's the committed one
+cp $dst/${tag}_pmc.json $dst/${tag}_layers.csv $root/profiles/ 2>/dev/null
 python3 bench.py 2>/dev/null | tail -1 > $dst/${tag}_bench.json
 python3 bench.py --steps 5 --warmup 2 --conv-mode fp32 --no-cpu-baseline 2>/dev/null | tail -1 > $dst/${tag}_bench_fp32_mode.json
 python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --host-input image 2>/dev/null | tail -1 > $dst/${tag}_bench_from_uint8_image.json
