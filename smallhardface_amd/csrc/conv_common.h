@@ -29,6 +29,7 @@ struct ConvK {
                      // main / the pooled output in the split-fp16 activation format (ConvArgs::out_split)
   int pool_stride;   // floats per pixel of the pool buffer
   int nct, nmem;
+  int ntile_blocks;  // persistent kernels: pixel tiles x cout tiles of the whole launch (the grid is smaller)
   const float* w1t;  // FUSE1: first-layer weights transposed to [27][64]
   const void* w1f;   // FUSE1 (producer/consumer kernel): the same as split-fp16 MFMA B fragments (pack_first_conv_frags)
   const float* b1;   // FUSE1: first-layer bias [64]
@@ -310,6 +311,133 @@ __device__ __forceinline__ void conv_flush_tile(const float* __restrict__ Cs, in
           conv_store_split4(pp, cout0 + cg * 4, m);
         else
           *(float4*)(pp + cout0 + cg * 4) = m;
+      }
+    }
+  }
+}
+
+// The persistent 4-wave kernel's epilogue unit: one QUARTER of the 16x16 tile -- tile rows {2q, 2q+1, 8+2q, 8+2q+1},
+// staged as Cs rows 0..3 (64 pixels x BN couts) -- written by 256 threads, 8 channels each: a block-wide round is one
+// tile row (16 pixels x 128 couts), four rounds; the 16 pooling windows of the quarter are one per 16 threads.
+template <int BN>
+__device__ __forceinline__ void conv_flush_quarter(const float* __restrict__ Cs, int tid, int q, int ty0, int tx0, int H,
+                                                   int W, int b, int cout0, float* __restrict__ gout, int out_stride,
+                                                   float* __restrict__ gpool, int pool_stride, bool write_main,
+                                                   bool main_split, bool pool_split) {
+  constexpr int CG = BN / 8;
+  static_assert(CG == 16, "256 threads = 16 pixels x 16 channel groups");
+  const int cg = tid % CG, p0 = tid / CG;
+  if (write_main) {
+    const int x = tx0 + p0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int y = ty0 + (r >> 1) * 8 + 2 * q + (r & 1);
+      if (y < H && x < W) {
+        const float* c = Cs + (r * 16 + p0) * (BN + CS_PAD) + cg * 8;
+        float* g = gout + ((size_t)(b * H + y) * W + x) * out_stride;
+        const float4 v0 = *(const float4*)c, v1 = *(const float4*)(c + 4);
+        if (main_split) {
+          conv_store_split8(g, cout0 + cg * 8, v0, v1);
+        } else {
+          *(float4*)(g + cout0 + cg * 8) = v0;
+          *(float4*)(g + cout0 + cg * 8 + 4) = v1;
+        }
+      }
+    }
+  }
+  if (gpool) {
+    const int Hp = (H + 1) >> 1, Wp = (W + 1) >> 1;
+    const int pair = p0 >> 3, lx = (p0 & 7) * 2;
+    const int y = ty0 + pair * 8 + 2 * q, x = tx0 + lx;
+    if (y < H && x < W) {
+      // windows on a ragged edge are clipped like Caffe's (pooling_layer.cu:24-27)
+      const float* c0 = Cs + (pair * 2 * 16 + lx) * (BN + CS_PAD) + cg * 8;
+      float m[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) m[j] = -3.402823466e+38f;
+      auto mx = [&](const float* qq) {
+        const float4 a = *(const float4*)qq, bq = *(const float4*)(qq + 4);
+        const float v[8] = {a.x, a.y, a.z, a.w, bq.x, bq.y, bq.z, bq.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) m[j] = v[j] > m[j] ? v[j] : m[j];
+      };
+      mx(c0);
+      if (x + 1 < W) mx(c0 + (BN + CS_PAD));
+      if (y + 1 < H) {
+        mx(c0 + 16 * (BN + CS_PAD));
+        if (x + 1 < W) mx(c0 + 17 * (BN + CS_PAD));
+      }
+      float* pq = gpool + ((size_t)(b * Hp + (y >> 1)) * Wp + (x >> 1)) * pool_stride;
+      if (pool_split) {
+        conv_store_split8(pq, cout0 + cg * 8, make_float4(m[0], m[1], m[2], m[3]), make_float4(m[4], m[5], m[6], m[7]));
+      } else {
+        *(float4*)(pq + cout0 + cg * 8) = make_float4(m[0], m[1], m[2], m[3]);
+        *(float4*)(pq + cout0 + cg * 8 + 4) = make_float4(m[4], m[5], m[6], m[7]);
+      }
+    }
+  }
+}
+
+// REGISTER epilogue for kernels that run the MFMA with the WEIGHTS as the A operand, i.e. D[cout][pixel]: a lane then
+// owns ONE pixel (column lane & 31 -> row_to_pixel) and 16 couts of the 32-cout tile, rows (r & 3) + 8 (r >> 2) + 4 kh.
+// Four v_permlane32_swap pairs exchange register quads between the two half-waves (same pixel, kh = 0 / 1) so that
+// kh = 0 ends up with couts 0..15 and kh = 1 with couts 16..31, in register order 0-3, 8-11, 4-7, 12-15 -- 64
+// contiguous bytes of the pixel (fp32 output) or 32 B of hi + 32 B of lo (split-fp16 output): four 16-byte stores per
+// accumulator tile, no LDS round trip and no barrier.  The fused 2x2 max-pool is a max over the four lanes of a quad
+// (row_to_pixel walks a 2x2 window with the two low lane bits): two DPP quad permutes; windows on a ragged edge are
+// clipped like Caffe's (pooling_layer.cu:24-27) by feeding -FLT_MAX for pixels outside the image.
+template <bool RELU>
+__device__ __forceinline__ void conv_epilogue_regs(const cs_f32x16 am, const cs_f32x16 ac, float inv, const float4* bias16,
+                                                   bool valid, float* __restrict__ pix_main, int cout16, bool main_split,
+                                                   float* __restrict__ pix_pool, bool pool_writer, bool pool_split,
+                                                   float& amax) {
+  float v[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) v[r] = __builtin_fmaf(ac[r], inv, am[r]);
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    const int x = (s & 3) + 4 * (s >> 2), y = x + 8;   // (0..3 <-> 8..11), (4..7 <-> 12..15)
+    // (inline asm: hipcc 7.2 drops the SECOND result of __builtin_amdgcn_permlane32_swap -- both outputs come back as
+    // the new vdst; the s_nop covers the VALU-write -> permlane-read wait states the compiler would have inserted)
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(v[x]), "+v"(v[y]));
+  }
+  constexpr int ORD[4] = {0, 8, 4, 12};
+  float4 o[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    o[g] = make_float4(v[ORD[g]] + bias16[g].x, v[ORD[g] + 1] + bias16[g].y, v[ORD[g] + 2] + bias16[g].z,
+                       v[ORD[g] + 3] + bias16[g].w);
+    if (RELU) o[g] = make_float4(fmaxf(o[g].x, 0.f), fmaxf(o[g].y, 0.f), fmaxf(o[g].z, 0.f), fmaxf(o[g].w, 0.f));
+    amax = fmaxf(fmaxf(amax, fabsf(o[g].x)), fabsf(o[g].y));
+    amax = fmaxf(fmaxf(amax, fabsf(o[g].z)), fabsf(o[g].w));
+  }
+  if (pix_main && valid) {
+    if (main_split) {
+      conv_store_split8(pix_main, cout16, o[0], o[1]);
+      conv_store_split8(pix_main, cout16 + 8, o[2], o[3]);
+    } else {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) *(float4*)(pix_main + cout16 + 4 * g) = o[g];
+    }
+  }
+  if (pix_pool) {
+    auto quad_max = [&](float x) {
+      x = valid ? x : -3.402823466e+38f;
+      int xi = __builtin_bit_cast(int, x);
+      x = fmaxf(x, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(xi, xi, 0xB1, 0xf, 0xf, false)));  // quad_perm [1,0,3,2]
+      xi = __builtin_bit_cast(int, x);
+      return fmaxf(x, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(xi, xi, 0x4E, 0xf, 0xf, false)));  // [2,3,0,1]
+    };
+    float4 m[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) m[g] = make_float4(quad_max(o[g].x), quad_max(o[g].y), quad_max(o[g].z), quad_max(o[g].w));
+    if (pool_writer) {
+      if (pool_split) {
+        conv_store_split8(pix_pool, cout16, m[0], m[1]);
+        conv_store_split8(pix_pool, cout16 + 8, m[2], m[3]);
+      } else {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) *(float4*)(pix_pool + cout16 + 4 * g) = m[g];
       }
     }
   }

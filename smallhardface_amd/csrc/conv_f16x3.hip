@@ -51,6 +51,14 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
                              // 16 lanes of a ds_read_b128 group then share banks two by two (SQ_LDS_BANK_CONFLICT: 37 % of
                              // the LDS cycles, profiles/r02_pmc.json).  +96 B makes the row distance 8 (mod 16): conflict-free.
 #endif
+#ifndef F16X3_W4_REGEPI
+#define F16X3_W4_REGEPI 1    // 4-wave kernels: MFMA as D[cout][pixel] + register epilogue (1) or D[pixel][cout] + LDS-transposed epilogue (0)
+#endif
+#if F16X3_W4_REGEPI
+#define W4_MFMA(px, wt, acc) __builtin_amdgcn_mfma_f32_32x32x16_f16(wt, px, acc, 0, 0, 0)
+#else
+#define W4_MFMA(px, wt, acc) __builtin_amdgcn_mfma_f32_32x32x16_f16(px, wt, acc, 0, 0, 0)
+#endif
 #ifndef F16X3_CONV_MID
 #define F16X3_CONV_MID 1   // 1: split the next halo tile to fp16 hi/lo in the middle of the last stage's MFMAs
 #endif
@@ -573,9 +581,14 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4_kernel(ConvK p) {
   // prologue: W(0) by DMA and the halo tile of chunk 0 are requested first; the accumulator clearing and
   // the fragment geometry fill the wait
   float4 areg0[ALD];
+#ifdef F16X3_EXPERIMENT_NO_PROLOGUE  // timing only (WRONG results): what a hidden prologue (persistent tiles) could save
+#pragma unroll
+  for (int j = 0; j < ALD; ++j) areg0[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+#else
   dma_w(0, 0, 0, DMA_ROUNDS_W4);
 #pragma unroll
   for (int j = 0; j < ALD; ++j) areg0[j] = *(const float4*)(gin + a_gsafe[j]);
+#endif
 
   const int i = lane & 31, kh = lane >> 5;
   int dy, px;
@@ -684,20 +697,20 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4_kernel(ConvK p) {
       for (int tm = 0; tm < MT; ++tm)
 #pragma unroll
         for (int tn = 0; tn < 2; ++tn)
-          accm[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[2 * tm], bf[2 * tn], accm[tm][tn], 0, 0, 0);
+          accm[tm][tn] = W4_MFMA(a[2 * tm], bf[2 * tn], accm[tm][tn]);
       if constexpr (NP >= 2) {
 #pragma unroll
         for (int tm = 0; tm < MT; ++tm)
 #pragma unroll
           for (int tn = 0; tn < 2; ++tn)
-            accc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[2 * tm], bf[2 * tn + 1], accc[tm][tn], 0, 0, 0);
+            accc[tm][tn] = W4_MFMA(a[2 * tm], bf[2 * tn + 1], accc[tm][tn]);
       }
       if constexpr (NP >= 3) {
 #pragma unroll
         for (int tm = 0; tm < MT; ++tm)
 #pragma unroll
           for (int tn = 0; tn < 2; ++tn)
-            accc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[2 * tm + 1], bf[2 * tn], accc[tm][tn], 0, 0, 0);
+            accc[tm][tn] = W4_MFMA(a[2 * tm + 1], bf[2 * tn], accc[tm][tn]);
       }
       if (s_ + 1 < 6) {
         // next step's 12 fragment reads go out under the first 12 MFMAs (12 more to land), the VMEM
@@ -755,6 +768,36 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4_kernel(ConvK p) {
 #endif
 
   float amax = 0.f;  // fp16 range guard: largest |output| of this lane
+#if F16X3_W4_REGEPI
+  // register epilogue (conv_common.h): the lane's pixel is row_to_pixel(i) of each M tile, its 16 couts follow kh
+  {
+    const bool relu = (p.relu & 1) != 0, write_main = !(p.relu & 8), main_split = (p.relu & 32) != 0,
+               pool_split = (p.relu & 64) != 0;
+    const int Hp = (H + 1) >> 1, Wp = (W + 1) >> 1;
+    const int x = tx0 + px;
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) {
+      const int cout16 = ct * BN + wn * 64 + tn * 32 + kh * 16;
+      float4 bias16[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        bias16[g] = p.bias ? *(const float4*)(p.bias + cout16 + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int tm = 0; tm < MT; ++tm) {
+        const int y = ty0 + wm * 2 * MT + tm * 2 + dy;
+        const bool valid = y < H && x < W;
+        float* pm = write_main ? gout + ((size_t)(b * H + y) * W + x) * p.out_stride : nullptr;
+        float* pp = mem.pool ? mem.pool + ((size_t)(b * Hp + (y >> 1)) * Wp + (x >> 1)) * p.pool_stride : nullptr;
+        if (relu)
+          conv_epilogue_regs<true>(accm[tm][tn], accc[tm][tn], LO_INV, bias16, valid, pm, cout16, main_split, pp,
+                                   valid && (i & 3) == 0, pool_split, amax);
+        else
+          conv_epilogue_regs<false>(accm[tm][tn], accc[tm][tn], LO_INV, bias16, valid, pm, cout16, main_split, pp,
+                                    valid && (i & 3) == 0, pool_split, amax);
+      }
+    }
+  }
+#else
   if (p.relu & 16) {
     __syncthreads();  // the K loop's LDS buffers are dead: the output tile is transposed through them
     float* Cs = (float*)smem;
@@ -797,7 +840,10 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4_kernel(ConvK p) {
       }
     }
   }
+#endif
+#ifndef F16X3_EXPERIMENT_NO_PROLOGUE
   conv_raise_range_flag(p.range_flag, amax);
+#endif
 #ifdef SHF_CONV_TIMING
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   const unsigned long long t_exit = __builtin_amdgcn_s_memtime(), r_exit = __builtin_amdgcn_s_memrealtime();
@@ -813,6 +859,331 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4_kernel(ConvK p) {
 #endif
   }
 #endif
+}
+
+// PERSISTENT form of the 4-wave kernel (16x16-pixel tiles): one block per CU walks the tiles bid, bid + grid, ...
+// The stage pipeline simply runs on across tiles: the LAST stage of tile t requests the halo tile of tile t+1's first
+// chunk (the same register hand-over a chunk boundary uses) and its weight DMA fetches stage 0 of tile t+1 (grid is a
+// multiple of the cout-tile count, so a block keeps its cout tile and stage 0 is always the same slab), and both land
+// under tile t's epilogue -- the 9-10 k cycles a fresh block spends waiting for its first ~100 KB are paid once per
+// block instead of once per tile.  The epilogue therefore has to leave the halo tile and weight buffer 0 alone: the
+// output tile goes through LDS in four QUARTERS (tile rows {2q, 2q+1, 8+2q, 8+2q+1} = every wave's M-tile q, 64 px x
+// 128 couts = 36 KiB) staged in weight buffer 1, which the last stage (NST is even) has just finished with.
+// Everything tile-dependent is either wave-uniform (SGPRs) or recomputed in place (the 11 halo offsets, from an
+// opaque copy of the thread id so that the tile-invariant half of that arithmetic is not hoisted out of the tile
+// loop into 22 long-lived registers: DESIGN.md, hipcc lessons).
+template <bool IN_SPLIT, int MT_, int NP = 3>
+__global__ __launch_bounds__(256) void conv_mfma_f16x3_w4p_kernel(ConvK p) {
+  using namespace f16x3;
+  static_assert(MT_ == 4, "persistent form: 16-row tiles");
+  constexpr int TH = 4 * MT_, HTH = TH + 2, HP = HTH * HTW;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int BN = 128, MT = MT_, NT = 256;
+  constexpr int ALD = (HP * 8 + NT - 1) / NT;  // float4 halo pieces per thread: 11
+  constexpr int HPITCH = HTW * ROWB + F16X3_W4_ROWPAD;
+  unsigned char* As = smem;                    // [HTH][HPITCH]
+  unsigned char* Bs = smem + HTH * HPITCH;     // [2][3][BN][ROWB]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave & 1, wm = wave >> 1;
+  const int G = gridDim.x;                     // a multiple of nct (launcher)
+  int t_cur = blockIdx.x;
+  const int ct = t_cur % p.nct;
+
+  const int nchunks = p.Cin / KC;
+  const int NST = nchunks * 3;                 // even: Cin is a multiple of 64 on this path
+  const _Float16* wsp = (const _Float16*)p.wp;
+  const size_t slab = (size_t)p.Cout * 72;
+  const _Float16* wbase = wsp + (size_t)ct * BN * 72;
+
+  // ---- tile geometry: wave-uniform ----
+  struct Geo { int ty0, tx0, H, W, b; const float* in; float* out; float* pool; };
+  auto geometry = [&](int t) {
+    Geo g;
+    int pt = t / p.nct;
+    const int mi = conv_find_member(p, pt);
+    const ConvMember& mem = p.m[mi];
+    pt -= mem.tile_start;
+    g.b = pt / mem.tiles_per_img;
+    pt -= g.b * mem.tiles_per_img;
+    g.ty0 = (pt / mem.tiles_x) * TH;
+    g.tx0 = (pt % mem.tiles_x) * TW;
+    g.H = mem.H; g.W = mem.W;
+    g.in = mem.in; g.out = mem.out; g.pool = mem.pool;
+    return g;
+  };
+  // halo piece j of this thread: float4 q of halo pixel hp0 + 32 j.  Out-of-image pieces read the member's first
+  // pixel and are zeroed afterwards (bit j of a_valid).  exists = false: a block without a next tile fetches nothing real.
+  int a_gsafe[ALD];
+  unsigned a_valid = 0;
+  auto halo_offsets = [&](const Geo& g, bool exists) {
+    int tid_o = tid;
+    asm volatile("" : "+v"(tid_o));  // (opaque: keeps hy / hx / q of the 11 pieces out of the tile loop's live set)
+    a_valid = 0;
+#pragma unroll
+    for (int j = 0; j < ALD; ++j) {
+      const int idx = tid_o + NT * j;
+      const int hp = idx >> 3, q = idx & 7;
+      const int hy = hp / HTW, hx = hp - hy * HTW;
+      const int gy = g.ty0 - 1 + hy, gx = g.tx0 - 1 + hx;
+      const bool in = exists && (idx < HP * 8) && ((unsigned)gy < (unsigned)g.H) && ((unsigned)gx < (unsigned)g.W);
+      a_gsafe[j] = in ? ((g.b * g.H + gy) * g.W + gx) * p.in_stride + q * 4 : 0;
+      a_valid |= in ? (1u << j) : 0u;
+    }
+  };
+  Geo go = geometry(t_cur);                    // the tile whose accumulators are live (epilogue geometry)
+  const float* __restrict__ gin = go.in;      // input of the tile whose halo pieces are fetched next
+  halo_offsets(go, true);
+
+  const int a_loff0 = (tid >> 3) * ROWB + (tid & 7) * 8;
+  const bool a_last = tid + NT * (ALD - 1) < HP * 8;
+  auto split_inplace = [&](float4& v, bool valid) {
+    if constexpr (IN_SPLIT) {
+      if (!valid) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      return;
+    }
+    half4 hi, lo;
+    split4(valid ? v : make_float4(0.f, 0.f, 0.f, 0.f), hi, lo);
+    const float2 h2 = __builtin_bit_cast(float2, hi), l2 = __builtin_bit_cast(float2, lo);
+    v = make_float4(h2.x, h2.y, l2.x, l2.y);
+  };
+  auto store_piece = [&](const float4& v, int j) {
+    const int rowpad = (((tid >> 3) + 32 * j) / HTW) * F16X3_W4_ROWPAD;
+    if constexpr (IN_SPLIT) {
+      *(float4*)(As + (tid >> 3) * ROWB + (tid & 7) * 16 + j * 32 * ROWB + rowpad) = v;
+    } else {
+      *(float2*)(As + a_loff0 + j * 32 * ROWB + rowpad) = make_float2(v.x, v.y);
+      *(float2*)(As + a_loff0 + j * 32 * ROWB + rowpad + 64) = make_float2(v.z, v.w);
+    }
+  };
+  constexpr int SLAB_B = BN * ROWB;
+  constexpr int PCS_SLAB = SLAB_B / 1024;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  constexpr int DMA_ROUNDS_W4 = 15;
+  const unsigned lane16 = (unsigned)lane * 16u;
+  const int last_piece = wave_u + 16 < PCS_SLAB ? wave_u + 16 : PCS_SLAB - 1;
+  auto dma_w = [&](int stage, int buf, int j0, int n) {
+    const unsigned char* ws_ = (const unsigned char*)(wbase + (size_t)stage * 3 * slab);
+    unsigned char* bd_ = Bs + buf * (3 * SLAB_B);
+#pragma unroll
+    for (int j = j0; j < j0 + n; ++j) {
+      const int sl = j / 5, i5 = j % 5;
+      const int within = i5 < 4 ? wave_u + 4 * i5 : last_piece;
+      const unsigned char* ub = ws_ + (size_t)sl * slab * 2 + within * 1024;   // wave-uniform
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ub + lane16),
+                                       (__attribute__((address_space(3))) void*)(bd_ + sl * SLAB_B + within * 1024), 16, 0,
+                                       0);
+    }
+  };
+  // prologue of the block's FIRST tile
+  float4 areg0[ALD];
+  dma_w(0, 0, 0, DMA_ROUNDS_W4);
+#pragma unroll
+  for (int j = 0; j < ALD; ++j) areg0[j] = *(const float4*)(gin + a_gsafe[j]);
+
+  const int i = lane & 31, kh = lane >> 5;
+  int dy, px;
+  row_to_pixel(i, dy, px);
+  int a_off[MT], b_off[2];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) a_off[t] = (wm * 2 * MT + t * 2 + dy) * HPITCH + px * ROWB + kh * 16;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) b_off[t] = (wn * 64 + t * 32 + i) * ROWB + kh * 16;
+  float bv[2];
+#pragma unroll
+  for (int tn = 0; tn < 2; ++tn) bv[tn] = p.bias ? p.bias[ct * BN + wn * 64 + tn * 32 + i] : 0.f;
+  f32x16 accm[MT][2], accc[MT][2];
+#pragma unroll
+  for (int a = 0; a < MT; ++a)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { accm[a][c][r] = 0.f; accc[a][c][r] = 0.f; }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int j = 0; j < ALD; ++j) {
+    split_inplace(areg0[j], (a_valid >> j) & 1);
+    if (j + 1 < ALD || a_last) store_piece(areg0[j], j);
+  }
+
+  // one stage = kernel row KY of chunk c.  MODE 0: plain; 2 (last kernel row of a chunk): fetch, split and park the
+  // halo tile of chunk c+1; 3 (last stage of the tile): the same for chunk 0 of the NEXT tile (gin / a_gsafe already
+  // point there), and the weight DMA wraps to stage 0
+  float4 areg[ALD];
+  auto stage = [&](int c, auto KY_, auto MODE_) {
+    constexpr int ky = decltype(KY_)::value;
+    constexpr int MODE = decltype(MODE_)::value;
+    constexpr bool HANDOVER = MODE >= 2;
+    const int st = c * 3 + ky;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of W(st) has landed
+    __syncthreads();
+    int st_next = st + 1;
+    if constexpr (MODE == 3) {
+      // stage 0 again -- through an opaque zero, or the 15 per-lane DMA addresses of that stage become tile-loop
+      // invariants: 30 hoisted (and spilled) VGPRs whose reloads sit in front of the waits of this stage
+      st_next = 0;
+      asm volatile("" : "+s"(st_next));
+    }
+    const int buf_next = (st + 1) & 1;
+    const float* inc_ = MODE == 3 ? gin : gin + (c + 1) * KC;
+    const unsigned char* Arow = As + ky * HPITCH;
+    const unsigned char* Bst = Bs + (st & 1) * (3 * BN * ROWB);
+    half8 fa[2][2 * MT], fb[2][4];
+    auto load_frag = [&](int s_, half8* a, half8* bf) {
+      const unsigned char* Ap = Arow + (s_ >> 1) * ROWB + (s_ & 1) * 32;
+      const unsigned char* Bp = Bst + (s_ >> 1) * (BN * ROWB) + (s_ & 1) * 32;
+#pragma unroll
+      for (int t = 0; t < MT; ++t) {
+        a[2 * t] = *(const half8*)(Ap + a_off[t]);
+        a[2 * t + 1] = *(const half8*)(Ap + a_off[t] + 64);
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        bf[2 * t] = *(const half8*)(Bp + b_off[t]);
+        bf[2 * t + 1] = *(const half8*)(Bp + b_off[t] + 64);
+      }
+    };
+    load_frag(0, fa[0], fb[0]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s_ = 0; s_ < 6; ++s_) {
+      half8* a = fa[s_ & 1];
+      half8* bf = fb[s_ & 1];
+      if (s_ + 1 < 6) load_frag(s_ + 1, fa[(s_ + 1) & 1], fb[(s_ + 1) & 1]);
+      constexpr int DMA_J0[6] = {0, 3, 6, 9, 12, 15}, DMA_N[6] = {3, 3, 3, 3, 3, 0};
+      if (DMA_N[s_]) dma_w(st_next, buf_next, DMA_J0[s_], DMA_N[s_]);
+      int n_vmem = DMA_N[s_];
+      if constexpr (HANDOVER) {
+        if (s_ < 2) {
+#pragma unroll
+          for (int j = s_ * 6; j < (s_ ? ALD : 6); ++j) areg[j] = *(const float4*)(inc_ + a_gsafe[j]);
+          n_vmem += s_ ? ALD - 6 : 6;
+        } else if (s_ >= 4) {
+#pragma unroll
+          for (int j = (s_ - 4) * 6; j < (s_ == 5 ? ALD : 6); ++j) split_inplace(areg[j], (a_valid >> j) & 1);
+        }
+      }
+#pragma unroll
+      for (int tm = 0; tm < MT; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+          accm[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[2 * tm], bf[2 * tn], accm[tm][tn], 0, 0, 0);
+      if constexpr (NP >= 2) {
+#pragma unroll
+        for (int tm = 0; tm < MT; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < 2; ++tn)
+            accc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[2 * tm], bf[2 * tn + 1], accc[tm][tn], 0, 0, 0);
+      }
+      if constexpr (NP >= 3) {
+#pragma unroll
+        for (int tm = 0; tm < MT; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < 2; ++tn)
+            accc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[2 * tm + 1], bf[2 * tn], accc[tm][tn], 0, 0, 0);
+      }
+      if (s_ + 1 < 6) {
+#pragma unroll
+        for (int g = 0; g < 2 * MT + 4; ++g) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+#pragma unroll
+        for (int g = 0; g < 2 * NP * MT - (2 * MT + 4) - 3; ++g) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          if (g < n_vmem) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (HANDOVER) {
+      __syncthreads();  // every wave is done reading the halo tile (and, MODE 3, weight buffer 1)
+#pragma unroll
+      for (int j = 0; j < ALD; ++j)
+        if (j + 1 < ALD || a_last) store_piece(areg[j], j);
+    }
+  };
+  using std::integral_constant;
+  float amax = 0.f;  // fp16 range guard: largest |output| of this lane
+  float* Cs = (float*)(Bs + 3 * SLAB_B);  // weight buffer 1
+  const bool relu = (p.relu & 1) != 0;
+  const bool write_main = !(p.relu & 8), main_split = (p.relu & 32) != 0, pool_split = (p.relu & 64) != 0;
+#ifdef SHF_W4P_TIMING
+  unsigned long long tk = 0, tl0 = 0, tg = 0, tl12 = 0, te[4] = {0, 0, 0, 0}, m0, m1;
+  int ntl = 0;
+#define W4P_T(x) x = __builtin_amdgcn_s_memtime()
+#else
+#define W4P_T(x)
+#endif
+#pragma unroll 1
+  for (;;) {
+    W4P_T(m0);
+#pragma unroll 1
+    for (int c = 0; c + 1 < nchunks; ++c) {
+      stage(c, integral_constant<int, 0>{}, integral_constant<int, 0>{});
+      stage(c, integral_constant<int, 1>{}, integral_constant<int, 0>{});
+      stage(c, integral_constant<int, 2>{}, integral_constant<int, 2>{});
+    }
+    // (opaque: the peeled stages' weight-DMA addresses would otherwise be tile-loop invariants -- 45 hoisted VGPRs)
+    int c_last = nchunks - 1;
+    asm volatile("" : "+s"(c_last));
+#ifdef SHF_W4P_TIMING
+    W4P_T(m1); tk += m1 - m0; m0 = m1;
+#endif
+    stage(c_last, integral_constant<int, 0>{}, integral_constant<int, 0>{});
+#ifdef SHF_W4P_TIMING
+    W4P_T(m1); tl0 += m1 - m0; m0 = m1;
+#endif
+    // the current tile's input is fully in LDS: gin / a_gsafe / a_valid move on to the next tile
+    const int t_next = t_cur + G;
+    const bool has_next = t_next < p.ntile_blocks;
+    const Geo gn = geometry(has_next ? t_next : t_cur);
+    gin = gn.in;
+    halo_offsets(gn, has_next);
+#ifdef SHF_W4P_TIMING
+    W4P_T(m1); tg += m1 - m0; m0 = m1;
+#endif
+    stage(c_last, integral_constant<int, 1>{}, integral_constant<int, 0>{});
+    stage(c_last, integral_constant<int, 2>{}, integral_constant<int, 3>{});
+#ifdef SHF_W4P_TIMING
+    W4P_T(m1); tl12 += m1 - m0; m0 = m1; ++ntl;
+#endif
+
+    // epilogue in quarters through weight buffer 1; the accumulators of a quarter are cleared as soon as staged
+    int tid_e = tid;
+    asm volatile("" : "+v"(tid_e));  // (the flush's thread-derived indices are recomputed here, not carried through the K loop)
+#pragma unroll
+    for (int q = 0; q < MT; ++q) {
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn) {
+        const int cl = wn * 64 + tn * 32 + i;
+        if (relu)
+          conv_stage_tile_pk<BN, true>(Cs, accm[q][tn], accc[q][tn], LO_INV, bv[tn], wm * 2, kh, cl, amax);
+        else
+          conv_stage_tile_pk<BN, false>(Cs, accm[q][tn], accc[q][tn], LO_INV, bv[tn], wm * 2, kh, cl, amax);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { accm[q][tn][r] = 0.f; accc[q][tn][r] = 0.f; }
+      }
+      __syncthreads();
+      conv_flush_quarter<BN>(Cs, tid_e, q, go.ty0, go.tx0, go.H, go.W, go.b, ct * BN, go.out, p.out_stride, go.pool,
+                             p.pool_stride, write_main, main_split, pool_split);
+      if (q + 1 < MT) __syncthreads();  // (after the last quarter the next stage's barrier does it)
+#ifdef SHF_W4P_TIMING
+      W4P_T(m1); te[q] += m1 - m0; m0 = m1;
+#endif
+    }
+    if (!has_next) break;
+    t_cur = t_next;
+    go = gn;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last stage's (unused) weight re-fetch
+#ifdef SHF_W4P_TIMING
+  if (lane == 0 && wave == 0 && (blockIdx.x == 0 || blockIdx.x == 100))
+    printf("[w4p] blk%d tiles %d stages/tile %d: per tile cycles: chunks0..n-2 %llu | last ky0 %llu | geometry %llu | last ky1+ky2 %llu | "
+           "epilogue quarters %llu %llu %llu %llu\n", (int)blockIdx.x, ntl, NST, tk / ntl, tl0 / ntl, tg / ntl, tl12 / ntl, te[0] / ntl,
+           te[1] / ntl, te[2] / ntl, te[3] / ntl);
+#endif
+  conv_raise_range_flag(p.range_flag, amax);
 }
 
 // Producer / consumer variant of the fused first pair (conv1_1 -> conv1_2, Cin = Cout = 64).  With only
@@ -1152,6 +1523,12 @@ bool conv_f16x3_eligible(int Cin, int Cout, int k, int pad, int dil) {
 // 4-wave kernel: 16-row tiles (MT 4) or 8-row tiles (MT 2)?  A launch runs in ceil(blocks / CUs) rounds of one block
 // per CU; an 8-row block costs ~0.56 of a 16-row one (half the MFMAs, the same weight traffic per stage and the same
 // prologue / epilogue latencies).  SHF_F16X3_W4_MT = 2 / 4 forces the choice (experiments).
+// persistent 4-wave kernel for the 16-row launches (SHF_F16X3_W4P = 0 / 1)
+bool conv_f16x3_w4_persistent() {
+  static const int v = getenv("SHF_F16X3_W4P") ? atoi(getenv("SHF_F16X3_W4P")) : 0;
+  return v != 0;
+}
+
 static int w4_pick_mt(const ConvArgs* as, int n, int nct) {
   static const int forced = getenv("SHF_F16X3_W4_MT") ? atoi(getenv("SHF_F16X3_W4_MT")) : 0;
   if (forced == 2 || forced == 4) return forced;
@@ -1196,14 +1573,18 @@ static int launch_f16x3_t(const ConvArgs* as, int n, hipStream_t s) {
   p.b1 = a.b1;
   long long tiles = 0;
   bool vec_ok = !(getenv("SHF_CONV_SCALAR_EPILOGUE") && atoi(getenv("SHF_CONV_SCALAR_EPILOGUE")));
-  // tile height: 16 rows, or 8 for the 4-wave kernel when that quantises better on this chip (w4_pick_mt)
-  const bool w4_path = BN == 128 && !FUSE1 && DIL == 1 && KS == 3 && conv_f16x3_uses_w4(p.Cin);
-  const int mt = w4_path ? w4_pick_mt(as, n, p.nct) : 4;
-  const int th = 4 * mt;
   for (int i = 0; i < n; ++i) {
     const ConvArgs& q = as[i];
     vec_ok = vec_ok && (q.out.cstride % 4 == 0) && (q.out.coff % 4 == 0) && (((uintptr_t)q.out.p & 15) == 0) &&
              (!q.pool.p || ((q.pool.cstride % 4 == 0) && (q.pool.coff % 4 == 0) && (((uintptr_t)q.pool.p & 15) == 0)));
+  }
+  // tile height: 16 rows, or 8 for the 4-wave kernel when that quantises better on this chip (w4_pick_mt).  The 4-wave
+  // kernels write 16-byte pieces from registers: unaligned views go through the 8-wave kernel's scalar epilogue.
+  const bool w4_path = BN == 128 && !FUSE1 && DIL == 1 && KS == 3 && conv_f16x3_uses_w4(p.Cin) && (vec_ok || !F16X3_W4_REGEPI);
+  const int mt = w4_path ? w4_pick_mt(as, n, p.nct) : 4;
+  const int th = 4 * mt;
+  for (int i = 0; i < n; ++i) {
+    const ConvArgs& q = as[i];
     if (FUSE1 && !q.img) { set_error("conv f16x3: fused first layer needs the image pointer"); return -1; }
     if (q.in.C != p.Cin || q.out.C != p.Cout || q.in.cstride != p.in_stride || q.out.cstride != p.out_stride ||
         q.wsplit16 != a.wsplit16 || q.in_split != a.in_split || q.out_split != a.out_split ||
@@ -1250,6 +1631,30 @@ static int launch_f16x3_t(const ConvArgs* as, int n, hipStream_t s) {
     const size_t lds4 = std::max((size_t)(th + 2) * ((TW + 2) * ROWB + F16X3_W4_ROWPAD) + 2 * 3 * (size_t)BN * ROWB,
                                  (size_t)16 * th * (BN + CS_PAD) * sizeof(float));
     const dim3 grid((unsigned)(tiles * p.nct));
+    p.ntile_blocks = (int)(tiles * p.nct);
+    if (mt == 4 && vec_ok && conv_f16x3_w4_persistent()) {
+      // persistent form: one block per CU walks the tiles; the grid stays a multiple of the cout-tile count
+      static int cus = 0;
+      if (!cus) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 4)
+          cus = 256;
+      }
+      const int gmax = cus / p.nct * p.nct;
+      const dim3 gp((unsigned)std::min<long long>(tiles * p.nct, gmax));
+      const size_t ldsp = (size_t)(th + 2) * ((TW + 2) * ROWB + F16X3_W4_ROWPAD) + 2 * 3 * (size_t)BN * ROWB;
+#define SHF_W4P_LAUNCH(SPLIT)                                                                                           \
+      {                                                                                                                 \
+        if (a.nprod >= 3) hipLaunchKernelGGL((conv_mfma_f16x3_w4p_kernel<SPLIT, 4, 3>), gp, dim3(256), ldsp, s, p);      \
+        else if (a.nprod == 2) hipLaunchKernelGGL((conv_mfma_f16x3_w4p_kernel<SPLIT, 4, 2>), gp, dim3(256), ldsp, s, p); \
+        else hipLaunchKernelGGL((conv_mfma_f16x3_w4p_kernel<SPLIT, 4, 1>), gp, dim3(256), ldsp, s, p);                   \
+      }
+      if (a.in_split) SHF_W4P_LAUNCH(true)
+      else SHF_W4P_LAUNCH(false)
+#undef SHF_W4P_LAUNCH
+      SHF_HIP_OK(hipGetLastError());
+      return 0;
+    }
 #define SHF_W4_LAUNCH(SPLIT, MTV)                                                                                      \
     {                                                                                                                   \
       if (a.nprod >= 3) hipLaunchKernelGGL((conv_mfma_f16x3_w4_kernel<SPLIT, MTV, 3>), grid, dim3(256), lds4, s, p);     \
@@ -1309,6 +1714,11 @@ int conv_f16x3_init_attributes() {
   SHF_W4_ATTR(false, 4, 2) SHF_W4_ATTR(true, 4, 2) SHF_W4_ATTR(false, 2, 2) SHF_W4_ATTR(true, 2, 2)
   SHF_W4_ATTR(false, 4, 1) SHF_W4_ATTR(true, 4, 1) SHF_W4_ATTR(false, 2, 1) SHF_W4_ATTR(true, 2, 1)
 #undef SHF_W4_ATTR
+#define SHF_W4P_ATTR(SPLIT, NPV)                                                                       \
+  SHF_HIP_OK(hipFuncSetAttribute((const void*)conv_mfma_f16x3_w4p_kernel<SPLIT, 4, NPV>,                \
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  SHF_W4P_ATTR(false, 3) SHF_W4P_ATTR(true, 3) SHF_W4P_ATTR(false, 2) SHF_W4P_ATTR(true, 2) SHF_W4P_ATTR(false, 1) SHF_W4P_ATTR(true, 1)
+#undef SHF_W4P_ATTR
   SHF_HIP_OK(hipFuncSetAttribute((const void*)conv_mfma_f16x3_pc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                  160 * 1024));
   SHF_HIP_OK(hipFuncSetAttribute((const void*)conv_mfma_f16x3_kernel<64, false, 1, 3>,

@@ -61,6 +61,7 @@ int conv_init_attributes();
 bool conv_f16x3_eligible(int Cin, int Cout, int k, int pad, int dil);
 bool conv_f16x3_uses_pc();         // fused first pair: producer/consumer kernel (SHF_F16X3_PC=0 disables)
 bool conv_f16x3_uses_w4(int Cin);
+bool conv_f16x3_w4_persistent();  // 16-row launches of the 4-wave kernel in the persistent (block-walks-tiles) form
 int conv_f16x3_w4_mt(const ConvArgs* as, int n);  // 4-wave kernel: 16-row (4) or 8-row (2) tiles for this launch  // Cout % 128 == 0 layers: 4-wave (one per SIMD) kernel or the 8-wave one
 int conv_f16x3_init_attributes();
 int launch_conv_f16x3_group(const ConvArgs* as, int n, hipStream_t s);
