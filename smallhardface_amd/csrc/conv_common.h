@@ -388,12 +388,17 @@ __device__ __forceinline__ void conv_flush_quarter(const float* __restrict__ Cs,
 // clipped like Caffe's (pooling_layer.cu:24-27) by feeding -FLT_MAX for pixels outside the image.
 template <bool RELU>
 __device__ __forceinline__ void conv_epilogue_regs(const cs_f32x16 am, const cs_f32x16 ac, float inv, const float4* bias16,
-                                                   bool valid, float* __restrict__ pix_main, int cout16, bool main_split,
-                                                   float* __restrict__ pix_pool, bool pool_writer, bool pool_split,
-                                                   float& amax) {
+                                                   bool valid, bool interior, float* __restrict__ pix_main, int cout16,
+                                                   bool main_split, float* __restrict__ pix_pool, bool pool_writer,
+                                                   bool pool_split, float& amax) {
+  // `interior` (wave-uniform): every pixel of the block tile is inside the image -- no pooling window needs clipping
   float v[16];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) v[r] = __builtin_fmaf(ac[r], inv, am[r]);
+  for (int r = 0; r < 16; r += 2) {
+    const cs_f32x2 t = __builtin_elementwise_fma(cs_f32x2{ac[r], ac[r + 1]}, cs_f32x2{inv, inv}, cs_f32x2{am[r], am[r + 1]});
+    v[r] = t[0];
+    v[r + 1] = t[1];
+  }
 #pragma unroll
   for (int s = 0; s < 8; ++s) {
     const int x = (s & 3) + 4 * (s >> 2), y = x + 8;   // (0..3 <-> 8..11), (4..7 <-> 12..15)
@@ -405,9 +410,14 @@ __device__ __forceinline__ void conv_epilogue_regs(const cs_f32x16 am, const cs_
   float4 o[4];
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
-    o[g] = make_float4(v[ORD[g]] + bias16[g].x, v[ORD[g] + 1] + bias16[g].y, v[ORD[g] + 2] + bias16[g].z,
-                       v[ORD[g] + 3] + bias16[g].w);
-    if (RELU) o[g] = make_float4(fmaxf(o[g].x, 0.f), fmaxf(o[g].y, 0.f), fmaxf(o[g].z, 0.f), fmaxf(o[g].w, 0.f));
+    cs_f32x2 a = cs_f32x2{v[ORD[g]], v[ORD[g] + 1]} + cs_f32x2{bias16[g].x, bias16[g].y};
+    cs_f32x2 b = cs_f32x2{v[ORD[g] + 2], v[ORD[g] + 3]} + cs_f32x2{bias16[g].z, bias16[g].w};
+    o[g] = make_float4(a[0], a[1], b[0], b[1]);
+    if (RELU) {
+      // max(x, 0) on the bit patterns (signed): one v_max_i32 per value, no NaN-quieting pre-pass; -0 and negatives -> +0
+      auto relu1 = [](float x) { const int q = __builtin_bit_cast(int, x); return __builtin_bit_cast(float, q > 0 ? q : 0); };
+      o[g] = make_float4(relu1(o[g].x), relu1(o[g].y), relu1(o[g].z), relu1(o[g].w));
+    }
     amax = fmaxf(fmaxf(amax, fabsf(o[g].x)), fabsf(o[g].y));
     amax = fmaxf(fmaxf(amax, fabsf(o[g].z)), fabsf(o[g].w));
   }
@@ -421,16 +431,32 @@ __device__ __forceinline__ void conv_epilogue_regs(const cs_f32x16 am, const cs_
     }
   }
   if (pix_pool) {
-    auto quad_max = [&](float x) {
-      x = valid ? x : -3.402823466e+38f;
-      int xi = __builtin_bit_cast(int, x);
-      x = fmaxf(x, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(xi, xi, 0xB1, 0xf, 0xf, false)));  // quad_perm [1,0,3,2]
-      xi = __builtin_bit_cast(int, x);
-      return fmaxf(x, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(xi, xi, 0x4E, 0xf, 0xf, false)));  // [2,3,0,1]
-    };
     float4 m[4];
+    if (RELU) {
+      // values are >= 0: their bit patterns order like unsigned integers, 0 is the neutral element for pixels outside
+      // the image, and the quad max is two v_max_u32 with a DPP operand each
+      auto quad_max = [&](float x) {
+        unsigned u = __builtin_bit_cast(unsigned, x);
+        if (!interior) u = valid ? u : 0u;
+        unsigned w = (unsigned)__builtin_amdgcn_mov_dpp((int)u, 0xB1, 0xf, 0xf, true);  // quad_perm [1,0,3,2]
+        u = u > w ? u : w;
+        w = (unsigned)__builtin_amdgcn_mov_dpp((int)u, 0x4E, 0xf, 0xf, true);           // quad_perm [2,3,0,1]
+        u = u > w ? u : w;
+        return __builtin_bit_cast(float, u);
+      };
 #pragma unroll
-    for (int g = 0; g < 4; ++g) m[g] = make_float4(quad_max(o[g].x), quad_max(o[g].y), quad_max(o[g].z), quad_max(o[g].w));
+      for (int g = 0; g < 4; ++g) m[g] = make_float4(quad_max(o[g].x), quad_max(o[g].y), quad_max(o[g].z), quad_max(o[g].w));
+    } else {
+      auto quad_max = [&](float x) {
+        x = valid ? x : -3.402823466e+38f;
+        int xi = __builtin_bit_cast(int, x);
+        x = fmaxf(x, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(xi, xi, 0xB1, 0xf, 0xf, false)));
+        xi = __builtin_bit_cast(int, x);
+        return fmaxf(x, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(xi, xi, 0x4E, 0xf, 0xf, false)));
+      };
+#pragma unroll
+      for (int g = 0; g < 4; ++g) m[g] = make_float4(quad_max(o[g].x), quad_max(o[g].y), quad_max(o[g].z), quad_max(o[g].w));
+    }
     if (pool_writer) {
       if (pool_split) {
         conv_store_split8(pix_pool, cout16, m[0], m[1]);

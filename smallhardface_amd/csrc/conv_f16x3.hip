@@ -478,6 +478,7 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4_kernel(ConvK p) {
   constexpr int HPITCH = HTW * ROWB + F16X3_W4_ROWPAD;  // bytes per halo-tile row
   unsigned char* As = smem;                    // [HTH][HPITCH]: pixel (hy, hx) at hy * HPITCH + hx * ROWB
   unsigned char* Bs = smem + HTH * HPITCH;     // [2][3][BN][ROWB]
+  float* biasL = (float*)(Bs + 2 * 3 * BN * ROWB);  // [BN] this block's biases (register epilogue: read back as 8 ds_read_b128)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wn = wave & 1, wm = wave >> 1;
@@ -504,7 +505,7 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4_kernel(ConvK p) {
   // Pieces are fetched unconditionally -- out-of-image lanes read the member's first pixel and are
   // zeroed afterwards (bit j of a_valid) -- because predicated loads would split the MFMA
   // scheduling region into basic blocks.
-  int a_gsafe[ALD];
+  unsigned a_gsafe[ALD];  // BYTE offsets (unsigned: scalar base + 32-bit lane offset addressing, no 64-bit lane math)
   unsigned a_valid = 0;
   const int a_loff0 = (tid >> 3) * ROWB + (tid & 7) * 8;
   const bool a_last = tid + NT * (ALD - 1) < HP * 8;  // the ragged last piece exists for this thread
@@ -515,7 +516,7 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4_kernel(ConvK p) {
     const int hy = hp / HTW, hx = hp - hy * HTW;
     const int gy = ty0 - 1 + hy, gx = tx0 - 1 + hx;
     const bool in = (idx < HP * 8) && ((unsigned)gy < (unsigned)H) && ((unsigned)gx < (unsigned)W);
-    a_gsafe[j] = in ? ((b * H + gy) * W + gx) * p.in_stride + q * 4 : 0;
+    a_gsafe[j] = in ? (unsigned)(((b * H + gy) * W + gx) * p.in_stride + q * 4) * 4u : 0u;
     a_valid |= in ? (1u << j) : 0u;
   }
   // fp32 piece -> [hi half4 | lo half4] in the same four registers
@@ -587,7 +588,10 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4_kernel(ConvK p) {
 #else
   dma_w(0, 0, 0, DMA_ROUNDS_W4);
 #pragma unroll
-  for (int j = 0; j < ALD; ++j) areg0[j] = *(const float4*)(gin + a_gsafe[j]);
+  for (int j = 0; j < ALD; ++j) areg0[j] = *(const float4*)((const char*)gin + a_gsafe[j]);
+#endif
+#if F16X3_W4_REGEPI
+  if (tid < BN) biasL[tid] = p.bias ? p.bias[ct * BN + tid] : 0.f;  // (visible after the first stage barrier)
 #endif
 
   const int i = lane & 31, kh = lane >> 5;
@@ -672,7 +676,7 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4_kernel(ConvK p) {
       if constexpr (PREFETCH) {  // a whole stage of slack before the first use
         if (s_ >= 3 && s_ < 5) {
 #pragma unroll
-          for (int j = (s_ - 3) * 6; j < (s_ == 4 ? ALD : 6); ++j) areg[j] = *(const float4*)(inc_ + a_gsafe[j]);
+          for (int j = (s_ - 3) * 6; j < (s_ == 4 ? ALD : 6); ++j) areg[j] = *(const float4*)((const char*)inc_ + a_gsafe[j]);
           n_vmem += s_ == 4 ? ALD - 6 : 6;
         }
       }
@@ -684,7 +688,7 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4_kernel(ConvK p) {
       if constexpr (HANDOVER) {
         if (s_ < 2) {
 #pragma unroll
-          for (int j = s_ * 6; j < (s_ ? ALD : 6); ++j) areg[j] = *(const float4*)(inc_ + a_gsafe[j]);
+          for (int j = s_ * 6; j < (s_ ? ALD : 6); ++j) areg[j] = *(const float4*)((const char*)inc_ + a_gsafe[j]);
           n_vmem += s_ ? ALD - 6 : 6;
         } else if (s_ >= 4) {  // as late as possible: the loads get three k-steps to come back
 #pragma unroll
@@ -773,27 +777,32 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4_kernel(ConvK p) {
   {
     const bool relu = (p.relu & 1) != 0, write_main = !(p.relu & 8), main_split = (p.relu & 32) != 0,
                pool_split = (p.relu & 64) != 0;
+    // (opaque copies: what is derived from them is computed HERE -- hipcc otherwise forms the lane's 64-bit channel
+    // offset before the K loop, spills it, and reloads it once per accumulator tile behind the stores already issued)
+    int px_e = px, dy_e = dy, kh_e = kh, i_e = i;
+    asm volatile("" : "+v"(px_e), "+v"(dy_e), "+v"(kh_e), "+v"(i_e));
     const int Hp = (H + 1) >> 1, Wp = (W + 1) >> 1;
-    const int x = tx0 + px;
+    const bool interior = ty0 + TH <= H && tx0 + TW <= W;
+    const int x = tx0 + px_e;
+    float4 bias16[2][4];  // both cout tiles' biases up front: no lane address is carried across the stores
+#pragma unroll
+    for (int g = 0; g < 8; ++g)
+      bias16[g >> 2][g & 3] = *(const float4*)(biasL + wn * 64 + (g >> 2) * 32 + kh_e * 16 + 4 * (g & 3));
 #pragma unroll
     for (int tn = 0; tn < 2; ++tn) {
-      const int cout16 = ct * BN + wn * 64 + tn * 32 + kh * 16;
-      float4 bias16[4];
-#pragma unroll
-      for (int g = 0; g < 4; ++g)
-        bias16[g] = p.bias ? *(const float4*)(p.bias + cout16 + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const int cout16 = ct * BN + wn * 64 + tn * 32 + kh_e * 16;
 #pragma unroll
       for (int tm = 0; tm < MT; ++tm) {
-        const int y = ty0 + wm * 2 * MT + tm * 2 + dy;
+        const int y = ty0 + wm * 2 * MT + tm * 2 + dy_e;
         const bool valid = y < H && x < W;
         float* pm = write_main ? gout + ((size_t)(b * H + y) * W + x) * p.out_stride : nullptr;
         float* pp = mem.pool ? mem.pool + ((size_t)(b * Hp + (y >> 1)) * Wp + (x >> 1)) * p.pool_stride : nullptr;
         if (relu)
-          conv_epilogue_regs<true>(accm[tm][tn], accc[tm][tn], LO_INV, bias16, valid, pm, cout16, main_split, pp,
-                                   valid && (i & 3) == 0, pool_split, amax);
+          conv_epilogue_regs<true>(accm[tm][tn], accc[tm][tn], LO_INV, bias16[tn], valid, interior, pm, cout16, main_split, pp,
+                                   valid && (i_e & 3) == 0, pool_split, amax);
         else
-          conv_epilogue_regs<false>(accm[tm][tn], accc[tm][tn], LO_INV, bias16, valid, pm, cout16, main_split, pp,
-                                    valid && (i & 3) == 0, pool_split, amax);
+          conv_epilogue_regs<false>(accm[tm][tn], accc[tm][tn], LO_INV, bias16[tn], valid, interior, pm, cout16, main_split, pp,
+                                    valid && (i_e & 3) == 0, pool_split, amax);
       }
     }
   }
@@ -883,6 +892,7 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4p_kernel(ConvK p) {
   constexpr int HPITCH = HTW * ROWB + F16X3_W4_ROWPAD;
   unsigned char* As = smem;                    // [HTH][HPITCH]
   unsigned char* Bs = smem + HTH * HPITCH;     // [2][3][BN][ROWB]
+  float* biasL = (float*)(Bs + 2 * 3 * BN * ROWB);  // [BN] this block's biases
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wn = wave & 1, wm = wave >> 1;
@@ -914,7 +924,7 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4p_kernel(ConvK p) {
   };
   // halo piece j of this thread: float4 q of halo pixel hp0 + 32 j.  Out-of-image pieces read the member's first
   // pixel and are zeroed afterwards (bit j of a_valid).  exists = false: a block without a next tile fetches nothing real.
-  int a_gsafe[ALD];
+  unsigned a_gsafe[ALD];  // BYTE offsets (unsigned: scalar base + 32-bit lane offset addressing, no 64-bit lane math)
   unsigned a_valid = 0;
   auto halo_offsets = [&](const Geo& g, bool exists) {
     int tid_o = tid;
@@ -927,7 +937,7 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4p_kernel(ConvK p) {
       const int hy = hp / HTW, hx = hp - hy * HTW;
       const int gy = g.ty0 - 1 + hy, gx = g.tx0 - 1 + hx;
       const bool in = exists && (idx < HP * 8) && ((unsigned)gy < (unsigned)g.H) && ((unsigned)gx < (unsigned)g.W);
-      a_gsafe[j] = in ? ((g.b * g.H + gy) * g.W + gx) * p.in_stride + q * 4 : 0;
+      a_gsafe[j] = in ? (unsigned)(((g.b * g.H + gy) * g.W + gx) * p.in_stride + q * 4) * 4u : 0u;
       a_valid |= in ? (1u << j) : 0u;
     }
   };
@@ -979,7 +989,8 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4p_kernel(ConvK p) {
   float4 areg0[ALD];
   dma_w(0, 0, 0, DMA_ROUNDS_W4);
 #pragma unroll
-  for (int j = 0; j < ALD; ++j) areg0[j] = *(const float4*)(gin + a_gsafe[j]);
+  for (int j = 0; j < ALD; ++j) areg0[j] = *(const float4*)((const char*)gin + a_gsafe[j]);
+  if (tid < BN) biasL[tid] = p.bias ? p.bias[ct * BN + tid] : 0.f;  // (visible after the first stage barrier)
 
   const int i = lane & 31, kh = lane >> 5;
   int dy, px;
@@ -989,9 +1000,6 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4p_kernel(ConvK p) {
   for (int t = 0; t < MT; ++t) a_off[t] = (wm * 2 * MT + t * 2 + dy) * HPITCH + px * ROWB + kh * 16;
 #pragma unroll
   for (int t = 0; t < 2; ++t) b_off[t] = (wn * 64 + t * 32 + i) * ROWB + kh * 16;
-  float bv[2];
-#pragma unroll
-  for (int tn = 0; tn < 2; ++tn) bv[tn] = p.bias ? p.bias[ct * BN + wn * 64 + tn * 32 + i] : 0.f;
   f32x16 accm[MT][2], accc[MT][2];
 #pragma unroll
   for (int a = 0; a < MT; ++a)
@@ -1010,12 +1018,14 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4p_kernel(ConvK p) {
   // halo tile of chunk c+1; 3 (last stage of the tile): the same for chunk 0 of the NEXT tile (gin / a_gsafe already
   // point there), and the weight DMA wraps to stage 0
   float4 areg[ALD];
-  auto stage = [&](int c, auto KY_, auto MODE_) {
+  auto stage = [&](int c, auto KY_, auto MODE_, bool w0_waited = false) {
     constexpr int ky = decltype(KY_)::value;
     constexpr int MODE = decltype(MODE_)::value;
     constexpr bool HANDOVER = MODE >= 2;
     const int st = c * 3 + ky;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of W(st) has landed
+    // this wave's share of W(st) has landed (w0_waited, wave-uniform: the first stage of a tile after the block's
+    // first -- W(0) was waited for before the epilogue's stores went out)
+    if (!w0_waited) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     int st_next = st + 1;
     if constexpr (MODE == 3) {
@@ -1050,13 +1060,15 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4p_kernel(ConvK p) {
       half8* a = fa[s_ & 1];
       half8* bf = fb[s_ & 1];
       if (s_ + 1 < 6) load_frag(s_ + 1, fa[(s_ + 1) & 1], fb[(s_ + 1) & 1]);
-      constexpr int DMA_J0[6] = {0, 3, 6, 9, 12, 15}, DMA_N[6] = {3, 3, 3, 3, 3, 0};
+      // (the tile's last stage front-loads its weight DMA: W(0) of the next tile is waited for right after this stage)
+      constexpr int DMA_J0[6] = {0, MODE == 3 ? 5 : 3, MODE == 3 ? 10 : 6, MODE == 3 ? 15 : 9, MODE == 3 ? 15 : 12, 15};
+      constexpr int DMA_N[6] = {MODE == 3 ? 5 : 3, MODE == 3 ? 5 : 3, MODE == 3 ? 5 : 3, MODE == 3 ? 0 : 3, MODE == 3 ? 0 : 3, 0};
       if (DMA_N[s_]) dma_w(st_next, buf_next, DMA_J0[s_], DMA_N[s_]);
       int n_vmem = DMA_N[s_];
       if constexpr (HANDOVER) {
         if (s_ < 2) {
 #pragma unroll
-          for (int j = s_ * 6; j < (s_ ? ALD : 6); ++j) areg[j] = *(const float4*)(inc_ + a_gsafe[j]);
+          for (int j = s_ * 6; j < (s_ ? ALD : 6); ++j) areg[j] = *(const float4*)((const char*)inc_ + a_gsafe[j]);
           n_vmem += s_ ? ALD - 6 : 6;
         } else if (s_ >= 4) {
 #pragma unroll
@@ -1067,20 +1079,20 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4p_kernel(ConvK p) {
       for (int tm = 0; tm < MT; ++tm)
 #pragma unroll
         for (int tn = 0; tn < 2; ++tn)
-          accm[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[2 * tm], bf[2 * tn], accm[tm][tn], 0, 0, 0);
+          accm[tm][tn] = W4_MFMA(a[2 * tm], bf[2 * tn], accm[tm][tn]);
       if constexpr (NP >= 2) {
 #pragma unroll
         for (int tm = 0; tm < MT; ++tm)
 #pragma unroll
           for (int tn = 0; tn < 2; ++tn)
-            accc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[2 * tm], bf[2 * tn + 1], accc[tm][tn], 0, 0, 0);
+            accc[tm][tn] = W4_MFMA(a[2 * tm], bf[2 * tn + 1], accc[tm][tn]);
       }
       if constexpr (NP >= 3) {
 #pragma unroll
         for (int tm = 0; tm < MT; ++tm)
 #pragma unroll
           for (int tn = 0; tn < 2; ++tn)
-            accc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[2 * tm + 1], bf[2 * tn], accc[tm][tn], 0, 0, 0);
+            accc[tm][tn] = W4_MFMA(a[2 * tm + 1], bf[2 * tn], accc[tm][tn]);
       }
       if (s_ + 1 < 6) {
 #pragma unroll
@@ -1105,7 +1117,6 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4p_kernel(ConvK p) {
   };
   using std::integral_constant;
   float amax = 0.f;  // fp16 range guard: largest |output| of this lane
-  float* Cs = (float*)(Bs + 3 * SLAB_B);  // weight buffer 1
   const bool relu = (p.relu & 1) != 0;
   const bool write_main = !(p.relu & 8), main_split = (p.relu & 32) != 0, pool_split = (p.relu & 64) != 0;
 #ifdef SHF_W4P_TIMING
@@ -1118,9 +1129,14 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4p_kernel(ConvK p) {
 #pragma unroll 1
   for (;;) {
     W4P_T(m0);
+    // the next tile's geometry (scalar loads + two integer divisions: ~2 k cycles of dependent latency) is requested
+    // here, a whole K loop before its first use
+    const int t_next = t_cur + G;
+    const bool has_next = t_next < p.ntile_blocks;
+    const Geo gn = geometry(has_next ? t_next : t_cur);
 #pragma unroll 1
     for (int c = 0; c + 1 < nchunks; ++c) {
-      stage(c, integral_constant<int, 0>{}, integral_constant<int, 0>{});
+      stage(c, integral_constant<int, 0>{}, integral_constant<int, 0>{}, c == 0 && t_cur != (int)blockIdx.x);
       stage(c, integral_constant<int, 1>{}, integral_constant<int, 0>{});
       stage(c, integral_constant<int, 2>{}, integral_constant<int, 2>{});
     }
@@ -1135,9 +1151,6 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4p_kernel(ConvK p) {
     W4P_T(m1); tl0 += m1 - m0; m0 = m1;
 #endif
     // the current tile's input is fully in LDS: gin / a_gsafe / a_valid move on to the next tile
-    const int t_next = t_cur + G;
-    const bool has_next = t_next < p.ntile_blocks;
-    const Geo gn = geometry(has_next ? t_next : t_cur);
     gin = gn.in;
     halo_offsets(gn, has_next);
 #ifdef SHF_W4P_TIMING
@@ -1149,29 +1162,51 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4p_kernel(ConvK p) {
     W4P_T(m1); tl12 += m1 - m0; m0 = m1; ++ntl;
 #endif
 
-    // epilogue in quarters through weight buffer 1; the accumulators of a quarter are cleared as soon as staged
-    int tid_e = tid;
-    asm volatile("" : "+v"(tid_e));  // (the flush's thread-derived indices are recomputed here, not carried through the K loop)
+    // register epilogue (conv_common.h): no LDS, no barrier -- the halo tile and W(0) of the next tile stay untouched.
+    // This wave's share of W(0) is waited for HERE, before the stores go out: the next tile's first stage then needs
+    // no vmcnt(0), which would sit behind these stores.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef SHF_W4P_TIMING
+    W4P_T(m1); te[1] += m1 - m0; m0 = m1;
+#endif
+    {
+      // (opaque copies: the pixel / cout byte offsets derived from them are tile-invariant 64-bit values that would
+      // otherwise live -- spilled -- across the K loop, and every reload here waits behind the stores already issued)
+      int px_e = px, dy_e = dy, kh_e = kh, i_e = i;
+      asm volatile("" : "+v"(px_e), "+v"(dy_e), "+v"(kh_e), "+v"(i_e));
+      const int Hp = (go.H + 1) >> 1, Wp = (go.W + 1) >> 1;
+      const bool interior = go.ty0 + TH <= go.H && go.tx0 + TW <= go.W;
+      const int x = go.tx0 + px_e;
+      float4 bias16[2][4];  // both cout tiles' biases up front: no lane address is carried across the stores
 #pragma unroll
-    for (int q = 0; q < MT; ++q) {
+      for (int g = 0; g < 8; ++g)
+        bias16[g >> 2][g & 3] = *(const float4*)(biasL + wn * 64 + (g >> 2) * 32 + kh_e * 16 + 4 * (g & 3));
 #pragma unroll
       for (int tn = 0; tn < 2; ++tn) {
-        const int cl = wn * 64 + tn * 32 + i;
-        if (relu)
-          conv_stage_tile_pk<BN, true>(Cs, accm[q][tn], accc[q][tn], LO_INV, bv[tn], wm * 2, kh, cl, amax);
-        else
-          conv_stage_tile_pk<BN, false>(Cs, accm[q][tn], accc[q][tn], LO_INV, bv[tn], wm * 2, kh, cl, amax);
+        const int cout16 = ct * BN + wn * 64 + tn * 32 + kh_e * 16;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { accm[q][tn][r] = 0.f; accc[q][tn][r] = 0.f; }
-      }
-      __syncthreads();
-      conv_flush_quarter<BN>(Cs, tid_e, q, go.ty0, go.tx0, go.H, go.W, go.b, ct * BN, go.out, p.out_stride, go.pool,
-                             p.pool_stride, write_main, main_split, pool_split);
-      if (q + 1 < MT) __syncthreads();  // (after the last quarter the next stage's barrier does it)
+        for (int tm = 0; tm < MT; ++tm) {
+          const int y = go.ty0 + wm * 2 * MT + tm * 2 + dy_e;
+          const bool valid = y < go.H && x < go.W;
+          float* pm = write_main ? go.out + ((size_t)(go.b * go.H + y) * go.W + x) * p.out_stride : nullptr;
+          float* pp = go.pool ? go.pool + ((size_t)(go.b * Hp + (y >> 1)) * Wp + (x >> 1)) * p.pool_stride : nullptr;
+          if (relu)
+            conv_epilogue_regs<true>(accm[tm][tn], accc[tm][tn], LO_INV, bias16[tn], valid, interior, pm, cout16, main_split, pp,
+                                     valid && (i_e & 3) == 0, pool_split, amax);
+          else
+            conv_epilogue_regs<false>(accm[tm][tn], accc[tm][tn], LO_INV, bias16[tn], valid, interior, pm, cout16, main_split, pp,
+                                      valid && (i_e & 3) == 0, pool_split, amax);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { accm[tm][tn][r] = 0.f; accc[tm][tn][r] = 0.f; }
+        }
 #ifdef SHF_W4P_TIMING
-      W4P_T(m1); te[q] += m1 - m0; m0 = m1;
+        W4P_T(m1); te[2 + tn] += m1 - m0; m0 = m1;
 #endif
+      }
     }
+#ifdef SHF_W4P_TIMING
+    W4P_T(m1); te[0] += m1 - m0; m0 = m1;
+#endif
     if (!has_next) break;
     t_cur = t_next;
     go = gn;
@@ -1628,8 +1663,8 @@ static int launch_f16x3_t(const ConvArgs* as, int n, hipStream_t s) {
     hipLaunchKernelGGL(conv_mfma_f16x3_pc_kernel, dim3((unsigned)tiles), dim3(512), lds_pc, s, p);
   }
   else if (w4_path) {
-    const size_t lds4 = std::max((size_t)(th + 2) * ((TW + 2) * ROWB + F16X3_W4_ROWPAD) + 2 * 3 * (size_t)BN * ROWB,
-                                 (size_t)16 * th * (BN + CS_PAD) * sizeof(float));
+    const size_t lds4 = std::max((size_t)(th + 2) * ((TW + 2) * ROWB + F16X3_W4_ROWPAD) + 2 * 3 * (size_t)BN * ROWB + BN * sizeof(float),
+                                 F16X3_W4_REGEPI ? (size_t)0 : (size_t)16 * th * (BN + CS_PAD) * sizeof(float));
     const dim3 grid((unsigned)(tiles * p.nct));
     p.ntile_blocks = (int)(tiles * p.nct);
     if (mt == 4 && vec_ok && conv_f16x3_w4_persistent()) {
@@ -1642,7 +1677,7 @@ static int launch_f16x3_t(const ConvArgs* as, int n, hipStream_t s) {
       }
       const int gmax = cus / p.nct * p.nct;
       const dim3 gp((unsigned)std::min<long long>(tiles * p.nct, gmax));
-      const size_t ldsp = (size_t)(th + 2) * ((TW + 2) * ROWB + F16X3_W4_ROWPAD) + 2 * 3 * (size_t)BN * ROWB;
+      const size_t ldsp = (size_t)(th + 2) * ((TW + 2) * ROWB + F16X3_W4_ROWPAD) + 2 * 3 * (size_t)BN * ROWB + BN * sizeof(float);
 #define SHF_W4P_LAUNCH(SPLIT)                                                                                           \
       {                                                                                                                 \
         if (a.nprod >= 3) hipLaunchKernelGGL((conv_mfma_f16x3_w4p_kernel<SPLIT, 4, 3>), gp, dim3(256), ldsp, s, p);      \
