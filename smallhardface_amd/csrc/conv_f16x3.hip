@@ -19,6 +19,10 @@
 // STAGE is one kernel row (3 taps) of one 32-channel chunk: its three BNx32 weight slabs are double-buffered in
 // LDS and arrive by LDS DMA; the 18x18x32 halo tile is staged once per chunk and reused by all 9 taps.  LDS rows
 // are [hi: 32 halfs][lo: 32 halfs][16 B pad] = 144 B (conflict-free ds_read_b128 over consecutive rows).
+// Epilogues: the 4-wave kernels run the MFMA as D[cout][pixel] and store from registers (conv_epilogue_regs); the
+// 8-wave and fused-pair kernels run D[pixel][cout] and transpose the tile through LDS (conv_stage_tile / conv_flush_tile).
+// conv_mfma_f16x3_w4p_kernel is the persistent (block walks tiles) form of the 4-wave kernel: off by default
+// (SHF_F16X3_W4P=1), see DESIGN.md for why it does not pay.
 #include <algorithm>
 #include <cstdint>
 #include <cstdio>
