@@ -1,6 +1,8 @@
-"""Hash of the kernel sources: ties a committed PMC summary (profiles/*.json) to the code it was measured on."""
+"""Hash of the kernel sources: ties a committed PMC summary (profiles/*.json) to the code it was measured on.
+Comments and white space do not count (a reworded comment does not invalidate a counter run)."""
 import hashlib
 import os
+import re
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FILES = ["conv.hip", "conv_f16x3.hip", "conv_common.h", "misc.hip", "tail.hip", "merge.hip", "pre.hip", "shf_internal.h"]
@@ -10,7 +12,11 @@ def kernel_source_hash():
     h = hashlib.sha256()
     for f in FILES:
         with open(os.path.join(ROOT, "smallhardface_amd", "csrc", f), "rb") as fh:
-            h.update(f.encode() + b"\0" + fh.read())
+            src = fh.read().decode("utf-8", "replace")
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        src = re.sub(r"//[^\n]*", "", src)
+        src = re.sub(r"\s+", " ", src)
+        h.update(f.encode() + b"\0" + src.encode())
     return h.hexdigest()[:16]
 
 
