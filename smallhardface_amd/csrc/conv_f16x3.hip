@@ -63,6 +63,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #else
 #define W4_MFMA(px, wt, acc) __builtin_amdgcn_mfma_f32_32x32x16_f16(px, wt, acc, 0, 0, 0)
 #endif
+#ifndef F16X3_W4_HALO_STEP0
+#define F16X3_W4_HALO_STEP0 6
+#endif
 #ifndef F16X3_CONV_MID
 #define F16X3_CONV_MID 1   // 1: split the next halo tile to fp16 hi/lo in the middle of the last stage's MFMAs
 #endif
@@ -690,10 +693,11 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4_kernel(ConvK p) {
       }
 #else
       if constexpr (HANDOVER) {
+        constexpr int HL0 = F16X3_W4_HALO_STEP0;  // halo pieces requested in k-step 0 (the rest in k-step 1)
         if (s_ < 2) {
 #pragma unroll
-          for (int j = s_ * 6; j < (s_ ? ALD : 6); ++j) areg[j] = *(const float4*)((const char*)inc_ + a_gsafe[j]);
-          n_vmem += s_ ? ALD - 6 : 6;
+          for (int j = s_ * HL0; j < (s_ ? ALD : HL0); ++j) areg[j] = *(const float4*)((const char*)inc_ + a_gsafe[j]);
+          n_vmem += s_ ? ALD - HL0 : HL0;
         } else if (s_ >= 4) {  // as late as possible: the loads get three k-steps to come back
 #pragma unroll
           for (int j = (s_ - 4) * 6; j < (s_ == 5 ? ALD : 6); ++j) split_inplace(areg[j], (a_valid >> j) & 1);

@@ -435,7 +435,7 @@ def test_device_preprocessing_feeds_the_detector():
 def test_kernel_selection_knobs_do_not_change_results(tmp_path, conv_mode):
     """Every kernel-selection / data-format knob of the split-fp16 path is a pure performance choice: the
     detections of the fused path are bit-identical with the 4-wave kernel, the producer/consumer first pair,
-    the split activation format and the logits-first tail schedule switched off one at a time... except the
+    the split activation format switched off one at a time and with the persistent 4-wave kernel... except the
     first pair, whose conv1_1 runs on the matrix cores instead of the vector ALUs (tolerance)."""
     if conv_mode != "f16x3":
         pytest.skip("split-fp16 knobs")
@@ -460,7 +460,7 @@ np.save(sys.argv[1], fd.detect(list(T.pyramid_units(im)), thresh=0.05)[0])
     outs = {}
     for name, env in (("default", {}), ("no_split_act", {"SHF_F16X3_SPLIT_ACT": "0"}), ("no_w4", {"SHF_F16X3_W4": "0"}),
                       ("scalar_epilogue", {"SHF_CONV_SCALAR_EPILOGUE": "1", "SHF_F16X3_SPLIT_ACT": "0"}),
-                      ("no_pc", {"SHF_F16X3_PC": "0"})):
+                      ("persistent_w4", {"SHF_F16X3_W4P": "1"}), ("no_pc", {"SHF_F16X3_PC": "0"})):
         out = str(tmp_path / (name + ".npy"))
         e = dict(os.environ, PYTHONPATH=root, **env)
         r = subprocess.run([sys.executable, str(script), out], env=e, cwd=root, capture_output=True, text=True, timeout=600)
@@ -468,7 +468,8 @@ np.save(sys.argv[1], fd.detect(list(T.pyramid_units(im)), thresh=0.05)[0])
         outs[name] = np.load(out)
     assert len(outs["default"]) > 0
     # (the scalar epilogue also rules the producer/consumer first pair out: its twin is "no_pc")
-    bad = [(name, ref) for name, ref in (("no_split_act", "default"), ("no_w4", "default"), ("scalar_epilogue", "no_pc"))
+    bad = [(name, ref) for name, ref in (("no_split_act", "default"), ("no_w4", "default"), ("persistent_w4", "default"),
+                                         ("scalar_epilogue", "no_pc"))
            if outs[name].shape != outs[ref].shape or not np.array_equal(outs[name], outs[ref])]
     assert not bad, bad
     a, b = outs["default"], outs["no_pc"]
