@@ -66,6 +66,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef F16X3_W4_HALO_STEP0
 #define F16X3_W4_HALO_STEP0 6
 #endif
+#ifndef F16X3_W4_DMA_SCHED_MT2
+#define F16X3_W4_DMA_SCHED_MT2 1   // 8-row tiles: weight-DMA rounds per k-step (see the stage body)
+#endif
 #ifndef F16X3_CONV_MID
 #define F16X3_CONV_MID 1   // 1: split the next halo tile to fp16 hi/lo in the middle of the last stage's MFMAs
 #endif
@@ -674,7 +677,13 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4_kernel(ConvK p) {
       half8* bf = fb[s_ & 1];
       if (s_ + 1 < 6) load_frag(s_ + 1, fa[(s_ + 1) & 1], fb[(s_ + 1) & 1]);
       // the stage's side jobs ride under the MFMAs, a few per k-step so that no queue ever fills
-      constexpr int DMA_J0[6] = {0, 3, 6, 9, 12, 15}, DMA_N[6] = {3, 3, 3, 3, 3, 0};
+      // 16-row tiles: 3 rounds per k-step; the 8-row tiles' stage is half as long and its weights are late more often:
+      // front-loaded (F16X3_W4_DMA_SCHED_MT2: 1 = 4,4,4,3,0,0; 3 = 5,5,5,0,0,0; 4 = 8,7,0,0,0,0)
+      constexpr int SCH = MT == 2 ? F16X3_W4_DMA_SCHED_MT2 : 0;
+      constexpr int DMA_N[6] = {SCH == 4 ? 8 : SCH == 3 ? 5 : SCH == 1 ? 4 : 3, SCH == 4 ? 7 : SCH == 3 ? 5 : SCH == 1 ? 4 : 3,
+                                SCH == 4 ? 0 : SCH == 3 ? 5 : SCH == 1 ? 4 : 3, SCH >= 3 ? 0 : 3, SCH >= 1 ? 0 : 3, 0};
+      constexpr int DMA_J0[6] = {0, DMA_N[0], DMA_N[0] + DMA_N[1], DMA_N[0] + DMA_N[1] + DMA_N[2],
+                                 DMA_N[0] + DMA_N[1] + DMA_N[2] + DMA_N[3], 15};
 #ifndef F16X3_EXPERIMENT_NO_DMA  // timing experiment only (stale weights): what the in-loop DMA issue costs
       if (DMA_N[s_]) dma_w(st_next, buf_next, DMA_J0[s_], DMA_N[s_]);
 #endif
