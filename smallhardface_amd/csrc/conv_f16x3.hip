@@ -1632,7 +1632,12 @@ static int launch_f16x3_t(const ConvArgs* as, int n, hipStream_t s) {
   }
   // tile height: 16 rows, or 8 for the 4-wave kernel when that quantises better on this chip (w4_pick_mt).  The 4-wave
   // kernels write 16-byte pieces from registers: unaligned views go through the 8-wave kernel's scalar epilogue.
-  const bool w4_path = BN == 128 && !FUSE1 && DIL == 1 && KS == 3 && conv_f16x3_uses_w4(p.Cin) && (vec_ok || !F16X3_W4_REGEPI);
+  // (... and address their input with 32-bit BYTE offsets from the member's base: inputs of 4 GiB and more take the 8-wave path)
+  bool in_fits32 = true;
+  for (int i = 0; i < n; ++i)
+    in_fits32 = in_fits32 && (unsigned long long)as[i].in.B * as[i].in.H * as[i].in.W * as[i].in.cstride * 4ull < (1ull << 32);
+  const bool w4_path = BN == 128 && !FUSE1 && DIL == 1 && KS == 3 && conv_f16x3_uses_w4(p.Cin) && (vec_ok || !F16X3_W4_REGEPI) &&
+                       in_fits32;
   const int mt = w4_path ? w4_pick_mt(as, n, p.nct) : 4;
   const int th = 4 * mt;
   for (int i = 0; i < n; ++i) {
@@ -1719,7 +1724,7 @@ static int launch_f16x3_t(const ConvArgs* as, int n, hipStream_t s) {
     else SHF_W4_LAUNCH(false, 2)
 #undef SHF_W4_LAUNCH
   } else if (a.in_split) {
-    set_error("conv f16x3: split-format input reached a kernel other than the 4-wave one");
+    set_error("conv f16x3: split-format input reached a kernel other than the 4-wave one (unaligned views, or an input of 4 GiB or more)");
     return -1;
   }
   else
