@@ -91,6 +91,32 @@ def test_conv_identity_is_transpose_detecting():
     assert H.rel_err(go["c1"], oo["c1"]) < ACT_TOL
 
 
+@pytest.mark.parametrize("cin,cout,h,w,relu,consumer", [
+    (128, 128, 19, 21, True, True),     # conv2_2 class: pooled output only (a consumer reads the pool), ragged edges
+    (128, 256, 35, 18, False, True),    # no ReLU: the pool's neutral element for outside pixels is -FLT_MAX, not 0
+    (256, 128, 33, 47, True, False),    # pooled AND un-pooled output both read (the conv4_3 case)
+])
+def test_four_wave_kernel_fused_pool(cin, cout, h, w, relu, consumer):
+    """The register epilogue of the 4-wave kernels (conv_epilogue_regs): MFMA as D[cout][pixel], half-wave quad exchange,
+    2x2/2 max-pool as a DPP quad max with Caffe's clipped windows on odd maps -- against the oracle's conv + pool."""
+    pool = 'layer { name: "p" type: "Pooling" bottom: "c1" top: "p" pooling_param { pool: MAX kernel_size: 2 stride: 2 } }\n'
+    txt = H.single_layer_net(conv_layer("c0", "data", cin, 3, 1) + conv_layer("c1", "c0", cout, 3, 1, 1, relu) + pool +
+                             conv_layer("c2", "p", 64, 1, 0) + ("" if consumer else conv_layer("c3", "c1", 64, 1, 0)), 3, h, w)
+    gnet, onet = H.make_pair(P.parse(txt), seed=11)
+    rng = np.random.default_rng(4)
+    for name in ("c0", "c1"):
+        onet.params[name][1][...] = rng.normal(0, 0.5, onet.params[name][1].shape).astype(np.float32)
+    H.load_params(gnet, onet.params)
+    data = rng.normal(0, 1, (1, 3, h, w)).astype(np.float32)
+    go, oo = H.run_both(gnet, onet, data, np.array([[h, w, 1]], np.float32))
+    for name in ("p", "c2") + (() if consumer else ("c1", "c3")):
+        a, b = gnet.blobs[name].data, onet.blobs[name].data
+        assert a.shape == b.shape, name
+        assert H.rel_err(a, b) < ACT_TOL, name
+    if not relu:
+        assert gnet.blobs["p"].data.min() < 0      # negative maxima survive
+
+
 def test_pool_deconv_concat():
     h, w = 18, 26
     txt = H.single_layer_net(
