@@ -69,6 +69,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef F16X3_W4_DMA_SCHED_MT2
 #define F16X3_W4_DMA_SCHED_MT2 1   // 8-row tiles: weight-DMA rounds per k-step (see the stage body)
 #endif
+#ifndef F16X3_W4_WREG
+#define F16X3_W4_WREG 0   // 4-wave kernel: the next stage's weights through registers (1) or by LDS DMA (0) in the stages without a halo hand-over
+#endif
 #ifndef F16X3_CONV_MID
 #define F16X3_CONV_MID 1   // 1: split the next halo tile to fp16 hi/lo in the middle of the last stage's MFMAs
 #endif
@@ -576,18 +579,58 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4_kernel(ConvK p) {
   constexpr int DMA_ROUNDS_W4 = 15;
   const unsigned lane16 = (unsigned)lane * 16u;
   const int last_piece = wave_u + 16 < PCS_SLAB ? wave_u + 16 : PCS_SLAB - 1;
+  // Round r (0..13) of a wave moves piece q = wave + 4 r of the stage's 54 (piece 53 again for waves 2, 3 in the last
+  // round: 2 wasted KiB per stage instead of the 6 of a 5-rounds-per-slab walk -- the weight traffic is what this
+  // power-limited kernel pays most for).  LDS offset = q KiB (the three slabs are contiguous there);
+  // global offset = slab (q / 18) + (q % 18) KiB: compile-time per round except round 4, where waves 0, 1 are still in
+  // slab 0 and waves 2, 3 already in slab 1 (one per-wave scalar).
+  constexpr int W_ROUNDS = 14;
+  const size_t slab_b = slab * 2;   // bytes between the tap slabs of a cout tile in global memory
+  const size_t goff_r4 = wave_u < 2 ? (size_t)(16 + wave_u) * 1024 : slab_b + (size_t)(wave_u - 2) * 1024;
+  const int q_r13 = wave_u < 2 ? 52 + wave_u : 53;
+  auto w_goff = [&](int r) -> size_t {
+    if (r == 4) return goff_r4;
+    if (r == 13) return 2 * slab_b + (size_t)(q_r13 - 36) * 1024;
+    const int sl = (4 * r) / 18;                       // (rounds other than 4: all four waves in one slab)
+    return (size_t)sl * slab_b + (size_t)(4 * r - 18 * sl + wave_u) * 1024;
+  };
+  auto w_loff = [&](int r) { return (r == 13 ? q_r13 : 4 * r + wave_u) * 1024; };
   auto dma_w = [&](int stage, int buf, int j0, int n) {
     const unsigned char* ws_ = (const unsigned char*)(wbase + (size_t)stage * 3 * slab);
     unsigned char* bd_ = Bs + buf * (3 * SLAB_B);
 #pragma unroll
-    for (int j = j0; j < j0 + n; ++j) {
-      const int sl = j / 5, i5 = j % 5;
-      const int within = i5 < 4 ? wave_u + 4 * i5 : last_piece;
-      const unsigned char* ub = ws_ + (size_t)sl * slab * 2 + within * 1024;   // wave-uniform
+    for (int r = j0; r < j0 + n; ++r) {
+      const unsigned char* ub = ws_ + w_goff(r);   // wave-uniform
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ub + lane16),
-                                       (__attribute__((address_space(3))) void*)(bd_ + sl * SLAB_B + within * 1024), 16, 0,
-                                       0);
+                                       (__attribute__((address_space(3))) void*)(bd_ + w_loff(r)), 16, 0, 0);
     }
+  };
+  // The same rounds THROUGH REGISTERS (F16X3_W4_WREG): a plain global_load_dwordx4 + ds_write_b128 pair.  An LDS-DMA
+  // instruction holds the issuing wave ~70 cycles with four waves at it (tools/dma_rate.hip: 59 B/clk per CU), a plain
+  // load ~13, and with one wave per SIMD every cycle the wave is held the matrix pipe idles: the in-loop weight DMA is
+  // 22 % of this kernel (F16X3_EXPERIMENT_NO_DMA).  The registers are the halo hand-over's (areg), which only the
+  // last kernel row of a chunk uses: that stage keeps the DMA.
+  // (named registers, not an array: hipcc keeps a local array that is written in one unrolled k-step and read in a
+  // later one in scratch memory)
+  auto w_addr = [&](int stage, int r) {
+    return (const unsigned char*)(wbase + (size_t)stage * 3 * slab) + w_goff(r < W_ROUNDS ? r : W_ROUNDS - 1) + lane16;
+  };
+  auto w_load5 = [&](int stage, int j0, float4& r0, float4& r1, float4& r2, float4& r3, float4& r4) {
+    r0 = *(const float4*)w_addr(stage, j0);
+    r1 = *(const float4*)w_addr(stage, j0 + 1);
+    r2 = *(const float4*)w_addr(stage, j0 + 2);
+    r3 = *(const float4*)w_addr(stage, j0 + 3);
+    r4 = *(const float4*)w_addr(stage, j0 + 4);
+  };
+  auto w_lds = [&](int buf, int r) {
+    return (float4*)(Bs + buf * (3 * SLAB_B) + w_loff(r < W_ROUNDS ? r : W_ROUNDS - 1) + lane16);
+  };
+  auto w_store5 = [&](int buf, int j0, const float4& r0, const float4& r1, const float4& r2, const float4& r3, const float4& r4) {
+    *w_lds(buf, j0) = r0;
+    *w_lds(buf, j0 + 1) = r1;
+    *w_lds(buf, j0 + 2) = r2;
+    *w_lds(buf, j0 + 3) = r3;
+    *w_lds(buf, j0 + 4) = r4;
   };
   // prologue: W(0) by DMA and the halo tile of chunk 0 are requested first; the accumulator clearing and
   // the fragment geometry fill the wait
@@ -596,7 +639,7 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4_kernel(ConvK p) {
 #pragma unroll
   for (int j = 0; j < ALD; ++j) areg0[j] = make_float4(0.f, 0.f, 0.f, 0.f);
 #else
-  dma_w(0, 0, 0, DMA_ROUNDS_W4);
+  dma_w(0, 0, 0, W_ROUNDS);
 #pragma unroll
   for (int j = 0; j < ALD; ++j) areg0[j] = *(const float4*)((const char*)gin + a_gsafe[j]);
 #endif
@@ -640,11 +683,17 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4_kernel(ConvK p) {
   auto stage = [&](int c, auto KY_, auto MODE_) {
     constexpr int ky = decltype(KY_)::value;
     constexpr bool PREFETCH = decltype(MODE_)::value == 1;
+#ifdef F16X3_EXPERIMENT_NO_HANDOVER   // timing only (WRONG results): the halo tile of chunk 0 serves every chunk
+    constexpr bool HANDOVER = false;
+#else
     constexpr bool HANDOVER = decltype(MODE_)::value == 2;
+#endif
     const int st = c * 3 + ky;
     SHF_T(t0);
+#ifndef F16X3_EXPERIMENT_NO_BARRIER   // timing only (WRONG results)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of W(st) has landed
     __syncthreads();
+#endif
     SHF_T(t1);
     const int st_next = st + 1 < NST ? st + 1 : st;  // the last stage re-fetches itself (unused) instead of branching
     const int buf_next = (st + 1) & 1;
@@ -652,7 +701,17 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4_kernel(ConvK p) {
     const unsigned char* Arow = As + ky * HPITCH;
     const unsigned char* Bst = Bs + (st & 1) * (3 * BN * ROWB);
     half8 fa[2][2 * MT], fb[2][4];
+    float4 wA0, wA1, wA2, wA3, wA4, wB0, wB1, wB2, wB3, wB4, wC0, wC1, wC2, wC3, wC4;  // F16X3_W4_WREG: weight pieces on their way to LDS
     auto load_frag = [&](int s_, half8* a, half8* bf) {
+#ifdef F16X3_EXPERIMENT_NO_FRAG   // timing only (WRONG results): fragments read once per stage
+      if (s_ > 0) {
+#pragma unroll
+        for (int t = 0; t < 2 * MT; ++t) a[t] = fa[0][t];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) bf[t] = fb[0][t];
+        return;
+      }
+#endif
       const unsigned char* Ap = Arow + (s_ >> 1) * ROWB + (s_ & 1) * 32;
       const unsigned char* Bp = Bst + (s_ >> 1) * (BN * ROWB) + (s_ & 1) * 32;
 #pragma unroll
@@ -678,16 +737,29 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4_kernel(ConvK p) {
       if (s_ + 1 < 6) load_frag(s_ + 1, fa[(s_ + 1) & 1], fb[(s_ + 1) & 1]);
       // the stage's side jobs ride under the MFMAs, a few per k-step so that no queue ever fills
       // 16-row tiles: 3 rounds per k-step; the 8-row tiles' stage is half as long and its weights are late more often:
-      // front-loaded (F16X3_W4_DMA_SCHED_MT2: 1 = 4,4,4,3,0,0; 3 = 5,5,5,0,0,0; 4 = 8,7,0,0,0,0)
-      constexpr int SCH = MT == 2 ? F16X3_W4_DMA_SCHED_MT2 : 0;
-      constexpr int DMA_N[6] = {SCH == 4 ? 8 : SCH == 3 ? 5 : SCH == 1 ? 4 : 3, SCH == 4 ? 7 : SCH == 3 ? 5 : SCH == 1 ? 4 : 3,
-                                SCH == 4 ? 0 : SCH == 3 ? 5 : SCH == 1 ? 4 : 3, SCH >= 3 ? 0 : 3, SCH >= 1 ? 0 : 3, 0};
+      // front-loaded
+      constexpr int DMA_N[6] = {MT == 2 ? 4 : 3, MT == 2 ? 4 : 3, MT == 2 ? 4 : 3, MT == 2 ? 2 : 3, MT == 2 ? 0 : 2, 0};
       constexpr int DMA_J0[6] = {0, DMA_N[0], DMA_N[0] + DMA_N[1], DMA_N[0] + DMA_N[1] + DMA_N[2],
-                                 DMA_N[0] + DMA_N[1] + DMA_N[2] + DMA_N[3], 15};
+                                 DMA_N[0] + DMA_N[1] + DMA_N[2] + DMA_N[3], W_ROUNDS};
+      int n_vmem = DMA_N[s_], n_dsw = 0;
 #ifndef F16X3_EXPERIMENT_NO_DMA  // timing experiment only (stale weights): what the in-loop DMA issue costs
-      if (DMA_N[s_]) dma_w(st_next, buf_next, DMA_J0[s_], DMA_N[s_]);
+      if constexpr (F16X3_W4_WREG && !HANDOVER && !PREFETCH) {
+        // through registers: rounds 0-4 / 5-9 requested in k-steps 0 / 1, parked in k-steps 2 / 3 (two k-steps to
+        // come back), rounds 10-14 take the first batch's registers in k-step 2 and are parked in k-step 4
+        if (s_ == 0) { w_load5(st_next, 0, wA0, wA1, wA2, wA3, wA4); n_vmem = 5; }
+        else if (s_ == 1) { w_load5(st_next, 5, wB0, wB1, wB2, wB3, wB4); n_vmem = 5; }
+        else if (s_ == 2) {
+          w_store5(buf_next, 0, wA0, wA1, wA2, wA3, wA4);
+          w_load5(st_next, 10, wC0, wC1, wC2, wC3, wC4);
+          n_vmem = 5; n_dsw = 5;
+        }
+        else if (s_ == 3) { w_store5(buf_next, 5, wB0, wB1, wB2, wB3, wB4); n_vmem = 0; n_dsw = 5; }
+        else if (s_ == 4) { w_store5(buf_next, 10, wC0, wC1, wC2, wC3, wC4); n_vmem = 0; n_dsw = 5; }
+        else n_vmem = 0;
+      } else {
+        if (DMA_N[s_]) dma_w(st_next, buf_next, DMA_J0[s_], DMA_N[s_]);
+      }
 #endif
-      int n_vmem = DMA_N[s_];
 #if F16X3_W4_PREFETCH
       if constexpr (PREFETCH) {  // a whole stage of slack before the first use
         if (s_ >= 3 && s_ < 5) {
@@ -744,6 +816,7 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4_kernel(ConvK p) {
 #pragma unroll
         for (int g = 0; g < 2 * NP * MT - (2 * MT + 4) - 3; ++g) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          if (g < n_dsw) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
           if (g < n_vmem) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
         }
       }
@@ -867,7 +940,8 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4_kernel(ConvK p) {
     }
   }
 #endif
-#ifndef F16X3_EXPERIMENT_NO_PROLOGUE
+#if !defined(F16X3_EXPERIMENT_NO_PROLOGUE) && !defined(F16X3_EXPERIMENT_NO_FRAG) && !defined(F16X3_EXPERIMENT_NO_BARRIER) && \
+    !defined(F16X3_EXPERIMENT_NO_HANDOVER) && !defined(F16X3_EXPERIMENT_NO_DMA)
   conv_raise_range_flag(p.range_flag, amax);
 #endif
 #ifdef SHF_CONV_TIMING
