@@ -72,6 +72,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef F16X3_W4_WREG
 #define F16X3_W4_WREG 0   // 4-wave kernel: the next stage's weights through registers (1) or by LDS DMA (0) in the stages without a halo hand-over
 #endif
+#ifndef F16X3_W4_EARLY_HANDOVER
+#define F16X3_W4_EARLY_HANDOVER 0   // 4-wave kernel: park the next halo tile under the last k-step's MFMAs (1) or after the stage (0)
+#endif
 #ifndef F16X3_CONV_MID
 #define F16X3_CONV_MID 1   // 1: split the next halo tile to fp16 hi/lo in the middle of the last stage's MFMAs
 #endif
@@ -779,10 +782,22 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4_kernel(ConvK p) {
 #pragma unroll
           for (int j = s_ * HL0; j < (s_ ? ALD : HL0); ++j) areg[j] = *(const float4*)((const char*)inc_ + a_gsafe[j]);
           n_vmem += s_ ? ALD - HL0 : HL0;
-        } else if (s_ >= 4) {  // as late as possible: the loads get three k-steps to come back
+        } else if (F16X3_W4_EARLY_HANDOVER ? s_ == 4 : s_ >= 4) {  // as late as possible: the loads get three k-steps to come back
 #pragma unroll
-          for (int j = (s_ - 4) * 6; j < (s_ == 5 ? ALD : 6); ++j) split_inplace(areg[j], (a_valid >> j) & 1);
+          for (int j = F16X3_W4_EARLY_HANDOVER ? 0 : (s_ - 4) * 6; j < (F16X3_W4_EARLY_HANDOVER || s_ == 5 ? ALD : 6); ++j)
+            split_inplace(areg[j], (a_valid >> j) & 1);
         }
+#if F16X3_W4_EARLY_HANDOVER
+        if (s_ == 5) {
+          // The fragments of this last k-step were read under the previous one: once every wave is here the halo tile
+          // of chunk c is dead, and the next tile is parked UNDER these 24 MFMAs instead of after them (the stage
+          // barrier that follows makes it visible).
+          __syncthreads();
+#pragma unroll
+          for (int j = 0; j < ALD; ++j)
+            if (j + 1 < ALD || a_last) store_piece(areg[j], j);
+        }
+#endif
       }
 #endif
       // three sweeps over the 8 output tiles: consecutive MFMAs never chain on one accumulator
@@ -820,6 +835,17 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4_kernel(ConvK p) {
           if (g < n_vmem) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
         }
       }
+#if F16X3_W4_EARLY_HANDOVER && !F16X3_W4_PREFETCH
+      if constexpr (HANDOVER) {
+        if (s_ == 5) {
+#pragma unroll
+          for (int g = 0; g < (IN_SPLIT ? ALD : 2 * ALD); ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+          }
+        }
+      }
+#endif
       __builtin_amdgcn_sched_barrier(0);
 #ifdef SHF_CONV_TIMING_STEPS
       ts1 = __builtin_amdgcn_s_memtime();
@@ -833,7 +859,7 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4_kernel(ConvK p) {
     SHF_T(t3);
     tb += t1 - t0; tc += t3 - t1;
 #endif
-    if constexpr (HANDOVER) {
+    if constexpr (HANDOVER && !(F16X3_W4_EARLY_HANDOVER && !F16X3_W4_PREFETCH)) {
       __syncthreads();  // every wave is done reading the halo tile of chunk c
 #pragma unroll
       for (int j = 0; j < ALD; ++j)
