@@ -746,6 +746,10 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4_kernel(ConvK p) {
                                  DMA_N[0] + DMA_N[1] + DMA_N[2] + DMA_N[3], W_ROUNDS};
       int n_vmem = DMA_N[s_], n_dsw = 0;
 #ifndef F16X3_EXPERIMENT_NO_DMA  // timing experiment only (stale weights): what the in-loop DMA issue costs
+#ifdef F16X3_EXPERIMENT_HALF_DMA   // timing only (WRONG results): half of the weight pieces -- what 2x weight reuse would buy
+      if (s_ >= F16X3_EXPERIMENT_HALF_DMA) n_vmem = 0;
+      else
+#endif
       if constexpr (F16X3_W4_WREG && !HANDOVER && !PREFETCH) {
         // through registers: rounds 0-4 / 5-9 requested in k-steps 0 / 1, parked in k-steps 2 / 3 (two k-steps to
         // come back), rounds 10-14 take the first batch's registers in k-step 2 and are parked in k-step 4
@@ -967,7 +971,7 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4_kernel(ConvK p) {
   }
 #endif
 #if !defined(F16X3_EXPERIMENT_NO_PROLOGUE) && !defined(F16X3_EXPERIMENT_NO_FRAG) && !defined(F16X3_EXPERIMENT_NO_BARRIER) && \
-    !defined(F16X3_EXPERIMENT_NO_HANDOVER) && !defined(F16X3_EXPERIMENT_NO_DMA)
+    !defined(F16X3_EXPERIMENT_NO_HANDOVER) && !defined(F16X3_EXPERIMENT_NO_DMA) && !defined(F16X3_EXPERIMENT_HALF_DMA)
   conv_raise_range_flag(p.range_flag, amax);
 #endif
 #ifdef SHF_CONV_TIMING
