@@ -21,6 +21,8 @@ struct ConvMember {
 
 struct ConvK {
   const float* wp;   // packed weights
+  const void* wph;   // dual-tile 4-wave kernel: its own split-fp16 pack (16-channel chunks, unscaled low parts)
+  float wscale_inv;  // ... and the power of two its epilogue multiplies back
   const float* bias;
   int Cin, Cout;
   int in_stride, out_stride;
@@ -29,7 +31,8 @@ struct ConvK {
                      // main / the pooled output in the split-fp16 activation format (ConvArgs::out_split)
   int pool_stride;   // floats per pixel of the pool buffer
   int nct, nmem;
-  int ntile_blocks;  // persistent kernels: pixel tiles x cout tiles of the whole launch (the grid is smaller)
+  int ntile_blocks;  // persistent / dual-tile kernels: (pixel tiles of the group this launch ends at) x cout tiles
+  int tile_base;     // dual-tile kernels: first pixel tile of this launch (a group may be covered by two launches)
   const float* w1t;  // FUSE1: first-layer weights transposed to [27][64]
   const void* w1f;   // FUSE1 (producer/consumer kernel): the same as split-fp16 MFMA B fragments (pack_first_conv_frags)
   const float* b1;   // FUSE1: first-layer bias [64]
@@ -387,18 +390,10 @@ __device__ __forceinline__ void conv_flush_quarter(const float* __restrict__ Cs,
 // (row_to_pixel walks a 2x2 window with the two low lane bits): two DPP quad permutes; windows on a ragged edge are
 // clipped like Caffe's (pooling_layer.cu:24-27) by feeding -FLT_MAX for pixels outside the image.
 template <bool RELU>
-__device__ __forceinline__ void conv_epilogue_regs(const cs_f32x16 am, const cs_f32x16 ac, float inv, const float4* bias16,
-                                                   bool valid, bool interior, float* __restrict__ pix_main, int cout16,
-                                                   bool main_split, float* __restrict__ pix_pool, bool pool_writer,
-                                                   bool pool_split, float& amax) {
-  // `interior` (wave-uniform): every pixel of the block tile is inside the image -- no pooling window needs clipping
-  float v[16];
-#pragma unroll
-  for (int r = 0; r < 16; r += 2) {
-    const cs_f32x2 t = __builtin_elementwise_fma(cs_f32x2{ac[r], ac[r + 1]}, cs_f32x2{inv, inv}, cs_f32x2{am[r], am[r + 1]});
-    v[r] = t[0];
-    v[r + 1] = t[1];
-  }
+__device__ __forceinline__ void conv_epilogue_regs_tail(float (&v)[16], const float4* bias16, bool valid, bool interior,
+                                                        float* __restrict__ pix_main, int cout16, bool main_split,
+                                                        float* __restrict__ pix_pool, bool pool_writer, bool pool_split,
+                                                        float& amax) {
 #pragma unroll
   for (int s = 0; s < 8; ++s) {
     const int x = (s & 3) + 4 * (s >> 2), y = x + 8;   // (0..3 <-> 8..11), (4..7 <-> 12..15)
@@ -467,6 +462,38 @@ __device__ __forceinline__ void conv_epilogue_regs(const cs_f32x16 am, const cs_
       }
     }
   }
+}
+
+template <bool RELU>
+__device__ __forceinline__ void conv_epilogue_regs(const cs_f32x16 am, const cs_f32x16 ac, float inv, const float4* bias16,
+                                                   bool valid, bool interior, float* __restrict__ pix_main, int cout16,
+                                                   bool main_split, float* __restrict__ pix_pool, bool pool_writer,
+                                                   bool pool_split, float& amax) {
+  // `interior` (wave-uniform): every pixel of the block tile is inside the image -- no pooling window needs clipping
+  float v[16];
+#pragma unroll
+  for (int r = 0; r < 16; r += 2) {
+    const cs_f32x2 t = __builtin_elementwise_fma(cs_f32x2{ac[r], ac[r + 1]}, cs_f32x2{inv, inv}, cs_f32x2{am[r], am[r + 1]});
+    v[r] = t[0];
+    v[r + 1] = t[1];
+  }
+  conv_epilogue_regs_tail<RELU>(v, bias16, valid, interior, pix_main, cout16, main_split, pix_pool, pool_writer, pool_split, amax);
+}
+
+// one accumulator (dual-tile kernel: unscaled low parts, weights pre-scaled by a power of two): out = acc * scale
+template <bool RELU>
+__device__ __forceinline__ void conv_epilogue_regs1(const cs_f32x16 acc, float scale, const float4* bias16, bool valid,
+                                                    bool interior, float* __restrict__ pix_main, int cout16, bool main_split,
+                                                    float* __restrict__ pix_pool, bool pool_writer, bool pool_split,
+                                                    float& amax) {
+  float v[16];
+#pragma unroll
+  for (int r = 0; r < 16; r += 2) {
+    const cs_f32x2 t = cs_f32x2{acc[r], acc[r + 1]} * cs_f32x2{scale, scale};
+    v[r] = t[0];
+    v[r + 1] = t[1];
+  }
+  conv_epilogue_regs_tail<RELU>(v, bias16, valid, interior, pix_main, cout16, main_split, pix_pool, pool_writer, pool_split, amax);
 }
 
 }  // namespace shf

@@ -24,6 +24,7 @@
 // conv_mfma_f16x3_w4p_kernel is the persistent (block walks tiles) form of the 4-wave kernel: off by default
 // (SHF_F16X3_W4P=1), see DESIGN.md for why it does not pay.
 #include <algorithm>
+#include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -1342,6 +1343,362 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4p_kernel(ConvK p) {
   conv_raise_range_flag(p.range_flag, amax);
 }
 
+// DUAL-TILE form of the 4-wave kernel: a block computes TWO 16x16-pixel tiles (consecutive in the launch's tile order)
+// x 128 couts and every weight slab it fetches serves both -- the weights' way from L2 to LDS is what this power-limited
+// kernel pays most for after the MFMAs themselves (halving it is worth 15 %).  What makes room for the second
+// tile's accumulators is ONE accumulator per output instead of two: the low parts are kept UNSCALED in LDS
+// (lo = fp16(x - hi); the split activation format of HBM keeps its 2^11 -- the halo staging multiplies it away; the
+// weights come from their own pack, pre-scaled by a power of two: pack_conv_weights_split16h), so hi*hi, hi*lo and
+// lo*hi have one scale and share a register (v_mfma_f32_32x32x16_f16 honours fp16 subnormals: tools/mfma_denorm.hip;
+// end-to-end error of the scheme: tools/single_acc_study.py).  What makes room for the second halo tile's hand-over
+// registers is a CHUNK of 16 input channels instead of 32: a stage is still one kernel row of a chunk = 144 MFMAs per
+// wave (3 taps x 1 k-step x 2 tiles x 24), its three weight slabs are 30 KB instead of 55, a halo tile 30 KB instead
+// of 48, and a hand-over moves 2 x 6 pieces per thread.  LDS rows are [hi 16 halfs | lo 16 halfs | 16 B pad] = 80 B
+// (conflict-free ds_read_b128 over 16 consecutive rows; +224 B per halo-tile row puts the second pixel row of an A
+// fragment on the other half of the banks).  The six half-steps of a stage (tap kx, tile t) are software-pipelined
+// like the six k-steps of the single-tile kernel: while (kx, t) runs, the A fragments of the next (kx, t) -- and, on
+// even half-steps, the B fragments of tap kx + 1 -- are read.
+template <bool IN_SPLIT, int MT_, int NTILE, int NP = 3>
+__global__ __launch_bounds__(256) void conv_mfma_f16x3_w4d_kernel(ConvK p) {
+  static_assert((MT_ == 4 || MT_ == 2) && (NTILE == 1 || NTILE == 2), "16- or 8-row tiles, one or two per block");
+  constexpr int MT = MT_, TH = 4 * MT, TW = 16, HTW = 18, HTH = TH + 2, HP = HTH * HTW;
+  constexpr int KC = 16, ROWB = 80, ROWPAD = 224, BN = 128, NT = 256;
+  constexpr int HPITCH = HTW * ROWB + ROWPAD;        // 1664 B per halo-tile row
+  constexpr int AS_B = HTH * HPITCH;                  // 29 952 B per halo tile
+  constexpr int SLAB_B = BN * ROWB;                   // 10 240 B per tap slab
+  constexpr int ALD = (HP * 4 + NT - 1) / NT;         // 16-byte halo pieces per thread and tile: 6 (16 rows) or 3
+  constexpr float LO_SCALE = 2048.0f;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* As = smem;                           // [NTILE][HTH][HPITCH]
+  unsigned char* Bs = smem + NTILE * AS_B;            // [2 buffers][3 taps][BN][ROWB]
+  float* biasL = (float*)(Bs + 2 * 3 * SLAB_B);       // [BN]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave & 1, wm = wave >> 1;
+  const int bid = blockIdx.x;
+  const int ct = bid % p.nct;
+  const int pp = bid / p.nct;
+  const int ntiles = p.ntile_blocks / p.nct;          // the launch covers pixel tiles [tile_base, ntiles) of the group
+
+  struct Geo { int ty0, tx0, H, W, b; const float* in; float* out; float* pool; };
+  auto geometry = [&](int t) {
+    Geo g;
+    int pt = t;
+    const int mi = conv_find_member(p, pt);
+    const ConvMember& mem = p.m[mi];
+    pt -= mem.tile_start;
+    g.b = pt / mem.tiles_per_img;
+    pt -= g.b * mem.tiles_per_img;
+    g.ty0 = (pt / mem.tiles_x) * TH;
+    g.tx0 = (pt % mem.tiles_x) * TW;
+    g.H = mem.H; g.W = mem.W;
+    g.in = mem.in; g.out = mem.out; g.pool = mem.pool;
+    return g;
+  };
+  const int t0 = p.tile_base + NTILE * pp;
+  const bool has1 = NTILE == 2 && t0 + 1 < ntiles;    // (an odd tile count: the last block's second tile is a dummy)
+  const Geo g0 = geometry(t0), g1 = geometry(has1 ? t0 + 1 : t0);
+
+  const int nchunks = p.Cin / KC;
+  const int NST = nchunks * 3;
+  const size_t slab = (size_t)p.Cout * 40;            // halfs per tap slab of the whole layer
+  const _Float16* wbase = (const _Float16*)p.wph + (size_t)ct * BN * 40;
+
+  // halo piece j of this thread (per tile): 16-byte piece q = idx & 3 of halo pixel idx >> 2, idx = tid + 256 j.
+  //   split input : q = 0, 1: hi channels 0-7 / 8-15 of the 16-channel half chunk; q = 2, 3: lo (scaled by 2^11 in HBM)
+  //   fp32 input  : q = channels 4q .. 4q+3 (float4)
+  // a_goff = BYTE offset of the piece inside the member's input for chunk 0 (the chunk adds a uniform offset)
+  unsigned a_goff[NTILE][ALD];
+  unsigned a_valid = 0;                               // bit t * 8 + j
+  auto halo_offsets = [&](const Geo& g, int t, bool exists) {
+#pragma unroll
+    for (int j = 0; j < ALD; ++j) {
+      const int idx = tid + NT * j;
+      const int hp = idx >> 2, q = idx & 3;
+      const int hy = hp / HTW, hx = hp - hy * HTW;
+      const int gy = g.ty0 - 1 + hy, gx = g.tx0 - 1 + hx;
+      const bool in = exists && (idx < HP * 4) && ((unsigned)gy < (unsigned)g.H) && ((unsigned)gx < (unsigned)g.W);
+      const unsigned pix = (unsigned)(((g.b * g.H + gy) * g.W + gx) * p.in_stride) * 4u;
+      a_goff[t][j] = in ? pix + (IN_SPLIT ? (unsigned)((q >> 1) * 64 + (q & 1) * 16) : (unsigned)(q * 16)) : 0u;
+      a_valid |= in ? (1u << (t * 8 + j)) : 0u;
+    }
+  };
+  halo_offsets(g0, 0, true);
+  if constexpr (NTILE == 2) halo_offsets(g1, 1, has1);
+  const bool a_last = tid + NT * (ALD - 1) < HP * 4;  // the ragged last piece exists for this thread
+  // chunk c16 -> byte offset inside a pixel
+  auto chunk_off = [&](int c16) -> unsigned {
+    return IN_SPLIT ? (unsigned)((c16 >> 1) * 128 + (c16 & 1) * 32) : (unsigned)(c16 * 64);
+  };
+  // piece as fetched -> the 16 bytes (split input) / the hi half4 | lo half4 pair (fp32 input) that go to LDS
+  const float lo_unscale = (tid & 2) ? 1.0f / LO_SCALE : 1.0f;   // (q = tid & 3 for every piece of this thread)
+  auto convert = [&](float4& v, bool valid) {
+    if (!valid) v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (IN_SPLIT) {
+      typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+      const h2 f = {(_Float16)lo_unscale, (_Float16)lo_unscale};
+      float* e = &v.x;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        h2 x = __builtin_bit_cast(h2, e[k]);
+        x = x * f;
+        e[k] = __builtin_bit_cast(float, x);
+      }
+    } else {
+      typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+      const f32x2 x01 = {v.x, v.y}, x23 = {v.z, v.w};
+      const h2 h01 = __builtin_convertvector(x01, h2), h23 = __builtin_convertvector(x23, h2);
+      // (lo through the split activation format's 2^11, like a producer's epilogue + the unscale above would: the two
+      // input formats then give the same bits even where lo is an fp16 subnormal)
+      const h2 un = {(_Float16)(1.0f / LO_SCALE), (_Float16)(1.0f / LO_SCALE)};
+      const h2 l01 = __builtin_convertvector((x01 - __builtin_convertvector(h01, f32x2)) * LO_SCALE, h2) * un;
+      const h2 l23 = __builtin_convertvector((x23 - __builtin_convertvector(h23, f32x2)) * LO_SCALE, h2) * un;
+      v = make_float4(__builtin_bit_cast(float, h01), __builtin_bit_cast(float, h23), __builtin_bit_cast(float, l01),
+                      __builtin_bit_cast(float, l23));
+    }
+  };
+  auto store_piece = [&](const float4& v, int t, int j) {
+    const int idx = tid + NT * j;
+    const int hp = idx >> 2, q = idx & 3;
+    unsigned char* row = As + t * AS_B + hp * ROWB + (hp / HTW) * ROWPAD;
+    if constexpr (IN_SPLIT) {
+      *(float4*)(row + q * 16) = v;
+    } else {
+      *(float2*)(row + q * 8) = make_float2(v.x, v.y);
+      *(float2*)(row + 32 + q * 8) = make_float2(v.z, v.w);
+    }
+  };
+
+  // weight DMA: round r (0..7) of a wave moves 1-KiB piece q = wave + 4 r of the stage's 30 (piece 29 again for waves
+  // 2, 3 in the last round).  LDS offset = q KiB; global offset = slab (q / 10) + (q % 10) KiB: compile-time per round
+  // except round 2, where waves 0, 1 are still in slab 0 (pieces 8, 9) and waves 2, 3 in slab 1 (pieces 10, 11).
+  constexpr int W_ROUNDS = 8;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const unsigned lane16 = (unsigned)lane * 16u;
+  const size_t slab_b = slab * 2;
+  const size_t goff_r2 = wave_u < 2 ? (size_t)(8 + wave_u) * 1024 : slab_b + (size_t)(wave_u - 2) * 1024;
+  const int q_r7 = wave_u < 2 ? 28 + wave_u : 29;
+  auto w_goff = [&](int r) -> size_t {
+    if (r == 2) return goff_r2;
+    if (r == 7) return 2 * slab_b + (size_t)(q_r7 - 20) * 1024;
+    const int sl = (4 * r) / 10;
+    return (size_t)sl * slab_b + (size_t)(4 * r - 10 * sl + wave_u) * 1024;
+  };
+  auto w_loff = [&](int r) { return (r == 7 ? q_r7 : 4 * r + wave_u) * 1024; };
+  auto dma_w = [&](int stage, int buf, int r0, int n) {
+    const unsigned char* ws_ = (const unsigned char*)(wbase + (size_t)stage * 3 * slab);
+    unsigned char* bd_ = Bs + buf * (3 * SLAB_B);
+#pragma unroll
+    for (int r = r0; r < r0 + n; ++r) {
+      const unsigned char* ub = ws_ + w_goff(r);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ub + lane16),
+                                       (__attribute__((address_space(3))) void*)(bd_ + w_loff(r)), 16, 0, 0);
+    }
+  };
+
+  // prologue
+  float4 areg0[ALD], areg1[ALD];  // (two named arrays, indexed by unrolled inner loops only: anything indexed by the
+                                  // half-step variable stays in scratch memory)
+  dma_w(0, 0, 0, W_ROUNDS);
+#pragma unroll
+  for (int j = 0; j < ALD; ++j) {
+    areg0[j] = *(const float4*)((const char*)g0.in + a_goff[0][j]);
+    if constexpr (NTILE == 2) areg1[j] = *(const float4*)((const char*)g1.in + a_goff[1][j]);
+  }
+  if (tid < BN) biasL[tid] = p.bias ? p.bias[ct * BN + tid] : 0.f;
+
+  const int i = lane & 31, kh = lane >> 5;
+  int dy, px;
+  row_to_pixel(i, dy, px);
+  int a_off[MT], b_off[2];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) a_off[t] = (wm * 2 * MT + t * 2 + dy) * HPITCH + px * ROWB + kh * 16;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) b_off[t] = (wn * 64 + t * 32 + i) * ROWB + kh * 16;
+  f32x16 acc0[MT][2], acc1[MT][2];
+#pragma unroll
+  for (int a = 0; a < MT; ++a)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc0[a][c][r] = 0.f; acc1[a][c][r] = 0.f; }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int j = 0; j < ALD; ++j) {
+    convert(areg0[j], (a_valid >> j) & 1);
+    if (j + 1 < ALD || a_last) store_piece(areg0[j], 0, j);
+  }
+  if constexpr (NTILE == 2) {
+#pragma unroll
+    for (int j = 0; j < ALD; ++j) {
+      convert(areg1[j], (a_valid >> (8 + j)) & 1);
+      if (j + 1 < ALD || a_last) store_piece(areg1[j], 1, j);
+    }
+  }
+
+  // one stage = kernel row KY of the 16-channel chunk c; HANDOVER (last kernel row of a chunk but the last): fetch,
+  // convert and park both halo tiles of chunk c + 1
+  auto stage = [&](int c, auto KY_, auto HAND_) {
+    constexpr int ky = decltype(KY_)::value;
+    constexpr bool HANDOVER = decltype(HAND_)::value != 0;
+    const int st = c * 3 + ky;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of W(st) has landed
+    __syncthreads();
+    const int st_next = st + 1 < NST ? st + 1 : st;   // the last stage re-fetches itself (unused) instead of branching
+    const int buf_next = (st + 1) & 1;
+    const unsigned coff = chunk_off(c + 1);
+    const unsigned char* Bst = Bs + (st & 1) * (3 * SLAB_B);
+    half8 fa[2][2 * MT], fb[2][4];
+    auto load_a = [&](int h, half8* a) {              // half-step h = NTILE kx + tile
+      const unsigned char* Ap = As + (h % NTILE) * AS_B + ky * HPITCH + (h / NTILE) * ROWB;
+#pragma unroll
+      for (int t = 0; t < MT; ++t) {
+        a[2 * t] = *(const half8*)(Ap + a_off[t]);
+        a[2 * t + 1] = *(const half8*)(Ap + a_off[t] + 32);
+      }
+    };
+    auto load_b = [&](int kx, half8* bf) {
+      const unsigned char* Bp = Bst + kx * SLAB_B;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        bf[2 * t] = *(const half8*)(Bp + b_off[t]);
+        bf[2 * t + 1] = *(const half8*)(Bp + b_off[t] + 32);
+      }
+    };
+    load_a(0, fa[0]);
+    load_b(0, fb[0]);
+    __builtin_amdgcn_sched_barrier(0);
+    constexpr int NH = 3 * NTILE;                     // half-steps per stage
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+      constexpr int DMA_N2[6] = {2, 2, 2, 2, 0, 0}, DMA_N1[3] = {3, 3, 2}, DMA_J1[3] = {0, 3, 6};
+      const int dma_n = NTILE == 2 ? DMA_N2[h] : DMA_N1[h], dma_j = NTILE == 2 ? 2 * h : DMA_J1[h];
+      const int kx = h / NTILE, tl = h % NTILE;
+      half8* a = fa[h & 1];
+      half8* bf = fb[kx & 1];
+      int n_ds = 0;
+      if (h + 1 < NH) { load_a(h + 1, fa[(h + 1) & 1]); n_ds += 2 * MT; }
+      if (tl == 0 && kx + 1 < 3) { load_b(kx + 1, fb[(kx + 1) & 1]); n_ds += 4; }
+      if (dma_n) dma_w(st_next, buf_next, dma_j, dma_n);
+      int n_vmem = dma_n;
+      if constexpr (HANDOVER) {
+        // tile 0's / tile 1's pieces of the next chunk are requested in the first half-steps (converted and parked
+        // after the stage)
+        if (h == 0) {
+#pragma unroll
+          for (int j = 0; j < ALD; ++j) areg0[j] = *(const float4*)((const char*)g0.in + (a_goff[0][j] + coff));
+          n_vmem += ALD;
+        } else if (NTILE == 2 && h == 1) {
+#pragma unroll
+          for (int j = 0; j < ALD; ++j) areg1[j] = *(const float4*)((const char*)g1.in + (a_goff[NTILE - 1][j] + coff));
+          n_vmem += ALD;
+        }
+      }
+      auto mfmas = [&](f32x16 (&acc)[MT][2]) {
+#pragma unroll
+        for (int tm = 0; tm < MT; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < 2; ++tn)
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[2 * tn], a[2 * tm], acc[tm][tn], 0, 0, 0);
+        if constexpr (NP >= 2) {
+#pragma unroll
+          for (int tm = 0; tm < MT; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn)
+              acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[2 * tn + 1], a[2 * tm], acc[tm][tn], 0, 0, 0);
+        }
+        if constexpr (NP >= 3) {
+#pragma unroll
+          for (int tm = 0; tm < MT; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn)
+              acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[2 * tn], a[2 * tm + 1], acc[tm][tn], 0, 0, 0);
+        }
+      };
+      if (tl) mfmas(acc1);
+      else mfmas(acc0);
+      if (h + 1 < NH) {
+        // next half-step's fragment reads go out under the first MFMAs, the VMEM issues over the rest
+#pragma unroll
+        for (int g = 0; g < (n_ds < 2 * NP * MT ? n_ds : 2 * NP * MT); ++g) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+#pragma unroll
+        for (int g = 0; g < (2 * NP * MT > n_ds + 2 ? 2 * NP * MT - n_ds - 2 : 0); ++g) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          if (g < n_vmem) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (HANDOVER) {
+      __syncthreads();  // every wave is done reading the halo tiles of chunk c
+#pragma unroll
+      for (int j = 0; j < ALD; ++j) {
+        convert(areg0[j], (a_valid >> j) & 1);
+        if (j + 1 < ALD || a_last) store_piece(areg0[j], 0, j);
+      }
+      if constexpr (NTILE == 2) {
+#pragma unroll
+        for (int j = 0; j < ALD; ++j) {
+          convert(areg1[j], (a_valid >> (8 + j)) & 1);
+          if (j + 1 < ALD || a_last) store_piece(areg1[j], 1, j);
+        }
+      }
+    }
+  };
+  using std::integral_constant;
+#pragma unroll 1
+  for (int c = 0; c + 1 < nchunks; ++c) {
+    stage(c, integral_constant<int, 0>{}, integral_constant<int, 0>{});
+    stage(c, integral_constant<int, 1>{}, integral_constant<int, 0>{});
+    stage(c, integral_constant<int, 2>{}, integral_constant<int, 1>{});
+  }
+  stage(nchunks - 1, integral_constant<int, 0>{}, integral_constant<int, 0>{});
+  stage(nchunks - 1, integral_constant<int, 1>{}, integral_constant<int, 0>{});
+  stage(nchunks - 1, integral_constant<int, 2>{}, integral_constant<int, 0>{});
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last stage's (unused) self re-fetch
+
+  // register epilogue, one tile after the other
+  float amax = 0.f;
+  {
+    const bool relu = (p.relu & 1) != 0, write_main = !(p.relu & 8), main_split = (p.relu & 32) != 0,
+               pool_split = (p.relu & 64) != 0;
+    int px_e = px, dy_e = dy, kh_e = kh, i_e = i;
+    asm volatile("" : "+v"(px_e), "+v"(dy_e), "+v"(kh_e), "+v"(i_e));
+    float4 bias16[2][4];
+#pragma unroll
+    for (int g = 0; g < 8; ++g)
+      bias16[g >> 2][g & 3] = *(const float4*)(biasL + wn * 64 + (g >> 2) * 32 + kh_e * 16 + 4 * (g & 3));
+    auto tile_out = [&](f32x16 (&acc)[MT][2], const Geo& g, bool exists) {
+      const int Hp = (g.H + 1) >> 1, Wp = (g.W + 1) >> 1;
+      const bool interior = exists && g.ty0 + TH <= g.H && g.tx0 + TW <= g.W;
+      const int x = g.tx0 + px_e;
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn) {
+        const int cout16 = ct * BN + wn * 64 + tn * 32 + kh_e * 16;
+#pragma unroll
+        for (int tm = 0; tm < MT; ++tm) {
+          const int y = g.ty0 + wm * 2 * MT + tm * 2 + dy_e;
+          const bool valid = exists && y < g.H && x < g.W;
+          float* pm = write_main ? g.out + ((size_t)(g.b * g.H + y) * g.W + x) * p.out_stride : nullptr;
+          float* pq = g.pool ? g.pool + ((size_t)(g.b * Hp + (y >> 1)) * Wp + (x >> 1)) * p.pool_stride : nullptr;
+          if (relu)
+            conv_epilogue_regs1<true>(acc[tm][tn], p.wscale_inv, bias16[tn], valid, interior, pm, cout16, main_split, pq,
+                                      valid && (i_e & 3) == 0, pool_split, amax);
+          else
+            conv_epilogue_regs1<false>(acc[tm][tn], p.wscale_inv, bias16[tn], valid, interior, pm, cout16, main_split, pq,
+                                       valid && (i_e & 3) == 0, pool_split, amax);
+        }
+      }
+    };
+    tile_out(acc0, g0, true);
+    if constexpr (NTILE == 2) tile_out(acc1, g1, has1);
+  }
+  conv_raise_range_flag(p.range_flag, amax);
+}
+
 // Producer / consumer variant of the fused first pair (conv1_1 -> conv1_2, Cin = Cout = 64).  With only
 // 64 couts a wave of the 8-wave kernel owns ONE 32-pixel MFMA row tile (MT = 1) and needs a ds_read_b128 per
 // MFMA -- LDS-bound at ~40 % matrix-pipe use -- and its conv1_1 (lane = halo pixel, 27 taps x 32 channels
@@ -1643,6 +2000,53 @@ void pack_conv_weights_split16(const float* w, int Cout, int Cin, int k, void* d
       }
 }
 
+size_t split16h_conv_weight_halfs(int Cout, int Cin, int k) { return (size_t)Cout * (Cin / 16) * k * k * 40; }
+
+// (Cout,Cin,3,3) fp32 -> [Cin/16][ky][kx][Cout][hi 16 | lo 16 | 8 pad] fp16 (80-B rows = the dual-tile kernel's LDS image).
+// lo is NOT scaled here: lo = fp16(w s - hi) with one power of two s per layer that lifts the weights to [8, 16) at the top,
+// so that the low parts of all but the tiniest weights are normal fp16 numbers (the MFMA honours subnormals anyway:
+// tools/mfma_denorm.hip) and the three products share one accumulator.  Returns 1 / s for the epilogue.
+float pack_conv_weights_split16h(const float* w, int Cout, int Cin, int k, void* dst_) {
+  _Float16* dst = (_Float16*)dst_;
+  const int taps = k * k;
+  float amax = 0.f;
+  for (size_t i = 0; i < (size_t)Cout * Cin * taps; ++i) amax = std::max(amax, std::fabs(w[i]));
+  int e = 0;
+  if (amax > 0.f) e = (int)std::floor(std::log2(8.0 / (double)amax));
+  e = std::max(-14, std::min(14, e));
+  const float s = std::ldexp(1.0f, e);
+  memset(dst_, 0, split16h_conv_weight_halfs(Cout, Cin, k) * 2);
+  for (int co = 0; co < Cout; ++co)
+    for (int ci = 0; ci < Cin; ++ci)
+      for (int t = 0; t < taps; ++t) {
+        const float x = w[((size_t)co * Cin + ci) * taps + t] * s;
+        const _Float16 h = (_Float16)x;
+        const _Float16 l = (_Float16)(x - (float)h);
+        const size_t row = (((size_t)(ci / 16) * taps + t) * Cout + co) * 40;
+        dst[row + (ci % 16)] = h;
+        dst[row + 16 + (ci % 16)] = l;
+      }
+  return 1.0f / s;
+}
+
+// (net.cpp: will launch_conv_f16x3_group(as, n) take the dual-tile family?  Then the sub-launch hook does the profiling.)
+bool conv_f16x3_group_is_dual(const ConvArgs* as, int n) {
+  if (!conv_f16x3_w4_dual() || !as[0].wsplit16h || as[0].img || as[0].k != 3 || as[0].dil != 1 || as[0].out.C % 128) return false;
+  if (!conv_f16x3_uses_w4(as[0].in.C)) return false;
+  for (int i = 0; i < n; ++i) {
+    const ConvArgs& q = as[i];
+    if ((q.out.cstride % 4) || (q.out.coff % 4) || ((uintptr_t)q.out.p & 15)) return false;
+    if (q.pool.p && ((q.pool.cstride % 4) || (q.pool.coff % 4) || ((uintptr_t)q.pool.p & 15))) return false;
+    if ((unsigned long long)q.in.B * q.in.H * q.in.W * q.in.cstride * 4ull >= (1ull << 32)) return false;
+  }
+  return !(getenv("SHF_CONV_SCALAR_EPILOGUE") && atoi(getenv("SHF_CONV_SCALAR_EPILOGUE")));
+}
+
+bool conv_f16x3_w4_dual() {
+  static const int v = getenv("SHF_F16X3_W4D") ? atoi(getenv("SHF_F16X3_W4D")) : 1;
+  return v != 0;
+}
+
 void pack_first_conv_frags(const float* w, void* dst_) {
   _Float16* dst = (_Float16*)dst_;
   for (int n = 0; n < 2; ++n)
@@ -1714,6 +2118,9 @@ static int launch_f16x3_t(const ConvArgs* as, int n, hipStream_t s) {
   const ConvArgs& a = as[0];
   ConvK p;
   p.wp = (const float*)a.wsplit16;
+  p.wph = nullptr;
+  p.wscale_inv = 1.f;
+  p.tile_base = 0;
   p.bias = a.bias;
   p.Cin = a.in.C; p.Cout = a.out.C;
   p.in_stride = a.in.cstride; p.out_stride = a.out.cstride;
@@ -1793,6 +2200,70 @@ static int launch_f16x3_t(const ConvArgs* as, int n, hipStream_t s) {
                                  F16X3_W4_REGEPI ? (size_t)0 : (size_t)16 * th * (BN + CS_PAD) * sizeof(float));
     const dim3 grid((unsigned)(tiles * p.nct));
     p.ntile_blocks = (int)(tiles * p.nct);
+    const bool dual = vec_ok && conv_f16x3_w4_dual() && a.wsplit16h;
+    if (dual) {
+      // dual-tile family (conv_mfma_f16x3_w4d_kernel<.., MT, NTILE, ..>): every variant forms an output with the same
+      // operations in the same order, so the choice below -- two tiles per block where that fills whole rounds of one
+      // block per CU, single tiles for the rest -- never changes a result.
+      p.wph = a.wsplit16h;
+      p.wscale_inv = a.wscale_inv;
+      static int cus = 0;
+      if (!cus) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 4)
+          cus = 256;
+      }
+      const long long per_round = cus / p.nct;                    // pixel tiles (single) or pairs (dual) per round
+      const long long pairs = (tiles + 1) / 2;
+      const double c1 = mt == 4 ? 1.0 : 0.56, c2 = mt == 4 ? 1.82 : 1.02;   // block cost: one / two tiles (w4_pick_mt's unit)
+      const long long full2 = pairs / per_round;                  // whole rounds of dual blocks
+      const long long rest = std::max(0LL, tiles - 2 * full2 * per_round);
+      const double cost_all1 = c1 * (double)((tiles + per_round - 1) / per_round);
+      const double cost_all2 = c2 * (double)((pairs + per_round - 1) / per_round);
+      const double cost_hyb = c2 * (double)full2 + c1 * (double)((rest + per_round - 1) / per_round);
+      long long n2 = 0;                                           // pixel tiles covered by the dual launch
+      if (cost_all2 <= cost_all1 && cost_all2 <= cost_hyb) n2 = tiles;
+      else if (cost_hyb < cost_all1) n2 = 2 * full2 * per_round;
+      static const int force = getenv("SHF_F16X3_W4D_NTILE") ? atoi(getenv("SHF_F16X3_W4D_NTILE")) : 0;
+      if (force == 1) n2 = 0;
+      if (force == 2) n2 = tiles;
+      const size_t as_b = (size_t)(th + 2) * (18 * 80 + 224);
+      const size_t lds1 = as_b + 2 * 3 * (size_t)BN * 80 + BN * sizeof(float), lds2 = lds1 + as_b;
+#define SHF_W4D_LAUNCH(SPLIT, MTV, NTV, GRID, LDS)                                                                        \
+      {                                                                                                                    \
+        if (a.nprod >= 3) hipLaunchKernelGGL((conv_mfma_f16x3_w4d_kernel<SPLIT, MTV, NTV, 3>), GRID, dim3(256), LDS, s, p);    \
+        else if (a.nprod == 2) hipLaunchKernelGGL((conv_mfma_f16x3_w4d_kernel<SPLIT, MTV, NTV, 2>), GRID, dim3(256), LDS, s, p); \
+        else hipLaunchKernelGGL((conv_mfma_f16x3_w4d_kernel<SPLIT, MTV, NTV, 1>), GRID, dim3(256), LDS, s, p);                 \
+      }
+#define SHF_W4D_PICK(NTV, GRID, LDS)                                       \
+      {                                                                     \
+        if (mt == 4 && a.in_split) SHF_W4D_LAUNCH(true, 4, NTV, GRID, LDS)  \
+        else if (mt == 4) SHF_W4D_LAUNCH(false, 4, NTV, GRID, LDS)          \
+        else if (a.in_split) SHF_W4D_LAUNCH(true, 2, NTV, GRID, LDS)        \
+        else SHF_W4D_LAUNCH(false, 2, NTV, GRID, LDS)                       \
+      }
+      const int vbase = (a.in_split ? 4 : 0) + (mt == 2 ? 2 : 0);
+      if (n2 > 0) {
+        p.tile_base = 0;
+        p.ntile_blocks = (int)(n2 * p.nct);
+        const dim3 g2((unsigned)(((n2 + 1) / 2) * p.nct));
+        if (a.sub_hook) a.sub_hook(a.sub_ctx, 0, vbase, (double)n2 / (double)tiles);
+        SHF_W4D_PICK(2, g2, lds2)
+        if (a.sub_hook) a.sub_hook(a.sub_ctx, 1, vbase, (double)n2 / (double)tiles);
+      }
+      if (n2 < tiles) {
+        p.tile_base = (int)n2;
+        p.ntile_blocks = (int)(tiles * p.nct);
+        const dim3 g1((unsigned)((tiles - n2) * p.nct));
+        if (a.sub_hook) a.sub_hook(a.sub_ctx, 0, vbase + 1, (double)(tiles - n2) / (double)tiles);
+        SHF_W4D_PICK(1, g1, lds1)
+        if (a.sub_hook) a.sub_hook(a.sub_ctx, 1, vbase + 1, (double)(tiles - n2) / (double)tiles);
+      }
+#undef SHF_W4D_PICK
+#undef SHF_W4D_LAUNCH
+      SHF_HIP_OK(hipGetLastError());
+      return 0;
+    }
     if (mt == 4 && vec_ok && conv_f16x3_w4_persistent()) {
       // persistent form: one block per CU walks the tiles; the grid stays a multiple of the cout-tile count
       static int cus = 0;
@@ -1875,6 +2346,16 @@ int conv_f16x3_init_attributes() {
   SHF_W4_ATTR(false, 4, 2) SHF_W4_ATTR(true, 4, 2) SHF_W4_ATTR(false, 2, 2) SHF_W4_ATTR(true, 2, 2)
   SHF_W4_ATTR(false, 4, 1) SHF_W4_ATTR(true, 4, 1) SHF_W4_ATTR(false, 2, 1) SHF_W4_ATTR(true, 2, 1)
 #undef SHF_W4_ATTR
+#define SHF_W4D_ATTR(SPLIT, MTV, NTV)                                                                     \
+  SHF_HIP_OK(hipFuncSetAttribute((const void*)conv_mfma_f16x3_w4d_kernel<SPLIT, MTV, NTV, 3>,                \
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                   \
+  SHF_HIP_OK(hipFuncSetAttribute((const void*)conv_mfma_f16x3_w4d_kernel<SPLIT, MTV, NTV, 2>,                \
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                   \
+  SHF_HIP_OK(hipFuncSetAttribute((const void*)conv_mfma_f16x3_w4d_kernel<SPLIT, MTV, NTV, 1>,                \
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  SHF_W4D_ATTR(false, 4, 2) SHF_W4D_ATTR(true, 4, 2) SHF_W4D_ATTR(false, 4, 1) SHF_W4D_ATTR(true, 4, 1)
+  SHF_W4D_ATTR(false, 2, 2) SHF_W4D_ATTR(true, 2, 2) SHF_W4D_ATTR(false, 2, 1) SHF_W4D_ATTR(true, 2, 1)
+#undef SHF_W4D_ATTR
 #define SHF_W4P_ATTR(SPLIT, NPV)                                                                       \
   SHF_HIP_OK(hipFuncSetAttribute((const void*)conv_mfma_f16x3_w4p_kernel<SPLIT, 4, NPV>,                \
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

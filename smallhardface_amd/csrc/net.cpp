@@ -87,7 +87,8 @@ struct HostBuf {
 struct ParamBlob {
   std::vector<int> shape;
   std::vector<float> host;
-  DevBuf raw, packed, packed16, first_t, first_frag;
+  DevBuf raw, packed, packed16, packed16h, first_t, first_frag;
+  float wscale_inv = 1.f;  // packed16h: the power of two its weights were scaled by, inverted
   bool dirty = true;
   size_t count() const {
     size_t c = 1;
@@ -135,7 +136,7 @@ struct Layer {
 };
 
 // the first 8 classes are the instantiations of conv_mfma_f32_kernel, named like rocprofv3 prints them
-enum ProfClass { PC_CONV_MFMA, PC_CONV_MFMA_1 = 1, PC_CONV_MFMA_7 = 7, PC_CONV_F16X3_128, PC_CONV_F16X3_W4, PC_CONV_F16X3_W4_SPLIT, PC_CONV_F16X3_W4_MT2, PC_CONV_F16X3_W4_SPLIT_MT2, PC_CONV_F16X3_64, PC_CONV_F16X3_64_FUSE1, PC_CONV_F16X3_64_D2, PC_CONV_F16X3_64_D4, PC_CONV_F16X3_128_K1, PC_CONV_F16X3_64_K1, PC_CONV_F16X3_PC, PC_CONV_FIRST, PC_CONV_DIRECT, PC_POOL, PC_DECONV, PC_TAIL, PC_MERGE, PC_LAYOUT, PC_COUNT };
+enum ProfClass { PC_CONV_MFMA, PC_CONV_MFMA_1 = 1, PC_CONV_MFMA_7 = 7, PC_CONV_F16X3_128, PC_CONV_F16X3_W4, PC_CONV_F16X3_W4_SPLIT, PC_CONV_F16X3_W4_MT2, PC_CONV_F16X3_W4_SPLIT_MT2, PC_CONV_F16X3_64, PC_CONV_F16X3_64_FUSE1, PC_CONV_F16X3_64_D2, PC_CONV_F16X3_64_D4, PC_CONV_F16X3_128_K1, PC_CONV_F16X3_64_K1, PC_CONV_F16X3_PC, PC_CONV_F16X3_W4D_0, PC_CONV_F16X3_W4D_7 = PC_CONV_F16X3_W4D_0 + 7, PC_CONV_FIRST, PC_CONV_DIRECT, PC_POOL, PC_DECONV, PC_TAIL, PC_MERGE, PC_LAYOUT, PC_COUNT };
 static const char* kProfNames[PC_COUNT] = {"conv_mfma_f32_kernel<3, 1, 128, 8, 16>", "conv_mfma_f32_kernel<3, 2, 128, 8, 16>",
                                            "conv_mfma_f32_kernel<3, 4, 128, 8, 16>", "conv_mfma_f32_kernel<3, 1, 64, 16, 16>",
                                            "conv_mfma_f32_kernel<3, 2, 64, 16, 16>", "conv_mfma_f32_kernel<3, 4, 64, 16, 16>",
@@ -147,6 +148,11 @@ static const char* kProfNames[PC_COUNT] = {"conv_mfma_f32_kernel<3, 1, 128, 8, 1
                                            "conv_mfma_f16x3_kernel<64, true, 1, 3>", "conv_mfma_f16x3_kernel<64, false, 2, 3>",
                                            "conv_mfma_f16x3_kernel<64, false, 4, 3>", "conv_mfma_f16x3_kernel<128, false, 1, 1>",
                                            "conv_mfma_f16x3_kernel<64, false, 1, 1>", "conv_mfma_f16x3_pc_kernel",
+                                           // dual-tile family <IN_SPLIT, rows / 4, tiles per block, products>: index = in_split * 4 + (rows == 8) * 2 + (tiles == 1)
+                                           "conv_mfma_f16x3_w4d_kernel<false, 4, 2, 3>", "conv_mfma_f16x3_w4d_kernel<false, 4, 1, 3>",
+                                           "conv_mfma_f16x3_w4d_kernel<false, 2, 2, 3>", "conv_mfma_f16x3_w4d_kernel<false, 2, 1, 3>",
+                                           "conv_mfma_f16x3_w4d_kernel<true, 4, 2, 3>", "conv_mfma_f16x3_w4d_kernel<true, 4, 1, 3>",
+                                           "conv_mfma_f16x3_w4d_kernel<true, 2, 2, 3>", "conv_mfma_f16x3_w4d_kernel<true, 2, 1, 3>",
                                            "conv_first_kernel", "conv_direct_kernel", "maxpool_kernel",
                                            "deconv_depthwise", "detect_tail", "box_merge", "layout"};
 
@@ -220,6 +226,29 @@ struct ProfScope {
     if (!on) return;
     (void)hipEventRecord(r.b, s);
     p.pending.push_back(r);
+  }
+};
+
+// dual-tile conv family: one profiler record per kernel of a (possibly two-launch) layer, through ConvArgs::sub_hook
+struct SubProf {
+  Prof* p;
+  hipStream_t s;
+  double flops, bytes;
+  Prof::Rec r;
+  static void hook(void* ctx, int after, int variant, double share) {
+    SubProf* sp = (SubProf*)ctx;
+    if (!sp->p->on) return;
+    if (!after) {
+      sp->r.cls = PC_CONV_F16X3_W4D_0 + variant;
+      sp->r.flops = sp->flops * share;
+      sp->r.bytes = sp->bytes * share;
+      sp->r.a = sp->p->get();
+      sp->r.b = sp->p->get();
+      (void)hipEventRecord(sp->r.a, sp->s);
+    } else {
+      (void)hipEventRecord(sp->r.b, sp->s);
+      sp->p->pending.push_back(sp->r);
+    }
   }
 };
 
@@ -1041,6 +1070,13 @@ void shf_net::commit_params(int li) {
         pack_conv_weights_split16(p.host.data(), p.shape[0], p.shape[1], p.shape[2], sp.data());
         p.packed16.ensure(sp.size() * 2);
         HIP_THROW(hipMemcpy(p.packed16.p, sp.data(), sp.size() * 2, hipMemcpyHostToDevice));
+        if (conv_f16x3_w4_dual() && L.k == 3 && L.dil == 1 && conv_f16x3_uses_w4(p.shape[1]) && p.shape[0] % 128 == 0 &&
+            p.shape[1] % 32 == 0) {
+          std::vector<uint16_t> sh(split16h_conv_weight_halfs(p.shape[0], p.shape[1], p.shape[2]));
+          p.wscale_inv = pack_conv_weights_split16h(p.host.data(), p.shape[0], p.shape[1], p.shape[2], sh.data());
+          p.packed16h.ensure(sh.size() * 2);
+          HIP_THROW(hipMemcpy(p.packed16h.p, sh.data(), sh.size() * 2, hipMemcpyHostToDevice));
+        }
       }
     }
     p.dirty = false;
@@ -1118,6 +1154,8 @@ void shf_net::forward_ops(bool fused_path, float im_h, float im_w, float im_scal
         const bool split16 = conv_mode >= 1 && L.kclass == 0 && L.params[0]->packed16.p &&
                              conv_f16x3_eligible(ib.shape[1], L.nout, L.k, L.pad, L.dil);
         a.wsplit16 = split16 ? L.params[0]->packed16.p : nullptr;
+        a.wsplit16h = split16 ? L.params[0]->packed16h.p : nullptr;
+        a.wscale_inv = L.params[0]->wscale_inv;
         if (fused_path && L.fuse_pool >= 0) {
           a.pool = view_of(layers[L.fuse_pool].tops[0]);
           a.write_main = L.pool_only ? 0 : 1;
@@ -1156,9 +1194,15 @@ void shf_net::forward_ops(bool fused_path, float im_h, float im_w, float im_scal
           if (L.kclass == 0 && collect) {
             *collect = a;  // grouped launch: the caller batches this layer over several units
           } else if (L.kclass == 0 && split16) {
-            ProfScope ps(pf, st, f16x3_prof_class(a, L.nout),
-                         fl, by);
-            CHECK_RC(launch_conv_f16x3_group(&a, 1, st));
+            if (conv_f16x3_group_is_dual(&a, 1)) {
+              SubProf sp{&pf, st, fl, by, {}};
+              a.sub_hook = &SubProf::hook;
+              a.sub_ctx = &sp;
+              CHECK_RC(launch_conv_f16x3_group(&a, 1, st));
+            } else {
+              ProfScope ps(pf, st, f16x3_prof_class(a, L.nout), fl, by);
+              CHECK_RC(launch_conv_f16x3_group(&a, 1, st));
+            }
           } else if (L.kclass == 0) {
             const int pc = conv_prof_class(L.k, L.dil, L.nout);
             ProfScope ps(pf, st, pc, fl, by);
@@ -1728,8 +1772,15 @@ int shf_detect_add_levels(shf_net* net, int n, shf_net** members, const float* c
           fl += conv_flops(F, mb->blobs[F.bottoms[0]].shape, mb->blobs[F.tops[0]].shape);
         }
       }
-      ProfScope ps(net->prof, st, f16x3_prof_class(group[0], L.nout, group.data(), n), fl, by);
-      CHECK_RC(launch_conv_f16x3_group(group.data(), n, st));
+      if (conv_f16x3_group_is_dual(group.data(), n)) {
+        SubProf sp{&net->prof, st, fl, by, {}};
+        group[0].sub_hook = &SubProf::hook;
+        group[0].sub_ctx = &sp;
+        CHECK_RC(launch_conv_f16x3_group(group.data(), n, st));
+      } else {
+        ProfScope ps(net->prof, st, f16x3_prof_class(group[0], L.nout, group.data(), n), fl, by);
+        CHECK_RC(launch_conv_f16x3_group(group.data(), n, st));
+      }
     } else {
       const int pc = conv_prof_class(L.k, L.dil, L.nout);
       ProfScope ps(net->prof, st, pc, fl, by);

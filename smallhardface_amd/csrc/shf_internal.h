@@ -31,6 +31,8 @@ struct ConvArgs {
   const float* wraw = nullptr;     // Caffe layout (Cout,Cin,k,k) for the direct kernels
   const float* wfirst = nullptr;   // first layer: weights transposed to [Cin*k*k][Cout]
   const void* wsplit16 = nullptr;  // split-fp16 pack [Cin/32][tap][Cout][hi32|lo32] (conv_f16x3.hip)
+  const void* wsplit16h = nullptr; // dual-tile 4-wave kernel: [Cin/16][tap][Cout][hi16|lo16], lo UNSCALED, weights x 1/wscale_inv
+  float wscale_inv = 1.f;          // ... and the power of two the epilogue multiplies back
   const float* bias = nullptr;     // [Cout] or null
   int k = 3, dil = 1, pad = 1;
   int relu = 0;
@@ -47,6 +49,11 @@ struct ConvArgs {
   int nprod = 3;  // split-fp16 kernels: fp16 products formed per fp32 product -- 3 (hi*hi + hi*lo + lo*hi: fp32-class),
                   // 2 (drops a_lo*b_hi: activations effectively fp16) or 1 (hi*hi only: plain fp16 operands)
   int* range_flag = nullptr;  // split-fp16 kernels raise it when an output leaves the fp16 range (net.cpp: fp32 re-run)
+  // dual-tile family: a layer may take two launches (two tiles per block, then single tiles); the profiler wants one
+  // record per KERNEL: hook(ctx, 0, variant, share) before and hook(ctx, 1, ..) after each, variant = in_split * 4 +
+  // (rows == 8) * 2 + (tiles per block == 1), share = its fraction of the launch's pixel tiles
+  void (*sub_hook)(void* ctx, int after, int variant, double share) = nullptr;
+  void* sub_ctx = nullptr;
 };
 // which kernel class a conv will use: 0 = mfma implicit GEMM, 1 = first-layer direct (NCHW in), 2 = generic direct
 int conv_kernel_class(int Cin, int Cout, int k, int pad, int dil, bool in_nchw);
@@ -66,6 +73,10 @@ int conv_f16x3_w4_mt(const ConvArgs* as, int n);  // 4-wave kernel: 16-row (4) o
 int conv_f16x3_init_attributes();
 int launch_conv_f16x3_group(const ConvArgs* as, int n, hipStream_t s);
 size_t split16_conv_weight_halfs(int Cout, int Cin, int k);
+size_t split16h_conv_weight_halfs(int Cout, int Cin, int k);
+float pack_conv_weights_split16h(const float* w, int Cout, int Cin, int k, void* dst);  // returns 1 / scale
+bool conv_f16x3_group_is_dual(const ConvArgs* as, int n);
+bool conv_f16x3_w4_dual();  // two pixel tiles per block sharing every weight slab (SHF_F16X3_W4D)
 void pack_conv_weights_split16(const float* w, int Cout, int Cin, int k, void* dst);
 // first layer (64, 27) as the B operand of v_mfma_f32_32x32x16_f16: [n 2][kk 2][hi/lo 2][lane 64][8 halfs], K padded 27 -> 32
 constexpr size_t kFirstConvFragHalfs = 2 * 2 * 2 * 64 * 8;

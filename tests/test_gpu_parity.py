@@ -34,6 +34,18 @@ SCORE_TOL = 1e-4
 BOX_TOL = 1e-3
 
 
+def unmatched_rows(a, b, box_tol=0.05):
+    """Detections of `a` without a partner in `b` (score within SCORE_TOL, every coordinate within box_tol): rows are in
+    score order, and near-ties may swap between two arithmetic paths."""
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    n = 0
+    for row in a:
+        near = np.abs(b[:, 4] - row[4]) < SCORE_TOL
+        if not near.any() or np.abs(b[near, :4] - row[:4]).max(axis=1).min() >= box_tol:
+            n += 1
+    return n
+
+
 def conv_layer(name, bottom, nout, k, pad, dil=1, relu=True):
     s = ('layer { name: "%s" type: "Convolution" bottom: "%s" top: "%s" convolution_param { num_output: %d '
          'kernel_size: %d pad: %d dilation: %d } }\n' % (name, bottom, name, nout, k, pad, dil))
@@ -311,8 +323,10 @@ def test_detect_driver_vs_fused_vs_oracle(conv_mode):
             # north-star tolerances
             assert abs(dets[0].shape[0] - fused[0].shape[0]) <= 2
             n = min(dets[0].shape[0], fused[0].shape[0])
-            assert np.abs(np.asarray(dets[0])[:n, 4] - fused[0][:n, 4]).max() < SCORE_TOL
-            assert np.abs(np.asarray(dets[0])[:n, :4] - fused[0][:n, :4]).max() < 0.05
+            a, b = np.asarray(dets[0], dtype=np.float64), np.asarray(fused[0], dtype=np.float64)
+            assert np.abs(a[:n, 4] - b[:n, 4]).max() < SCORE_TOL
+            # (rows are in score order and near-ties may swap between the two paths: match each box to its partner)
+            assert unmatched_rows(a, b) <= 2
         assert dets[0].shape[0] > 0
         # units spread over 3 execution lanes (streams): same detections, same order
         laned = T.FusedDetector(gnet, n_lanes=3).detect(list(T.pyramid_units(im)), thresh=0.05)
@@ -461,8 +475,9 @@ def test_device_preprocessing_feeds_the_detector():
 def test_kernel_selection_knobs_do_not_change_results(tmp_path, conv_mode):
     """Every kernel-selection / data-format knob of the split-fp16 path is a pure performance choice: the
     detections of the fused path are bit-identical with the 4-wave kernel, the producer/consumer first pair,
-    the split activation format switched off one at a time and with the persistent 4-wave kernel... except the
-    first pair, whose conv1_1 runs on the matrix cores instead of the vector ALUs (tolerance)."""
+    the split activation format switched off, single tiles forced in the dual-tile family, the persistent form of the
+    older 4-wave kernel; kernels with another accumulation scheme (8-wave, pre-dual 4-wave, conv1_1 on the vector ALUs)
+    agree to fp32-class tolerance."""
     if conv_mode != "f16x3":
         pytest.skip("split-fp16 knobs")
     import os
@@ -486,7 +501,9 @@ np.save(sys.argv[1], fd.detect(list(T.pyramid_units(im)), thresh=0.05)[0])
     outs = {}
     for name, env in (("default", {}), ("no_split_act", {"SHF_F16X3_SPLIT_ACT": "0"}), ("no_w4", {"SHF_F16X3_W4": "0"}),
                       ("scalar_epilogue", {"SHF_CONV_SCALAR_EPILOGUE": "1", "SHF_F16X3_SPLIT_ACT": "0"}),
-                      ("persistent_w4", {"SHF_F16X3_W4P": "1"}), ("no_pc", {"SHF_F16X3_PC": "0"})):
+                      ("persistent_w4", {"SHF_F16X3_W4P": "1"}), ("single_tile", {"SHF_F16X3_W4D_NTILE": "1"}),
+                      ("old_w4", {"SHF_F16X3_W4D": "0"}), ("old_w4_persistent", {"SHF_F16X3_W4D": "0", "SHF_F16X3_W4P": "1"}),
+                      ("no_pc", {"SHF_F16X3_PC": "0"})):
         out = str(tmp_path / (name + ".npy"))
         e = dict(os.environ, PYTHONPATH=root, **env)
         r = subprocess.run([sys.executable, str(script), out], env=e, cwd=root, capture_output=True, text=True, timeout=600)
@@ -494,14 +511,19 @@ np.save(sys.argv[1], fd.detect(list(T.pyramid_units(im)), thresh=0.05)[0])
         outs[name] = np.load(out)
     assert len(outs["default"]) > 0
     # (the scalar epilogue also rules the producer/consumer first pair out: its twin is "no_pc")
-    bad = [(name, ref) for name, ref in (("no_split_act", "default"), ("no_w4", "default"), ("persistent_w4", "default"),
-                                         ("scalar_epilogue", "no_pc"))
+    # same arithmetic, different data path: bit-identical
+    bad = [(name, ref) for name, ref in (("no_split_act", "default"), ("persistent_w4", "default"), ("single_tile", "default"),
+                                         ("old_w4", "old_w4_persistent"))
            if outs[name].shape != outs[ref].shape or not np.array_equal(outs[name], outs[ref])]
     assert not bad, bad
-    a, b = outs["default"], outs["no_pc"]
-    assert abs(len(a) - len(b)) <= 2
-    n = min(len(a), len(b))
-    assert np.abs(a[:n, 4] - b[:n, 4]).max() < SCORE_TOL and np.abs(a[:n, :4] - b[:n, :4]).max() < 0.05
+    # other kernels for the same layers (8-wave two-accumulator arithmetic, the pre-dual 4-wave kernels, conv1_1 on the
+    # vector ALUs): fp32-class agreement
+    for name in ("no_w4", "scalar_epilogue", "old_w4", "no_pc"):
+        a, b = outs["default"], outs[name]
+        assert abs(len(a) - len(b)) <= 2, name
+        n = min(len(a), len(b))
+        assert np.abs(a[:n, 4] - b[:n, 4]).max() < SCORE_TOL, name
+        assert unmatched_rows(a, b) <= 2, name
 
 
 def test_full_bench_pyramid_properties(conv_mode):
