@@ -46,7 +46,9 @@ def test_committed_pmc_summary_and_layer_table():
     """profiles/r02_pmc.json (counter passes) and r02_layers.csv (one row per conv launch of an image) are what the
     roofline numbers can be recomputed from; the layer table covers the whole image's algorithmic work."""
     d = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc.json")))
-    k = [v for n, v in d["kernels"].items() if n.startswith("conv_mfma_f16x3_w4_kernel<true")][0]
+    dom = json.load(open(os.path.join(ROOT, "profiles", "r02_bench.json")))["roofline"]["kernel"]
+    assert dom.startswith("conv_mfma_f16x3_w4")     # a 4-wave split-fp16 kernel (the dual-tile family since round 2)
+    k = d["kernels"][dom]
     for key in ("hbm_bytes_per_launch", "mfma_busy", "effective_clock_ghz", "lds_bank_conflict_frac", "avg_us"):
         assert key in k, key
     assert 0.0 < k["mfma_busy"] <= 1.0

@@ -173,19 +173,39 @@ def main():
     a = pcs[-1]
     conv_idx = [i for i in range(a, len(names)) if "conv_mfma" in names[i]]
     layers = conv_layers_of_the_bench_image()
-    conv_idx = conv_idx[:len(layers)]
+    # A layer of the dual-tile family may be TWO consecutive launches: two tiles per block for the whole rounds, then
+    # single tiles for the rest (same <IN_SPLIT, rows>).  Merge such pairs while there are more dispatches than layers.
+    import re
+    def w4d(n):
+        m = re.search(r"w4d_kernel<(\w+), (\d), (\d), (\d)>", n)
+        return None if m is None else (m.group(1), m.group(2), int(m.group(3)))
+    groups, j = [], 0
+    while j < len(conv_idx) and len(groups) < len(layers):
+        i = conv_idx[j]
+        left_d, left_l = len(conv_idx) - j, len(layers) - len(groups)
+        a_, b_ = w4d(names[i]), w4d(names[conv_idx[j + 1]]) if j + 1 < len(conv_idx) else None
+        if a_ and b_ and a_[2] == 2 and b_[2] == 1 and a_[:2] == b_[:2] and left_d > left_l:
+            groups.append([i, conv_idx[j + 1]])
+            j += 2
+        else:
+            groups.append([i])
+            j += 1
+    def gsum(c, g):
+        v = [cval(c, i) for i in g]
+        return None if any(x is None for x in v) else sum(v)
     rows = []
-    for (lname, cin, cout, k, px, fl), i in zip(layers, conv_idx):
-        us = dur[i]
+    for (lname, cin, cout, k, px, fl), g in zip(layers, groups):
+        i = g[0]
+        us = sum(dur[x] for x in g)
         tf = fl / (us * 1e-6) / 1e12
         alg_bytes = 4.0 * px * (cin + cout)   # input + output once, 4 B per element (weights: < 10 MB, L2-resident)
         hbm = None
-        if cval("FETCH_SIZE", i) is not None and cval("WRITE_SIZE", i) is not None:
-            hbm = (2.0 * cval("FETCH_SIZE", i) + cval("WRITE_SIZE", i)) * 1024.0
+        if gsum("FETCH_SIZE", g) is not None and gsum("WRITE_SIZE", g) is not None:
+            hbm = (2.0 * gsum("FETCH_SIZE", g) + gsum("WRITE_SIZE", g)) * 1024.0
         busy = None
-        if cval("SQ_VALU_MFMA_BUSY_CYCLES", i) is not None and cval("GRBM_GUI_ACTIVE", i):
-            busy = cval("SQ_VALU_MFMA_BUSY_CYCLES", i) / (cval("GRBM_GUI_ACTIVE", i) / N_XCD * N_SIMD * N_CU)
-        rows.append({"layer": lname, "kernel": short(names[i]), "cin": cin, "cout": cout, "k": k, "pixels": px,
+        if gsum("SQ_VALU_MFMA_BUSY_CYCLES", g) is not None and gsum("GRBM_GUI_ACTIVE", g):
+            busy = gsum("SQ_VALU_MFMA_BUSY_CYCLES", g) / (gsum("GRBM_GUI_ACTIVE", g) / N_XCD * N_SIMD * N_CU)
+        rows.append({"layer": lname, "kernel": " + ".join(short(names[x]) for x in g), "cin": cin, "cout": cout, "k": k, "pixels": px,
                      "us": round(us, 1), "algorithmic_gflop": round(fl / 1e9, 2), "algorithmic_tflops": round(tf, 1),
                      "frac_of_fp16_peak": round(tf / PEAK_F16, 4), "frac_issued": round(3.0 * tf / PEAK_F16, 4),
                      "mfma_busy": None if busy is None else round(busy, 4),
