@@ -1365,7 +1365,8 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4d_kernel(ConvK p) {
   constexpr int KC = 16, ROWB = 80, ROWPAD = 224, BN = 128, NT = 256;
   constexpr int HPITCH = HTW * ROWB + ROWPAD;        // 1664 B per halo-tile row
   constexpr int AS_B = HTH * HPITCH;                  // 29 952 B per halo tile
-  constexpr int SLAB_B = BN * ROWB;                   // 10 240 B per tap slab
+  constexpr int WROWB = 64;                           // weight rows: no padding, the 16-byte pieces rotated by row / 4
+  constexpr int SLAB_B = BN * WROWB;                  // 8 192 B per tap slab
   constexpr int ALD = (HP * 4 + NT - 1) / NT;         // 16-byte halo pieces per thread and tile: 6 (16 rows) or 3
   constexpr float LO_SCALE = 2048.0f;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1401,8 +1402,8 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4d_kernel(ConvK p) {
 
   const int nchunks = p.Cin / KC;
   const int NST = nchunks * 3;
-  const size_t slab = (size_t)p.Cout * 40;            // halfs per tap slab of the whole layer
-  const _Float16* wbase = (const _Float16*)p.wph + (size_t)ct * BN * 40;
+  const size_t slab = (size_t)p.Cout * 32;            // halfs per tap slab of the whole layer
+  const _Float16* wbase = (const _Float16*)p.wph + (size_t)ct * BN * 32;
 
   // halo piece j of this thread (per tile): 16-byte piece q = idx & 3 of halo pixel idx >> 2, idx = tid + 256 j.
   //   split input : q = 0, 1: hi channels 0-7 / 8-15 of the 16-channel half chunk; q = 2, 3: lo (scaled by 2^11 in HBM)
@@ -1469,22 +1470,14 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4d_kernel(ConvK p) {
     }
   };
 
-  // weight DMA: round r (0..7) of a wave moves 1-KiB piece q = wave + 4 r of the stage's 30 (piece 29 again for waves
-  // 2, 3 in the last round).  LDS offset = q KiB; global offset = slab (q / 10) + (q % 10) KiB: compile-time per round
-  // except round 2, where waves 0, 1 are still in slab 0 (pieces 8, 9) and waves 2, 3 in slab 1 (pieces 10, 11).
-  constexpr int W_ROUNDS = 8;
+  // weight DMA: round r (0..5) of a wave moves 1-KiB piece q = wave + 4 r of the stage's 24 (8 per tap slab: rounds
+  // 0-1 / 2-3 / 4-5 are slabs 0 / 1 / 2 for every wave).  LDS offset = q KiB; global offset = slab (q / 8) + (q % 8) KiB.
+  constexpr int W_ROUNDS = 6;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const unsigned lane16 = (unsigned)lane * 16u;
   const size_t slab_b = slab * 2;
-  const size_t goff_r2 = wave_u < 2 ? (size_t)(8 + wave_u) * 1024 : slab_b + (size_t)(wave_u - 2) * 1024;
-  const int q_r7 = wave_u < 2 ? 28 + wave_u : 29;
-  auto w_goff = [&](int r) -> size_t {
-    if (r == 2) return goff_r2;
-    if (r == 7) return 2 * slab_b + (size_t)(q_r7 - 20) * 1024;
-    const int sl = (4 * r) / 10;
-    return (size_t)sl * slab_b + (size_t)(4 * r - 10 * sl + wave_u) * 1024;
-  };
-  auto w_loff = [&](int r) { return (r == 7 ? q_r7 : 4 * r + wave_u) * 1024; };
+  auto w_goff = [&](int r) -> size_t { return (size_t)(r >> 1) * slab_b + (size_t)(4 * (r & 1) + wave_u) * 1024; };
+  auto w_loff = [&](int r) { return (4 * r + wave_u) * 1024; };
   auto dma_w = [&](int stage, int buf, int r0, int n) {
     const unsigned char* ws_ = (const unsigned char*)(wbase + (size_t)stage * 3 * slab);
     unsigned char* bd_ = Bs + buf * (3 * SLAB_B);
@@ -1514,7 +1507,8 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4d_kernel(ConvK p) {
 #pragma unroll
   for (int t = 0; t < MT; ++t) a_off[t] = (wm * 2 * MT + t * 2 + dy) * HPITCH + px * ROWB + kh * 16;
 #pragma unroll
-  for (int t = 0; t < 2; ++t) b_off[t] = (wn * 64 + t * 32 + i) * ROWB + kh * 16;
+  for (int t = 0; t < 2; ++t)   // the lane's hi piece (the lo piece sits two rotated positions further: b_off ^ ... below)
+    b_off[t] = (wn * 64 + t * 32 + i) * WROWB + ((kh + ((wn * 64 + t * 32 + i) >> 2)) & 3) * 16;
   f32x16 acc0[MT][2], acc1[MT][2];
 #pragma unroll
   for (int a = 0; a < MT; ++a)
@@ -1540,9 +1534,15 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4d_kernel(ConvK p) {
   // convert and park both halo tiles of chunk c + 1
   auto stage = [&](int c, auto KY_, auto HAND_) {
     constexpr int ky = decltype(KY_)::value;
+#ifdef F16X3_EXPERIMENT_NO_HANDOVER   // timing only (WRONG results)
+    constexpr bool HANDOVER = false;
+#else
     constexpr bool HANDOVER = decltype(HAND_)::value != 0;
+#endif
     const int st = c * 3 + ky;
+#ifndef F16X3_EXPERIMENT_NO_WAIT   // timing only (racy weights): what waiting for the weight DMA costs
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of W(st) has landed
+#endif
     __syncthreads();
     const int st_next = st + 1 < NST ? st + 1 : st;   // the last stage re-fetches itself (unused) instead of branching
     const int buf_next = (st + 1) & 1;
@@ -1562,7 +1562,7 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4d_kernel(ConvK p) {
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         bf[2 * t] = *(const half8*)(Bp + b_off[t]);
-        bf[2 * t + 1] = *(const half8*)(Bp + b_off[t] + 32);
+        bf[2 * t + 1] = *(const half8*)(Bp + (b_off[t] ^ 32));   // (piece + 2) mod 4 within the 64-byte row
       }
     };
     load_a(0, fa[0]);
@@ -1571,15 +1571,20 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4d_kernel(ConvK p) {
     constexpr int NH = 3 * NTILE;                     // half-steps per stage
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
-      constexpr int DMA_N2[6] = {2, 2, 2, 2, 0, 0}, DMA_N1[3] = {3, 3, 2}, DMA_J1[3] = {0, 3, 6};
-      const int dma_n = NTILE == 2 ? DMA_N2[h] : DMA_N1[h], dma_j = NTILE == 2 ? 2 * h : DMA_J1[h];
+      constexpr int DMA_N2[6] = {1, 1, 1, 1, 1, 1}, DMA_J2[6] = {0, 1, 2, 3, 4, 5};
+      constexpr int DMA_N1[3] = {2, 2, 2}, DMA_J1[3] = {0, 2, 4};
+      const int dma_n = NTILE == 2 ? DMA_N2[h] : DMA_N1[h], dma_j = NTILE == 2 ? DMA_J2[h] : DMA_J1[h];
       const int kx = h / NTILE, tl = h % NTILE;
       half8* a = fa[h & 1];
       half8* bf = fb[kx & 1];
       int n_ds = 0;
       if (h + 1 < NH) { load_a(h + 1, fa[(h + 1) & 1]); n_ds += 2 * MT; }
       if (tl == 0 && kx + 1 < 3) { load_b(kx + 1, fb[(kx + 1) & 1]); n_ds += 4; }
+#if defined(F16X3_EXPERIMENT_ONE_DMA)   // timing only (WRONG results): one round per stage
+      if (h == 0) dma_w(st_next, buf_next, 0, 1);
+#elif !defined(F16X3_EXPERIMENT_NO_DMA)   // timing only (WRONG results)
       if (dma_n) dma_w(st_next, buf_next, dma_j, dma_n);
+#endif
       int n_vmem = dma_n;
       if constexpr (HANDOVER) {
         // tile 0's / tile 1's pieces of the next chunk are requested in the first half-steps (converted and parked
@@ -1696,7 +1701,9 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4d_kernel(ConvK p) {
     tile_out(acc0, g0, true);
     if constexpr (NTILE == 2) tile_out(acc1, g1, has1);
   }
+#if !defined(F16X3_EXPERIMENT_NO_DMA) && !defined(F16X3_EXPERIMENT_NO_HANDOVER) && !defined(F16X3_EXPERIMENT_NO_WAIT) && !defined(F16X3_EXPERIMENT_ONE_DMA)
   conv_raise_range_flag(p.range_flag, amax);
+#endif
 }
 
 // Producer / consumer variant of the fused first pair (conv1_1 -> conv1_2, Cin = Cout = 64).  With only
@@ -2000,9 +2007,12 @@ void pack_conv_weights_split16(const float* w, int Cout, int Cin, int k, void* d
       }
 }
 
-size_t split16h_conv_weight_halfs(int Cout, int Cin, int k) { return (size_t)Cout * (Cin / 16) * k * k * 40; }
+size_t split16h_conv_weight_halfs(int Cout, int Cin, int k) { return (size_t)Cout * (Cin / 16) * k * k * 32; }
 
-// (Cout,Cin,3,3) fp32 -> [Cin/16][ky][kx][Cout][hi 16 | lo 16 | 8 pad] fp16 (80-B rows = the dual-tile kernel's LDS image).
+// (Cout,Cin,3,3) fp32 -> [Cin/16][ky][kx][Cout][4 x 8 halfs] fp16: 64-B rows, NO padding (every byte of the pack is
+// fetched by every block: padding is weight traffic) = the dual-tile kernel's LDS image.  The four 16-byte pieces of a row
+// -- hi k 0-7, hi k 8-15, lo k 0-7, lo k 8-15 -- are rotated by (row / 4) mod 4 so that the 16 lanes of a ds_read_b128
+// group (16 consecutive rows, one piece each) still fall on 16 different bank groups.
 // lo is NOT scaled here: lo = fp16(w s - hi) with one power of two s per layer that lifts the weights to [8, 16) at the top,
 // so that the low parts of all but the tiniest weights are normal fp16 numbers (the MFMA honours subnormals anyway:
 // tools/mfma_denorm.hip) and the three products share one accumulator.  Returns 1 / s for the epilogue.
@@ -2022,9 +2032,10 @@ float pack_conv_weights_split16h(const float* w, int Cout, int Cin, int k, void*
         const float x = w[((size_t)co * Cin + ci) * taps + t] * s;
         const _Float16 h = (_Float16)x;
         const _Float16 l = (_Float16)(x - (float)h);
-        const size_t row = (((size_t)(ci / 16) * taps + t) * Cout + co) * 40;
-        dst[row + (ci % 16)] = h;
-        dst[row + 16 + (ci % 16)] = l;
+        const size_t row = (((size_t)(ci / 16) * taps + t) * Cout + co) * 32;
+        const int kk = ci % 16, rot = ((co & 127) >> 2) & 3;
+        dst[row + (((kk >> 3) + rot) & 3) * 8 + (kk & 7)] = h;
+        dst[row + ((2 + (kk >> 3) + rot) & 3) * 8 + (kk & 7)] = l;
       }
   return 1.0f / s;
 }
@@ -2228,7 +2239,7 @@ static int launch_f16x3_t(const ConvArgs* as, int n, hipStream_t s) {
       if (force == 1) n2 = 0;
       if (force == 2) n2 = tiles;
       const size_t as_b = (size_t)(th + 2) * (18 * 80 + 224);
-      const size_t lds1 = as_b + 2 * 3 * (size_t)BN * 80 + BN * sizeof(float), lds2 = lds1 + as_b;
+      const size_t lds1 = as_b + 2 * 3 * (size_t)BN * 64 + BN * sizeof(float), lds2 = lds1 + as_b;
 #define SHF_W4D_LAUNCH(SPLIT, MTV, NTV, GRID, LDS)                                                                        \
       {                                                                                                                    \
         if (a.nprod >= 3) hipLaunchKernelGGL((conv_mfma_f16x3_w4d_kernel<SPLIT, MTV, NTV, 3>), GRID, dim3(256), LDS, s, p);    \
