@@ -13,12 +13,14 @@
 // epilogue (ConvArgs::in_split / out_split) -- and weights are split once at load time.  Every MFMA convolution
 // of the detector runs here in the split-fp16 modes: 3x3 at dilation 1, 2, 4 and the 1x1s.
 //
-// Kernels: conv_mfma_f16x3_w4_kernel (4 waves, one per SIMD: Cin >= 128, Cout % 128 == 0 -- 70 % of the time),
+// Kernels: conv_mfma_f16x3_w4d_kernel (the dual-tile 4-wave family: Cin >= 128, Cout % 128 == 0 -- 70 % of the time;
+// conv_mfma_f16x3_w4_kernel is its single-tile, two-accumulator predecessor, SHF_F16X3_W4D=0),
 // conv_mfma_f16x3_pc_kernel (fused first pair conv1_1 -> conv1_2, producer/consumer waves) and the 8-wave
 // conv_mfma_f16x3_kernel below (Cin 64, dilated heads, 1x1).  Common structure: tile 256 px (16x16) x BN couts; a
 // STAGE is one kernel row (3 taps) of one 32-channel chunk: its three BNx32 weight slabs are double-buffered in
 // LDS and arrive by LDS DMA; the 18x18x32 halo tile is staged once per chunk and reused by all 9 taps.  LDS rows
 // are [hi: 32 halfs][lo: 32 halfs][16 B pad] = 144 B (conflict-free ds_read_b128 over consecutive rows).
+// (The dual-tile family has its own geometry: 16-channel chunks, 64 / 80-byte rows, unscaled low parts -- see its header.)
 // Epilogues: the 4-wave kernels run the MFMA as D[cout][pixel] and store from registers (conv_epilogue_regs); the
 // 8-wave and fused-pair kernels run D[pixel][cout] and transpose the tile through LDS (conv_stage_tile / conv_flush_tile).
 // conv_mfma_f16x3_w4p_kernel is the persistent (block walks tiles) form of the 4-wave kernel: off by default
