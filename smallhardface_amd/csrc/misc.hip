@@ -5,6 +5,7 @@
 //   concat              caffe/src/caffe/layers/concat_layer.cu (zero-copy here: producers write channel slices)
 //   NCHW<->NHWC         the host-visible Blob.data layout (caffe/python/caffe/_caffe.cpp:222-242)
 #include <algorithm>
+#include <type_traits>
 
 #include "shf_internal.h"
 
@@ -106,34 +107,83 @@ struct DeconvGK {
   const float* w;
   const float* bias;
   int* range_flag;
+  int rows_per_block;
   DeconvGM m[16];
 };
+// K4S2P1: the detector's only deconvolution (kernel 4, stride 2, pad 1: exact 2x upsampling) with the tap geometry
+// resolved at compile time -- output row oy takes input rows (oy + 1) / 2 - 1 + {0, 1} with taps (oy + 1) % 2 + {2, 0}
+template <bool K4S2P1>
 __global__ void deconv_dw_group_kernel(DeconvGK g) {
   int mi = 0;
 #pragma unroll
   for (int q = 1; q < 16; ++q) mi += (q < g.n && (int)blockIdx.y >= g.m[q].row_start) ? 1 : 0;
   const DeconvGM& p = g.m[mi];
-  const int oy = (int)blockIdx.y - p.row_start;
   const unsigned C4 = (unsigned)g.C >> 2;
   const unsigned n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= (unsigned)p.Wo * C4) return;
   const int c4 = (int)(n % C4), ox = (int)(n / C4);
-  const int k = g.k, stride = g.stride, pad = g.pad;
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int a = (oy + pad) % stride; a < k; a += stride) {
-    const int ty = oy + pad - a;
-    if (ty < 0) break;
-    const int iy = ty / stride;
-    if (iy >= p.H) continue;
-    for (int bb = (ox + pad) % stride; bb < k; bb += stride) {
-      const int tx = ox + pad - bb;
-      if (tx < 0) break;
-      const int ix = tx / stride;
-      if (ix >= p.W) continue;
-      const float4 v = *(const float4*)(p.in + ((size_t)iy * p.W + ix) * p.in_stride + c4 * 4);
-      const float vv[4] = {v.x, v.y, v.z, v.w};
+  // the thread's 4 channels x 16 taps, fetched ONCE for all its rows (re-fetching them per output pixel was 1.8 GB of
+  // cache traffic per image: the whole cost of this kernel)
+  float wv[4][16];
+  if constexpr (K4S2P1) {
+    const float4* wq = (const float4*)(g.w + (size_t)c4 * 4 * 16);   // 16-byte aligned (launcher)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[j] = fmaf(vv[j], g.w[((size_t)(c4 * 4 + j) * k + a) * k + bb], acc[j]);
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 t = wq[j * 4 + q];
+        wv[j][4 * q] = t.x; wv[j][4 * q + 1] = t.y; wv[j][4 * q + 2] = t.z; wv[j][4 * q + 3] = t.w;
+      }
+  }
+  // a block does g.rows_per_block output rows (the launch is bound by the block dispatch rate otherwise: ~8 ns per
+  // 256-thread block of one row)
+  for (int oy = ((int)blockIdx.y - p.row_start) * g.rows_per_block, oy_end = min(oy + g.rows_per_block, p.Ho); oy < oy_end; ++oy) {
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  if constexpr (K4S2P1) {
+    // the generic loop below visits the taps in rising a (falling input row), rising bb: the same order here
+    const int a0 = (oy + 1) & 1, b0 = (ox + 1) & 1;
+    // (a0, b0) are wave-uniform (a wave is one output pixel x 64 channel quads): four straight-line variants with
+    // compile-time tap indices instead of a register-array lookup
+    auto taps = [&](auto A0_, auto B0_) {
+      constexpr int A0 = decltype(A0_)::value, B0 = decltype(B0_)::value;
+#pragma unroll
+      for (int da = 0; da < 2; ++da) {
+        constexpr int dummy = 0; (void)dummy;
+        const int a = A0 + 2 * da, iy = (oy + 1 - a) >> 1;
+        if (oy + 1 - a < 0 || iy >= p.H) continue;
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+          const int bb = B0 + 2 * db, ix = (ox + 1 - bb) >> 1;
+          if (ox + 1 - bb < 0 || ix >= p.W) continue;
+          const float4 v = *(const float4*)(p.in + ((size_t)iy * p.W + ix) * p.in_stride + c4 * 4);
+          const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[j] = fmaf(vv[j], wv[j][(A0 + 2 * da) * 4 + B0 + 2 * db], acc[j]);
+        }
+      }
+    };
+    using std::integral_constant;
+    if (a0 == 0 && b0 == 0) taps(integral_constant<int, 0>{}, integral_constant<int, 0>{});
+    else if (a0 == 0) taps(integral_constant<int, 0>{}, integral_constant<int, 1>{});
+    else if (b0 == 0) taps(integral_constant<int, 1>{}, integral_constant<int, 0>{});
+    else taps(integral_constant<int, 1>{}, integral_constant<int, 1>{});
+  } else {
+    const int k = g.k, stride = g.stride, pad = g.pad;
+    for (int a = (oy + pad) % stride; a < k; a += stride) {
+      const int ty = oy + pad - a;
+      if (ty < 0) break;
+      const int iy = ty / stride;
+      if (iy >= p.H) continue;
+      for (int bb = (ox + pad) % stride; bb < k; bb += stride) {
+        const int tx = ox + pad - bb;
+        if (tx < 0) break;
+        const int ix = tx / stride;
+        if (ix >= p.W) continue;
+        const float4 v = *(const float4*)(p.in + ((size_t)iy * p.W + ix) * p.in_stride + c4 * 4);
+        const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = fmaf(vv[j], g.w[((size_t)(c4 * 4 + j) * k + a) * k + bb], acc[j]);
+      }
     }
   }
   if (g.bias)
@@ -141,6 +191,7 @@ __global__ void deconv_dw_group_kernel(DeconvGK g) {
   *(float4*)(p.out + ((size_t)oy * p.Wo + ox) * p.out_stride + c4 * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
   if (g.range_flag && !(fmaxf(fmaxf(fabsf(acc[0]), fabsf(acc[1])), fmaxf(fabsf(acc[2]), fabsf(acc[3]))) <= 65504.0f))
     atomicOr(g.range_flag, 1);
+  }
 }
 
 int launch_deconv_depthwise_group(const View* ins, const View* outs, int n, const float* w, const float* bias, int k,
@@ -149,6 +200,7 @@ int launch_deconv_depthwise_group(const View* ins, const View* outs, int n, cons
   DeconvGK g;
   g.n = n; g.C = ins[0].C; g.k = k; g.stride = stride; g.pad = pad;
   g.w = w; g.bias = bias; g.range_flag = range_flag;
+  g.rows_per_block = 8;
   int rows = 0;
   unsigned per_row_max = 1;
   for (int i = 0; i < n; ++i) {
@@ -163,10 +215,13 @@ int launch_deconv_depthwise_group(const View* ins, const View* outs, int n, cons
     m.H = in.H; m.W = in.W; m.Ho = out.H; m.Wo = out.W;
     m.in_stride = in.cstride; m.out_stride = out.cstride;
     m.row_start = rows;
-    rows += out.H;
+    rows += (out.H + g.rows_per_block - 1) / g.rows_per_block;
     per_row_max = std::max(per_row_max, ((unsigned)out.W * (unsigned)(in.C / 4) + 255) / 256);
   }
-  hipLaunchKernelGGL(deconv_dw_group_kernel, dim3(per_row_max, rows, 1), dim3(256), 0, s, g);
+  if (k == 4 && stride == 2 && pad == 1 && (((uintptr_t)w) & 15) == 0)
+    hipLaunchKernelGGL(deconv_dw_group_kernel<true>, dim3(per_row_max, rows, 1), dim3(256), 0, s, g);
+  else
+    hipLaunchKernelGGL(deconv_dw_group_kernel<false>, dim3(per_row_max, rows, 1), dim3(256), 0, s, g);
   SHF_HIP_OK(hipGetLastError());
   return 0;
 }
