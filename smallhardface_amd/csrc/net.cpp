@@ -462,6 +462,9 @@ struct shf_net {
   int tail_gen = -1;
   hipEvent_t ev_mark = nullptr, ev_side_a = nullptr, ev_side_b = nullptr;
   hipEvent_t ev_logits = nullptr;  // recorded by every fused tail pass right after its logits kernel
+  hipEvent_t logits_done = nullptr;  // (not owned) what a later pass over this member waits for: its own ev_logits, or --
+                                     // after a pipelined grouped pass -- the head's ev_convs (ONE record for the group:
+                                     // ten event records in a row were ~90 us of idle conv stream per image)
   hipEvent_t ev_convs = nullptr;   // group pass: recorded on the head's stream after the last layer before the tails
   shf_net* pred = nullptr;         // shf_net_set_predecessor: the head lane whose image precedes this one's
   bool pipelined = false;   // shf_net_set_pipeline: convolutions go to sh->conv_stream, the rest stays on `stream`
@@ -1238,6 +1241,7 @@ void shf_net::forward_ops(bool fused_path, float im_h, float im_w, float im_scal
         CHECK_RC(launch_tail(t, tw, (float*)blobs[boxes_blob].dev.p,
                              prob_blob >= 0 ? (float*)blobs[prob_blob].dev.p : (float*)tw_rec.p, st,
                              fused_path ? ev_logits : nullptr, 0));
+        if (fused_path) logits_done = ev_logits;
         break;
       }
     }
@@ -1742,8 +1746,8 @@ int shf_detect_add_levels(shf_net* net, int n, shf_net** members, const float* c
   const bool early_start = !shared && net->pred && net->pred->ev_convs && first_feat_writer < (int)net->layers.size();
   if (early_start) HIP_THROW(hipStreamWaitEvent(net->stream, net->pred->ev_convs, 0));
   for (int m = 0; m < n; ++m) {
-    if (!shared && !early_start && members[m]->ev_logits)
-      HIP_THROW(hipStreamWaitEvent(net->stream, members[m]->ev_logits, 0));
+    if (!shared && !early_start && members[m]->logits_done)
+      HIP_THROW(hipStreamWaitEvent(net->stream, members[m]->logits_done, 0));
     members[m]->prepare_unit(data[m], data_on_device, H[m], W[m], cs);
   }
   if (shared && !per_member_lists) HIP_THROW(hipMemsetAsync(net->range_flag.p, 0, 4, cs));  // (detect_begin zeroes it on the head's stream)
@@ -1818,7 +1822,7 @@ int shf_detect_add_levels(shf_net* net, int n, shf_net** members, const float* c
     Layer& L = net->layers[li];
     if (early_start && (int)li == first_feat_writer)
       for (int m = 0; m < n; ++m)
-        if (members[m]->ev_logits) HIP_THROW(hipStreamWaitEvent(net->stream, members[m]->ev_logits, 0));
+        if (members[m]->logits_done) HIP_THROW(hipStreamWaitEvent(net->stream, members[m]->logits_done, 0));
     if (L.op == OP_SKIP) continue;
     if (side_j >= 0 && (int)li == side_e) {
       // an independent 1x1 branch (conv4_256 reads conv4_3, nothing before conv4_fuse needs it): on a side stream,
@@ -1900,8 +1904,13 @@ int shf_detect_add_levels(shf_net* net, int n, shf_net** members, const float* c
       }
       for (int m = 0; m < n; ++m) {  // hand-over mark for passes issued from another head without a pipeline
         shf_net* mb = members[m];
+        if (shared) {
+          mb->logits_done = net->ev_convs;   // recorded on the conv stream right after the logits launch above
+          continue;
+        }
         if (!mb->ev_logits) HIP_THROW(hipEventCreateWithFlags(&mb->ev_logits, hipEventDisableTiming));
-        HIP_THROW(hipEventRecord(mb->ev_logits, shared ? cs : net->stream));
+        HIP_THROW(hipEventRecord(mb->ev_logits, net->stream));
+        mb->logits_done = mb->ev_logits;
       }
       {
         ProfScope ps(net->prof, net->stream, PC_TAIL, 0, 0);
