@@ -56,9 +56,9 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_f32_kernel(ConvK p) {
   const int mi = conv_find_member(p, pt);
   const ConvMember& mem = p.m[mi];
   pt -= mem.tile_start;
-  const int b = pt / mem.tiles_per_img;
-  pt -= b * mem.tiles_per_img;
-  const int ty0 = (pt / mem.tiles_x) * TH, tx0 = (pt % mem.tiles_x) * TW;
+  int b, ty_, tx_;
+  conv_split_tile(mem, pt, b, ty_, tx_);
+  const int ty0 = ty_ * TH, tx0 = tx_ * TW;
   const int H = mem.H, W = mem.W;
   const float* __restrict__ gin = mem.in;
   float* __restrict__ gout = mem.out;
@@ -404,6 +404,8 @@ static int launch_mfma_t(const ConvArgs* as, int n, hipStream_t s) {
     m.B = q.in.B; m.H = q.in.H; m.W = q.in.W;
     m.tiles_x = (m.W + TW - 1) / TW;
     m.tiles_per_img = m.tiles_x * ((m.H + TH - 1) / TH);
+    m.inv_tiles_x = conv_inv32(m.tiles_x);
+    m.inv_tiles_per_img = conv_inv32(m.tiles_per_img);
     m.tile_start = (int)tiles;
     p.tile_starts[i] = (int)tiles;
     tiles += (long long)m.tiles_per_img * m.B;

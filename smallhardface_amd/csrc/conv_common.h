@@ -17,6 +17,7 @@ struct ConvMember {
   float* pool;       // fused 2x2/2 max-pool output (ceil(H/2) x ceil(W/2) x Cout, NHWC) or null
   int B, H, W;
   int tiles_x, tiles_per_img, tile_start;  // tile_start: first pixel-tile index of this member
+  unsigned inv_tiles_x, inv_tiles_per_img; // floor(2^32 / d) + 1: a tile index is split with two multiply-highs, not divisions
 };
 
 struct ConvK {
@@ -53,6 +54,18 @@ __device__ __forceinline__ int conv_find_member(const ConvK& p, int pt) {
   for (int q = 1; q < MAX_GROUP; ++q) mi += (pt >= p.tile_starts[q]) ? 1 : 0;
   return mi;
 }
+
+// pixel tile `pt` of a member -> image b, tile row ty, tile column tx.  Integer division on the scalar unit is a
+// ~40-instruction float sequence (two of them were ~1.5 k cycles of every block's prologue); n / d = umulhi(n, floor(2^32
+// / d) + 1) is exact while n * d < 2^32 (tile counts are < 2^20).
+__device__ __forceinline__ unsigned conv_div(unsigned n, unsigned d, unsigned inv) { return d == 1 ? n : __umulhi(n, inv); }
+__device__ __forceinline__ void conv_split_tile(const ConvMember& mem, int pt, int& b, int& ty, int& tx) {
+  b = (int)conv_div((unsigned)pt, (unsigned)mem.tiles_per_img, mem.inv_tiles_per_img);
+  pt -= b * mem.tiles_per_img;
+  ty = (int)conv_div((unsigned)pt, (unsigned)mem.tiles_x, mem.inv_tiles_x);
+  tx = pt - ty * mem.tiles_x;
+}
+inline unsigned conv_inv32(int d) { return d <= 1 ? 0u : (unsigned)((1ull << 32) / (unsigned long long)d) + 1u; }
 
 __device__ __forceinline__ void row_to_pixel(int i, int& dy, int& px) {
   dy = (i >> 1) & 1;

@@ -146,9 +146,9 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_kernel(ConvK p) {
   const int mi = conv_find_member(p, pt);
   const ConvMember& mem = p.m[mi];
   pt -= mem.tile_start;
-  const int b = pt / mem.tiles_per_img;
-  pt -= b * mem.tiles_per_img;
-  const int ty0 = (pt / mem.tiles_x) * TH, tx0 = (pt % mem.tiles_x) * TW;
+  int b, ty_, tx_;
+  conv_split_tile(mem, pt, b, ty_, tx_);
+  const int ty0 = ty_ * TH, tx0 = tx_ * TW;
   const int H = mem.H, W = mem.W;
   const float* __restrict__ gin = mem.in;
   float* __restrict__ gout = mem.out;
@@ -507,9 +507,9 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4_kernel(ConvK p) {
   const int mi = conv_find_member(p, pt);
   const ConvMember& mem = p.m[mi];
   pt -= mem.tile_start;
-  const int b = pt / mem.tiles_per_img;
-  pt -= b * mem.tiles_per_img;
-  const int ty0 = (pt / mem.tiles_x) * TH, tx0 = (pt % mem.tiles_x) * TW;
+  int b, ty_, tx_;
+  conv_split_tile(mem, pt, b, ty_, tx_);
+  const int ty0 = ty_ * TH, tx0 = tx_ * TW;
   const int H = mem.H, W = mem.W;
   const float* __restrict__ gin = mem.in;
   float* __restrict__ gout = mem.out;
@@ -1038,10 +1038,10 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4p_kernel(ConvK p) {
     const int mi = conv_find_member(p, pt);
     const ConvMember& mem = p.m[mi];
     pt -= mem.tile_start;
-    g.b = pt / mem.tiles_per_img;
-    pt -= g.b * mem.tiles_per_img;
-    g.ty0 = (pt / mem.tiles_x) * TH;
-    g.tx0 = (pt % mem.tiles_x) * TW;
+    int ty_, tx_;
+    conv_split_tile(mem, pt, g.b, ty_, tx_);
+    g.ty0 = ty_ * TH;
+    g.tx0 = tx_ * TW;
     g.H = mem.H; g.W = mem.W;
     g.in = mem.in; g.out = mem.out; g.pool = mem.pool;
     return g;
@@ -1390,10 +1390,10 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4d_kernel(ConvK p) {
     const int mi = conv_find_member(p, pt);
     const ConvMember& mem = p.m[mi];
     pt -= mem.tile_start;
-    g.b = pt / mem.tiles_per_img;
-    pt -= g.b * mem.tiles_per_img;
-    g.ty0 = (pt / mem.tiles_x) * TH;
-    g.tx0 = (pt % mem.tiles_x) * TW;
+    int ty_, tx_;
+    conv_split_tile(mem, pt, g.b, ty_, tx_);
+    g.ty0 = ty_ * TH;
+    g.tx0 = tx_ * TW;
     g.H = mem.H; g.W = mem.W;
     g.in = mem.in; g.out = mem.out; g.pool = mem.pool;
     return g;
@@ -1750,9 +1750,9 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
   const int mi = conv_find_member(p, pt);
   const ConvMember& mem = p.m[mi];
   pt -= mem.tile_start;
-  const int b = pt / mem.tiles_per_img;
-  pt -= b * mem.tiles_per_img;
-  const int ty0 = (pt / mem.tiles_x) * TH, tx0 = (pt % mem.tiles_x) * TW;
+  int b, ty_, tx_;
+  conv_split_tile(mem, pt, b, ty_, tx_);
+  const int ty0 = ty_ * TH, tx0 = tx_ * TW;
   const int H = mem.H, W = mem.W;
   float* __restrict__ gout = mem.out;
 #ifdef SHF_CONV_TIMING
@@ -2181,6 +2181,8 @@ static int launch_f16x3_t(const ConvArgs* as, int n, hipStream_t s) {
     m.B = q.in.B; m.H = q.in.H; m.W = q.in.W;
     m.tiles_x = (m.W + TW - 1) / TW;
     m.tiles_per_img = m.tiles_x * ((m.H + th - 1) / th);
+    m.inv_tiles_x = conv_inv32(m.tiles_x);
+    m.inv_tiles_per_img = conv_inv32(m.tiles_per_img);
     m.tile_start = (int)tiles;
     p.tile_starts[i] = (int)tiles;
     tiles += (long long)m.tiles_per_img * m.B;
