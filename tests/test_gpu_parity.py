@@ -59,6 +59,8 @@ def conv_layer(name, bottom, nout, k, pad, dil=1, relu=True):
     (64, 128, 3, 1, 32, 48, True),     # BN=128 tile
     (128, 256, 3, 1, 19, 21, False),   # no ReLU, negative outputs kept
     (512, 512, 3, 1, 16, 24, True),    # conv4/5 class, 16 K-chunks
+    (128, 384, 3, 1, 45, 83, True),    # three cout tiles, an odd number of 16-row tiles (dual-tile family: dummy second tile)
+    (160, 128, 3, 1, 23, 17, True),    # Cin = 10 x 16: an odd number of 32-channel chunks' worth
     (512, 256, 1, 1, 9, 13, True),     # 1x1 (conv5_256 / conv4_256)
     (128, 128, 3, 2, 22, 26, True),    # head_2
     (128, 128, 3, 4, 22, 26, True),    # head_4
