@@ -233,6 +233,8 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_f32_kernel(ConvK p) {
 #endif
 
   // epilogue: C row = (r&3) + 8*(r>>2) + 4*(lane>>5), C col = lane&31
+  float amax = 0.f;  // split-fp16 modes only (a layer the split kernels do not cover): range guard + activation exponent
+  const bool track = p.range_flag || mem.out_amax || mem.pool_amax;
 #pragma unroll
   for (int tn = 0; tn < 2; ++tn) {
     const int cout = ct * BN + wn * 64 + tn * 32 + i;
@@ -241,8 +243,12 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_f32_kernel(ConvK p) {
     for (int tm = 0; tm < 2; ++tm) {
       const f32x16 a = acc[tm][tn];
       conv_store_tile([&](int r) { return a[r]; }, bv, p.relu, ty0 + wm * 4 + tm * 2, tx0, kh, H, W, b, cout, gout,
-                      p.out_stride, mem.pool, p.pool_stride);
+                      p.out_stride, mem.pool, p.pool_stride, track ? &amax : nullptr);
     }
+  }
+  if (track) {
+    conv_raise_range_flag(p.range_flag, amax);
+    conv_publish_amax(mem.out_amax, mem.pool_amax, amax);
   }
 }
 
@@ -257,7 +263,8 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_f32_kernel(ConvK p) {
 __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict__ in, const float* __restrict__ wt,
                                                           const float* __restrict__ bias, float* __restrict__ out,
                                                           int B, int H, int W, int Cin, int Cout, int k, int dil,
-                                                          int pad, int relu, int out_stride, int* range_flag) {
+                                                          int pad, int relu, int out_stride, int* range_flag,
+                                                          unsigned* out_amax) {
   extern __shared__ __attribute__((aligned(16))) float tile[];  // [64][Cout + 4]
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int pitch = Cout + 4;
@@ -310,6 +317,7 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict
     __syncthreads();
   }
   conv_raise_range_flag(range_flag, amax);
+  conv_publish_amax(out_amax, nullptr, amax);
 }
 
 // ---------------------------------------------------------------------------
@@ -319,10 +327,11 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict
 __global__ void conv_direct_kernel(const float* __restrict__ in, const float* __restrict__ w,
                                    const float* __restrict__ bias, float* __restrict__ out, int B, int H, int W,
                                    int Cin, int Cout, int k, int dil, int pad, int relu, int in_stride,
-                                   int out_stride) {
+                                   int out_stride, int* range_flag, unsigned* out_amax) {
   const long long n = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long total = (long long)B * H * W * Cout;
-  if (n >= total) return;
+  float amax = 0.f;
+  if (n < total) {  // (no early return: every lane takes part in the wave reduction below)
   const int co = (int)(n % Cout);
   const long long P = n / Cout;
   const int x = (int)(P % W), y = (int)((P / W) % H), b = (int)(P / ((long long)W * H));
@@ -340,6 +349,10 @@ __global__ void conv_direct_kernel(const float* __restrict__ in, const float* __
   }
   if (relu) acc = fmaxf(acc, 0.f);
   out[(size_t)P * out_stride + co] = acc;
+  amax = acc != acc ? __builtin_inff() : fabsf(acc);
+  }
+  conv_raise_range_flag(range_flag, amax);   // split-fp16 modes: the consumer may be a split kernel (conv_common.h)
+  conv_publish_amax(out_amax, nullptr, amax);
 }
 
 // ---------------------------------------------------------------------------
@@ -388,6 +401,11 @@ static int launch_mfma_t(const ConvArgs* as, int n, hipStream_t s) {
   p.w1t = nullptr;
   p.w1f = nullptr;
   p.b1 = nullptr;
+  p.range_flag = a.range_flag;
+  p.wph = nullptr;
+  p.wscale_inv = 1.f;
+  p.tile_base = 0;
+  p.ntile_blocks = 0;
   long long tiles = 0;
   for (int i = 0; i < n; ++i) {
     const ConvArgs& q = as[i];
@@ -401,6 +419,7 @@ static int launch_mfma_t(const ConvArgs* as, int n, hipStream_t s) {
     m.out = q.out.p + q.out.coff;
     m.pool = q.pool.p ? q.pool.p + q.pool.coff : nullptr;
     m.img = nullptr;
+    m.in_amax = q.in_amax; m.out_amax = q.out_amax; m.pool_amax = q.pool.p ? q.pool_amax : nullptr;
     m.B = q.in.B; m.H = q.in.H; m.W = q.in.W;
     m.tiles_x = (m.W + TW - 1) / TW;
     m.tiles_per_img = m.tiles_x * ((m.H + TH - 1) / TH);
@@ -409,7 +428,13 @@ static int launch_mfma_t(const ConvArgs* as, int n, hipStream_t s) {
     m.tile_start = (int)tiles;
     p.tile_starts[i] = (int)tiles;
     tiles += (long long)m.tiles_per_img * m.B;
+    // conv_split_tile's multiply-high quotients are exact while tile index x divisor < 2^32
+    if ((unsigned long long)m.tiles_per_img * m.B * (unsigned long long)m.tiles_per_img >= (1ull << 32)) {
+      set_error("conv: more than 2^32 / tiles-per-image pixel tiles in one member (shrink the batch or the map)");
+      return -1;
+    }
   }
+  if (tiles * p.nct >= (1ll << 31)) { set_error("conv: grid too large"); return -1; }
   p.dbg = nullptr;
 #ifdef SHF_CONV_TIMING
   static unsigned long long* dbg_dev = nullptr;
@@ -479,7 +504,7 @@ int launch_conv_first(const float* in_nchw, const ConvArgs& a, hipStream_t s) {
   if (blocks > 256 * 8) blocks = 256 * 8;  // persistent blocks, grid-stride over 64-pixel groups
   hipLaunchKernelGGL(conv_first_kernel, dim3((unsigned)blocks), dim3(256), lds, s, in_nchw, a.wfirst, a.bias,
                      a.out.p + a.out.coff, a.in.B, a.in.H, a.in.W, Cin, Cout, a.k, a.dil, a.pad, a.relu,
-                     a.out.cstride, a.range_flag);
+                     a.out.cstride, a.range_flag, a.out_amax);
   SHF_HIP_OK(hipGetLastError());
   return 0;
 }
@@ -488,7 +513,7 @@ int launch_conv_direct(const ConvArgs& a, hipStream_t s) {
   const long long total = (long long)a.in.B * a.in.H * a.in.W * a.out.C;
   hipLaunchKernelGGL(conv_direct_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
                      a.in.p + a.in.coff, a.wraw, a.bias, a.out.p + a.out.coff, a.in.B, a.in.H, a.in.W, a.in.C,
-                     a.out.C, a.k, a.dil, a.pad, a.relu, a.in.cstride, a.out.cstride);
+                     a.out.C, a.k, a.dil, a.pad, a.relu, a.in.cstride, a.out.cstride, a.range_flag, a.out_amax);
   SHF_HIP_OK(hipGetLastError());
   return 0;
 }

@@ -18,6 +18,12 @@ struct ConvMember {
   int B, H, W;
   int tiles_x, tiles_per_img, tile_start;  // tile_start: first pixel-tile index of this member
   unsigned inv_tiles_x, inv_tiles_per_img; // floor(2^32 / d) + 1: a tile index is split with two multiply-highs, not divisions
+  // activation exponent (split-fp16 modes): one u32 slot per (lane, blob) = the bit pattern of max |value| of this unit's
+  // blob, raised by every producer's epilogue (conv_publish_amax) and read by the single-accumulator kernels, which lift
+  // their input to the top of the fp16 range before the unscaled low parts are formed (conv_act_exponent).  Null = unknown.
+  const unsigned* in_amax;
+  unsigned* out_amax;
+  unsigned* pool_amax;
 };
 
 struct ConvK {
@@ -91,8 +97,9 @@ __device__ __forceinline__ void conv_store_tile(GetV getv, float bv, int relu_fl
       const int y = gy0 + (s >> 1), x = gx + (s & 1);
       float v = getv(4 * q + s) + bv;
       if (relu_flags & 1) v = fmaxf(v, 0.f);
-      if (amax) *amax = fmaxf(*amax, fabsf(v));
       if (y < H && x < W) {
+        // (only what is stored counts: the unit's max must not depend on how the launch tiles the map)
+        if (amax) *amax = fmaxf(*amax, v != v ? __builtin_inff() : fabsf(v));
         if (write_main) gout[((size_t)(b * H + y) * W + x) * out_stride + cout] = v;
         m = v > m ? v : m;
       }
@@ -134,9 +141,12 @@ __device__ __forceinline__ void conv_stage_tile(float* __restrict__ Cs, GetV get
 // arithmetic and one ds_write2_b32 parks the pair (2.5 instead of 6.5 VALU ops per value).
 typedef float cs_f32x2 __attribute__((ext_vector_type(2)));
 typedef float cs_f32x16 __attribute__((ext_vector_type(16)));
+// (ylim, xlim) = rows / columns of the block tile that are inside the image: only those count for `amax` -- the unit's
+// max must not depend on how the launch tiles the map
 template <int BN, bool RELU>
 __device__ __forceinline__ void conv_stage_tile_pk(float* __restrict__ Cs, const cs_f32x16 am, const cs_f32x16 ac,
-                                                   float inv, float bv, int ly0, int kh, int cl, float& amax) {
+                                                   float inv, float bv, int ly0, int kh, int cl, float& amax, int ylim,
+                                                   int xlim) {
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int lx = 2 * (2 * q + kh);
@@ -146,7 +156,10 @@ __device__ __forceinline__ void conv_stage_tile_pk(float* __restrict__ Cs, const
       cs_f32x2 v = __builtin_elementwise_fma(cs_f32x2{ac[r], ac[r + 1]}, cs_f32x2{inv, inv}, cs_f32x2{am[r], am[r + 1]});
       v = v + cs_f32x2{bv, bv};
       if (RELU) v = __builtin_elementwise_max(v, cs_f32x2{0.f, 0.f});
-      amax = fmaxf(fmaxf(amax, fabsf(v[0])), fabsf(v[1]));  // fp16 range guard (v_max3 with abs modifiers)
+      if (ly0 + (sp >> 1) < ylim) {  // fp16 range guard + activation exponent (v_max3 with abs modifiers)
+        if (lx < xlim) amax = fmaxf(amax, fabsf(v[0]));
+        if (lx + 1 < xlim) amax = fmaxf(amax, fabsf(v[1]));
+      }
       float* d = Cs + ((ly0 + (sp >> 1)) * 16 + lx) * (BN + CS_PAD) + cl;
       d[0] = v[0];
       d[BN + CS_PAD] = v[1];
@@ -159,6 +172,43 @@ __device__ __forceinline__ void conv_stage_tile_pk(float* __restrict__ Cs, const
 // downstream of an inf, which has raised the flag of the same pass already.)
 __device__ __forceinline__ void conv_raise_range_flag(int* flag, float amax) {
   if (flag && !(amax <= 65504.0f)) atomicOr(flag, 1);
+}
+
+// ... and the unit's running max |output| for the consumer's activation exponent: one wave reduction, then at most one
+// atomic per wave and slot (none once the slot has caught up: the max converges within the first blocks).  amax >= 0, so
+// the float bit patterns order like unsigned integers; a pooled output is bounded by the un-pooled one (slot2).
+__device__ __forceinline__ unsigned conv_wave_umax(unsigned v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    const unsigned w = (unsigned)__shfl_xor((int)v, o, 64);
+    v = v > w ? v : w;
+  }
+  return v;
+}
+__device__ __forceinline__ void conv_publish_amax(unsigned* slot, unsigned* slot2, float amax) {
+  if (!slot && !slot2) return;
+  const unsigned m = conv_wave_umax(__builtin_bit_cast(unsigned, amax));
+  if ((threadIdx.x & 63) == 0) {
+    if (slot && m > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, m);
+    if (slot2 && m > __hip_atomic_load(slot2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot2, m);
+  }
+}
+
+// exponent e >= 0 with amax * 2^e in [2^13, 2^14) (fp16 tops out at 65504): what a single-accumulator kernel multiplies
+// its input by (exactly, in fp16) so that lo = fp16(x - hi) keeps its bits whatever the layer's magnitude -- unscaled,
+// lo of |x| < 0.25 is an fp16 subnormal (quantum 2^-24) and a layer that lives around 1e-3 would keep 14 bits, not 22.
+// 0 when the slot is unknown, zero, or not finite (the range flag is up in that case).
+__device__ __forceinline__ int conv_act_exponent(const unsigned* slot) {
+  if (!slot) return 0;
+  const unsigned b = *slot;
+  if (b == 0u || b >= 0x7f800000u) return 0;
+  const int e = 13 - ((int)(b >> 23) - 127);
+  return e < 0 ? 0 : (e > 30 ? 30 : e);
+}
+// 2^k as an fp16 bit pattern, twice (v_pk_mul_f16 operand); k in [-14, 15]
+__device__ __forceinline__ unsigned conv_pk_pow2_f16(int k) {
+  const unsigned h = (unsigned)(k + 15) << 10;
+  return h | (h << 16);
 }
 
 // write the staged tile (and its 2x2/2 max-pool) to global memory; all NT threads of the block.
@@ -426,8 +476,9 @@ __device__ __forceinline__ void conv_epilogue_regs_tail(float (&v)[16], const fl
       auto relu1 = [](float x) { const int q = __builtin_bit_cast(int, x); return __builtin_bit_cast(float, q > 0 ? q : 0); };
       o[g] = make_float4(relu1(o[g].x), relu1(o[g].y), relu1(o[g].z), relu1(o[g].w));
     }
-    amax = fmaxf(fmaxf(amax, fabsf(o[g].x)), fabsf(o[g].y));
-    amax = fmaxf(fmaxf(amax, fabsf(o[g].z)), fabsf(o[g].w));
+    // (only pixels inside the image count: the unit's max must not depend on how the launch tiles the map)
+    const float m4 = fmaxf(fmaxf(fabsf(o[g].x), fabsf(o[g].y)), fmaxf(fabsf(o[g].z), fabsf(o[g].w)));
+    amax = valid ? fmaxf(amax, m4) : amax;
   }
   if (pix_main && valid) {
     if (main_split) {

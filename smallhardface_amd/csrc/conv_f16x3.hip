@@ -13,18 +13,17 @@
 // epilogue (ConvArgs::in_split / out_split) -- and weights are split once at load time.  Every MFMA convolution
 // of the detector runs here in the split-fp16 modes: 3x3 at dilation 1, 2, 4 and the 1x1s.
 //
-// Kernels: conv_mfma_f16x3_w4d_kernel (the dual-tile 4-wave family: Cin >= 128, Cout % 128 == 0 -- 70 % of the time;
-// conv_mfma_f16x3_w4_kernel is its single-tile, two-accumulator predecessor, SHF_F16X3_W4D=0),
+// Kernels: conv_mfma_f16x3_w4d_kernel (the dual-tile 4-wave family: Cin >= 128, Cout % 128 == 0 -- 70 % of the time),
 // conv_mfma_f16x3_pc_kernel (fused first pair conv1_1 -> conv1_2, producer/consumer waves) and the 8-wave
 // conv_mfma_f16x3_kernel below (Cin 64, dilated heads, 1x1).  Common structure: tile 256 px (16x16) x BN couts; a
 // STAGE is one kernel row (3 taps) of one 32-channel chunk: its three BNx32 weight slabs are double-buffered in
 // LDS and arrive by LDS DMA; the 18x18x32 halo tile is staged once per chunk and reused by all 9 taps.  LDS rows
 // are [hi: 32 halfs][lo: 32 halfs][16 B pad] = 144 B (conflict-free ds_read_b128 over consecutive rows).
 // (The dual-tile family has its own geometry: 16-channel chunks, 64 / 80-byte rows, unscaled low parts -- see its header.)
-// Epilogues: the 4-wave kernels run the MFMA as D[cout][pixel] and store from registers (conv_epilogue_regs); the
+// Epilogues: the 4-wave kernels run the MFMA as D[cout][pixel] and store from registers (conv_epilogue_regs1); the
 // 8-wave and fused-pair kernels run D[pixel][cout] and transpose the tile through LDS (conv_stage_tile / conv_flush_tile).
-// conv_mfma_f16x3_w4p_kernel is the persistent (block walks tiles) form of the 4-wave kernel: off by default
-// (SHF_F16X3_W4P=1), see DESIGN.md for why it does not pay.
+// (The single-tile two-accumulator 4-wave kernel the family replaced, its persistent form and the timing-only
+// F16X3_EXPERIMENT_* builds of round 2 are in the history at c610267; DESIGN.md keeps what they measured.)
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
@@ -45,38 +44,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #ifndef F16X3_DMA_LATE
 #define F16X3_DMA_LATE 1   // 1: the early-finishing waves 0-3 issue the next stage's weight DMA after their MFMAs
-#endif
-#ifndef F16X3_W4_PREFETCH
-#define F16X3_W4_PREFETCH 0  // 4-wave kernel: request the next halo tile a stage early (1) or in the hand-over stage (0)
-#endif
-#ifndef F16X3_W4_PIN
-#define F16X3_W4_PIN 0       // 1: pin the fp16 split inside its k-step (fewer cycles, but measured SLOWER end to end: see below)
-#endif
-#ifndef F16X3_W4_ROWPAD
-#define F16X3_W4_ROWPAD 96   // 4-wave kernel: extra bytes per halo-tile ROW in LDS (0 = contiguous pixels).  A fragment's two
-                             // pixel rows (dy = 0 / 1) are 18 pixels = 162 sixteen-byte groups apart: 2 (mod 16), and the
-                             // 16 lanes of a ds_read_b128 group then share banks two by two (SQ_LDS_BANK_CONFLICT: 37 % of
-                             // the LDS cycles, profiles/r02_pmc.json).  +96 B makes the row distance 8 (mod 16): conflict-free.
-#endif
-#ifndef F16X3_W4_REGEPI
-#define F16X3_W4_REGEPI 1    // 4-wave kernels: MFMA as D[cout][pixel] + register epilogue (1) or D[pixel][cout] + LDS-transposed epilogue (0)
-#endif
-#if F16X3_W4_REGEPI
-#define W4_MFMA(px, wt, acc) __builtin_amdgcn_mfma_f32_32x32x16_f16(wt, px, acc, 0, 0, 0)
-#else
-#define W4_MFMA(px, wt, acc) __builtin_amdgcn_mfma_f32_32x32x16_f16(px, wt, acc, 0, 0, 0)
-#endif
-#ifndef F16X3_W4_HALO_STEP0
-#define F16X3_W4_HALO_STEP0 6
-#endif
-#ifndef F16X3_W4_DMA_SCHED_MT2
-#define F16X3_W4_DMA_SCHED_MT2 1   // 8-row tiles: weight-DMA rounds per k-step (see the stage body)
-#endif
-#ifndef F16X3_W4_WREG
-#define F16X3_W4_WREG 0   // 4-wave kernel: the next stage's weights through registers (1) or by LDS DMA (0) in the stages without a halo hand-over
-#endif
-#ifndef F16X3_W4_EARLY_HANDOVER
-#define F16X3_W4_EARLY_HANDOVER 0   // 4-wave kernel: park the next halo tile under the last k-step's MFMAs (1) or after the stage (0)
 #endif
 #ifndef F16X3_CONV_MID
 #define F16X3_CONV_MID 1   // 1: split the next halo tile to fp16 hi/lo in the middle of the last stage's MFMAs
@@ -442,15 +409,16 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_kernel(ConvK p) {
 #pragma unroll
       for (int tm = 0; tm < MT; ++tm) {
         if (p.relu & 1)
-          conv_stage_tile_pk<BN, true>(Cs, accm[tm][tn], accc[tm][tn], LO_INV, bv, wm * 2 * MT + tm * 2, kh, cl, amax);
+          conv_stage_tile_pk<BN, true>(Cs, accm[tm][tn], accc[tm][tn], LO_INV, bv, wm * 2 * MT + tm * 2, kh, cl, amax, H - ty0, W - tx0);
         else
-          conv_stage_tile_pk<BN, false>(Cs, accm[tm][tn], accc[tm][tn], LO_INV, bv, wm * 2 * MT + tm * 2, kh, cl, amax);
+          conv_stage_tile_pk<BN, false>(Cs, accm[tm][tn], accc[tm][tn], LO_INV, bv, wm * 2 * MT + tm * 2, kh, cl, amax, H - ty0, W - tx0);
       }
     }
     __syncthreads();
     conv_flush_tile<BN, 512>(Cs, tid, ty0, tx0, H, W, b, ct * BN, gout, p.out_stride, mem.pool, p.pool_stride,
                              !(p.relu & 8), (p.relu & 32) != 0, (p.relu & 64) != 0);
     conv_raise_range_flag(p.range_flag, amax);
+    conv_publish_amax(mem.out_amax, mem.pool ? mem.pool_amax : nullptr, amax);
 #ifdef SHF_CONV_TIMING
     if (p.dbg && tid == 0 && (bid == 0 || bid == 100))
       printf("[f16x3 8w] blk%d epilogue %llu\n", bid, (unsigned long long)__builtin_amdgcn_s_memtime() - t_end8);
@@ -469,880 +437,7 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_kernel(ConvK p) {
     }
   }
   conv_raise_range_flag(p.range_flag, amax);
-}
-
-// One-wave-per-SIMD variant for Cout % 128 == 0: block = 256 threads = 4 waves (2 M x 2 N), each wave
-// 128 px x 64 couts = 16 accumulator tiles (main + corr: 256 registers, the AGPR half of the 512 a lone
-// wave owns).  Against the 8-wave kernel: 12 LDS fragment reads per 24 MFMAs instead of 8 per 12, and
-// room for a second fragment set, so the six k-steps of a stage run as an explicit software pipeline
-// (step s+1's ds_reads interleaved 1:2 with step s's MFMAs) -- the matrix pipe only idles at the stage
-// barriers.  The weight DMA for stage st+1 is issued right after the barrier of stage st (a full stage
-// of slack), the next chunk's halo tile is fetched, split and parked in registers under the last stage.
-// IN_SPLIT: the input blob is in the split-fp16 activation format (written by the producer's epilogue): the
-// halo pieces are already [hi | lo] fp16 and go to LDS as they are -- no conversion anywhere in the K loop.
-// MT_: 2x16-pixel MFMA row tiles per wave.  4 = the 16x16-pixel block tile above; 2 = an 8x16-pixel tile (wave 64 px x
-// 64 couts, half the accumulators) for launches whose block count quantises badly on 256 CUs -- conv5_x on the bench
-// pyramid is 528 blocks = 2.06 rounds of 16x16 tiles but 960 half-size blocks = 3.75 rounds (launcher: w4_pick_mt).
-// NP: fp16 products per fp32 product -- 3 (fp32-class), 2 (a_lo * b_hi dropped: activations act as fp16) or 1 (hi * hi).
-template <bool IN_SPLIT, int MT_, int NP = 3>
-__global__ __launch_bounds__(256) void conv_mfma_f16x3_w4_kernel(ConvK p) {
-  using namespace f16x3;
-  constexpr int TH = 4 * MT_, HTH = TH + 2, HP = HTH * HTW;  // (shadow the 16-row constants of namespace f16x3)
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-#ifdef SHF_CONV_TIMING
-  const unsigned long long t_entry = __builtin_amdgcn_s_memtime(), r_entry = __builtin_amdgcn_s_memrealtime();
-#endif
-  constexpr int BN = 128, MT = MT_, NT = 256;
-  constexpr int ALD = (HP * 8 + NT - 1) / NT;  // float4 halo pieces per thread: 11
-  constexpr int HPITCH = HTW * ROWB + F16X3_W4_ROWPAD;  // bytes per halo-tile row
-  unsigned char* As = smem;                    // [HTH][HPITCH]: pixel (hy, hx) at hy * HPITCH + hx * ROWB
-  unsigned char* Bs = smem + HTH * HPITCH;     // [2][3][BN][ROWB]
-  float* biasL = (float*)(Bs + 2 * 3 * BN * ROWB);  // [BN] this block's biases (register epilogue: read back as 8 ds_read_b128)
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wn = wave & 1, wm = wave >> 1;
-  const int bid = blockIdx.x;
-  const int ct = bid % p.nct;
-  int pt = bid / p.nct;
-  const int mi = conv_find_member(p, pt);
-  const ConvMember& mem = p.m[mi];
-  pt -= mem.tile_start;
-  int b, ty_, tx_;
-  conv_split_tile(mem, pt, b, ty_, tx_);
-  const int ty0 = ty_ * TH, tx0 = tx_ * TW;
-  const int H = mem.H, W = mem.W;
-  const float* __restrict__ gin = mem.in;
-  float* __restrict__ gout = mem.out;
-
-  const int nchunks = p.Cin / KC;
-  const int NST = nchunks * 3;
-  const _Float16* wsp = (const _Float16*)p.wp;
-  const size_t slab = (size_t)p.Cout * 72;
-  const _Float16* wbase = wsp + (size_t)ct * BN * 72;
-
-  // halo piece j of this thread: float4 q of halo pixel hp0 + 32 j (LDS offset = a_loff0 + j * 32 rows).
-  // Pieces are fetched unconditionally -- out-of-image lanes read the member's first pixel and are
-  // zeroed afterwards (bit j of a_valid) -- because predicated loads would split the MFMA
-  // scheduling region into basic blocks.
-  unsigned a_gsafe[ALD];  // BYTE offsets (unsigned: scalar base + 32-bit lane offset addressing, no 64-bit lane math)
-  unsigned a_valid = 0;
-  const int a_loff0 = (tid >> 3) * ROWB + (tid & 7) * 8;
-  const bool a_last = tid + NT * (ALD - 1) < HP * 8;  // the ragged last piece exists for this thread
-#pragma unroll
-  for (int j = 0; j < ALD; ++j) {
-    const int idx = tid + NT * j;
-    const int hp = idx >> 3, q = idx & 7;
-    const int hy = hp / HTW, hx = hp - hy * HTW;
-    const int gy = ty0 - 1 + hy, gx = tx0 - 1 + hx;
-    const bool in = (idx < HP * 8) && ((unsigned)gy < (unsigned)H) && ((unsigned)gx < (unsigned)W);
-    a_gsafe[j] = in ? (unsigned)(((b * H + gy) * W + gx) * p.in_stride + q * 4) * 4u : 0u;
-    a_valid |= in ? (1u << j) : 0u;
-  }
-  // fp32 piece -> [hi half4 | lo half4] in the same four registers
-  auto split_inplace = [&](float4& v, bool valid) {
-    if constexpr (IN_SPLIT) {
-      if (!valid) v = make_float4(0.f, 0.f, 0.f, 0.f);
-      return;
-    }
-#ifdef F16X3_EXPERIMENT_NO_SPLIT  // upper bound of a pre-split activation format (WRONG results: timing only)
-    const float2 h2 = make_float2(v.x, v.y), l2 = make_float2(v.z, valid ? v.w : 0.f);
-#else
-    half4 hi, lo;
-    split4(valid ? v : make_float4(0.f, 0.f, 0.f, 0.f), hi, lo);
-    const float2 h2 = __builtin_bit_cast(float2, hi), l2 = __builtin_bit_cast(float2, lo);
-#endif
-    // Left alone the compiler sinks the conversion to its single use after the stage (the hand-over
-    // bubble, ~1 k cycles per chunk).  Pinning it here (F16X3_W4_PIN) puts the VALU work under the MFMAs
-    // and saves those cycles -- and measured 3 % SLOWER end to end on the same box: the chip is
-    // power-limited under this kernel (1.75-1.9 GHz sustained), VALU issued alongside the matrix pipe
-    // costs clock.  Same story for requesting the tile a stage early (F16X3_W4_PREFETCH).
-    float x0 = h2.x, x1 = h2.y, x2 = l2.x, x3 = l2.y;
-#if F16X3_W4_PIN
-    asm volatile("" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3));
-#endif
-    v = make_float4(x0, x1, x2, x3);
-  };
-  auto store_piece = [&](const float4& v, int j) {
-    const int rowpad = (((tid >> 3) + 32 * j) / HTW) * F16X3_W4_ROWPAD;  // halo pixel hp = tid/8 + 32 j sits in row hp / 18
-    if constexpr (IN_SPLIT) {  // 16-B piece q of the pixel's 128 B: hi pieces 0..3, lo pieces 4..7 = row offset q * 16
-      *(float4*)(As + (tid >> 3) * ROWB + (tid & 7) * 16 + j * 32 * ROWB + rowpad) = v;
-    } else {
-      *(float2*)(As + a_loff0 + j * 32 * ROWB + rowpad) = make_float2(v.x, v.y);
-      *(float2*)(As + a_loff0 + j * 32 * ROWB + rowpad + 64) = make_float2(v.z, v.w);
-    }
-  };
-  constexpr int SLAB_B = BN * ROWB;
-  constexpr int PCS_SLAB = SLAB_B / 1024;
-  constexpr int PCS = 3 * PCS_SLAB;          // 54 one-KiB DMA pieces per stage
-  constexpr int DMA_ROUNDS = (PCS + 3) / 4;  // 14 per wave; waves 2,3 repeat piece 53 in the last round
-  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-  // rounds [j0, j0+n) of the weight DMA for `stage` into buffer `buf`; branch-free so that it can sit
-  // inside the MFMA scheduling region
-  // Round j = 5 sl + i moves piece (wave + 4 i) of slab sl: the slab and the multiple of 4 KiB are compile-time,
-  // the wave's own KiB sits in two per-wave scalar bases, so a round is a couple of scalar adds, the M0 write
-  // and the DMA itself (scalar base + lane * 16 as the vector offset).  Waves 2, 3 have no fifth piece in a slab
-  // of 18: they repeat piece 17.
-  constexpr int DMA_ROUNDS_W4 = 15;
-  const unsigned lane16 = (unsigned)lane * 16u;
-  const int last_piece = wave_u + 16 < PCS_SLAB ? wave_u + 16 : PCS_SLAB - 1;
-  // Round r (0..13) of a wave moves piece q = wave + 4 r of the stage's 54 (piece 53 again for waves 2, 3 in the last
-  // round: 2 wasted KiB per stage instead of the 6 of a 5-rounds-per-slab walk -- the weight traffic is what this
-  // power-limited kernel pays most for).  LDS offset = q KiB (the three slabs are contiguous there);
-  // global offset = slab (q / 18) + (q % 18) KiB: compile-time per round except round 4, where waves 0, 1 are still in
-  // slab 0 and waves 2, 3 already in slab 1 (one per-wave scalar).
-  constexpr int W_ROUNDS = 14;
-  const size_t slab_b = slab * 2;   // bytes between the tap slabs of a cout tile in global memory
-  const size_t goff_r4 = wave_u < 2 ? (size_t)(16 + wave_u) * 1024 : slab_b + (size_t)(wave_u - 2) * 1024;
-  const int q_r13 = wave_u < 2 ? 52 + wave_u : 53;
-  auto w_goff = [&](int r) -> size_t {
-    if (r == 4) return goff_r4;
-    if (r == 13) return 2 * slab_b + (size_t)(q_r13 - 36) * 1024;
-    const int sl = (4 * r) / 18;                       // (rounds other than 4: all four waves in one slab)
-    return (size_t)sl * slab_b + (size_t)(4 * r - 18 * sl + wave_u) * 1024;
-  };
-  auto w_loff = [&](int r) { return (r == 13 ? q_r13 : 4 * r + wave_u) * 1024; };
-  auto dma_w = [&](int stage, int buf, int j0, int n) {
-    const unsigned char* ws_ = (const unsigned char*)(wbase + (size_t)stage * 3 * slab);
-    unsigned char* bd_ = Bs + buf * (3 * SLAB_B);
-#pragma unroll
-    for (int r = j0; r < j0 + n; ++r) {
-      const unsigned char* ub = ws_ + w_goff(r);   // wave-uniform
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ub + lane16),
-                                       (__attribute__((address_space(3))) void*)(bd_ + w_loff(r)), 16, 0, 0);
-    }
-  };
-  // The same rounds THROUGH REGISTERS (F16X3_W4_WREG): a plain global_load_dwordx4 + ds_write_b128 pair.  An LDS-DMA
-  // instruction holds the issuing wave ~70 cycles with four waves at it (tools/dma_rate.hip: 59 B/clk per CU), a plain
-  // load ~13, and with one wave per SIMD every cycle the wave is held the matrix pipe idles: the in-loop weight DMA is
-  // 22 % of this kernel (F16X3_EXPERIMENT_NO_DMA).  The registers are the halo hand-over's (areg), which only the
-  // last kernel row of a chunk uses: that stage keeps the DMA.
-  // (named registers, not an array: hipcc keeps a local array that is written in one unrolled k-step and read in a
-  // later one in scratch memory)
-  auto w_addr = [&](int stage, int r) {
-    return (const unsigned char*)(wbase + (size_t)stage * 3 * slab) + w_goff(r < W_ROUNDS ? r : W_ROUNDS - 1) + lane16;
-  };
-  auto w_load5 = [&](int stage, int j0, float4& r0, float4& r1, float4& r2, float4& r3, float4& r4) {
-    r0 = *(const float4*)w_addr(stage, j0);
-    r1 = *(const float4*)w_addr(stage, j0 + 1);
-    r2 = *(const float4*)w_addr(stage, j0 + 2);
-    r3 = *(const float4*)w_addr(stage, j0 + 3);
-    r4 = *(const float4*)w_addr(stage, j0 + 4);
-  };
-  auto w_lds = [&](int buf, int r) {
-    return (float4*)(Bs + buf * (3 * SLAB_B) + w_loff(r < W_ROUNDS ? r : W_ROUNDS - 1) + lane16);
-  };
-  auto w_store5 = [&](int buf, int j0, const float4& r0, const float4& r1, const float4& r2, const float4& r3, const float4& r4) {
-    *w_lds(buf, j0) = r0;
-    *w_lds(buf, j0 + 1) = r1;
-    *w_lds(buf, j0 + 2) = r2;
-    *w_lds(buf, j0 + 3) = r3;
-    *w_lds(buf, j0 + 4) = r4;
-  };
-  // prologue: W(0) by DMA and the halo tile of chunk 0 are requested first; the accumulator clearing and
-  // the fragment geometry fill the wait
-  float4 areg0[ALD];
-#ifdef F16X3_EXPERIMENT_NO_PROLOGUE  // timing only (WRONG results): what a hidden prologue (persistent tiles) could save
-#pragma unroll
-  for (int j = 0; j < ALD; ++j) areg0[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-#else
-  dma_w(0, 0, 0, W_ROUNDS);
-#pragma unroll
-  for (int j = 0; j < ALD; ++j) areg0[j] = *(const float4*)((const char*)gin + a_gsafe[j]);
-#endif
-#if F16X3_W4_REGEPI
-  if (tid < BN) biasL[tid] = p.bias ? p.bias[ct * BN + tid] : 0.f;  // (visible after the first stage barrier)
-#endif
-
-  const int i = lane & 31, kh = lane >> 5;
-  int dy, px;
-  row_to_pixel(i, dy, px);
-  int a_off[MT], b_off[2];
-#pragma unroll
-  for (int t = 0; t < MT; ++t) a_off[t] = (wm * 2 * MT + t * 2 + dy) * HPITCH + px * ROWB + kh * 16;
-#pragma unroll
-  for (int t = 0; t < 2; ++t) b_off[t] = (wn * 64 + t * 32 + i) * ROWB + kh * 16;
-  f32x16 accm[MT][2], accc[MT][2];
-#pragma unroll
-  for (int a = 0; a < MT; ++a)
-#pragma unroll
-    for (int c = 0; c < 2; ++c)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { accm[a][c][r] = 0.f; accc[a][c][r] = 0.f; }
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int j = 0; j < ALD; ++j) {
-    split_inplace(areg0[j], (a_valid >> j) & 1);
-    if (j + 1 < ALD || a_last) store_piece(areg0[j], j);
-  }
-
-#ifdef SHF_CONV_TIMING
-  unsigned long long tb = 0, tc = 0, tx = 0, t0, t1, t3;
-#ifdef SHF_CONV_TIMING_STEPS
-  unsigned long long tstep[6] = {0, 0, 0, 0, 0, 0};
-#endif
-  const unsigned long long t_loop = __builtin_amdgcn_s_memtime();
-#endif
-  // one stage = kernel row KY of chunk c; HANDOVER: also fetch / split / park the halo tile of chunk c+1
-  // MODE 0: plain; 1 (middle kernel row): also request the halo tile of chunk c+1 into registers;
-  // 2 (last kernel row): split it to fp16 hi/lo under the MFMAs and park it in LDS after the stage
-  float4 areg[ALD];
-  auto stage = [&](int c, auto KY_, auto MODE_) {
-    constexpr int ky = decltype(KY_)::value;
-    constexpr bool PREFETCH = decltype(MODE_)::value == 1;
-#ifdef F16X3_EXPERIMENT_NO_HANDOVER   // timing only (WRONG results): the halo tile of chunk 0 serves every chunk
-    constexpr bool HANDOVER = false;
-#else
-    constexpr bool HANDOVER = decltype(MODE_)::value == 2;
-#endif
-    const int st = c * 3 + ky;
-    SHF_T(t0);
-#ifndef F16X3_EXPERIMENT_NO_BARRIER   // timing only (WRONG results)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of W(st) has landed
-    __syncthreads();
-#endif
-    SHF_T(t1);
-    const int st_next = st + 1 < NST ? st + 1 : st;  // the last stage re-fetches itself (unused) instead of branching
-    const int buf_next = (st + 1) & 1;
-    const float* inc_ = gin + (c + 1) * KC;
-    const unsigned char* Arow = As + ky * HPITCH;
-    const unsigned char* Bst = Bs + (st & 1) * (3 * BN * ROWB);
-    half8 fa[2][2 * MT], fb[2][4];
-    float4 wA0, wA1, wA2, wA3, wA4, wB0, wB1, wB2, wB3, wB4, wC0, wC1, wC2, wC3, wC4;  // F16X3_W4_WREG: weight pieces on their way to LDS
-    auto load_frag = [&](int s_, half8* a, half8* bf) {
-#ifdef F16X3_EXPERIMENT_NO_FRAG   // timing only (WRONG results): fragments read once per stage
-      if (s_ > 0) {
-#pragma unroll
-        for (int t = 0; t < 2 * MT; ++t) a[t] = fa[0][t];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) bf[t] = fb[0][t];
-        return;
-      }
-#endif
-      const unsigned char* Ap = Arow + (s_ >> 1) * ROWB + (s_ & 1) * 32;
-      const unsigned char* Bp = Bst + (s_ >> 1) * (BN * ROWB) + (s_ & 1) * 32;
-#pragma unroll
-      for (int t = 0; t < MT; ++t) {
-        a[2 * t] = *(const half8*)(Ap + a_off[t]);
-        a[2 * t + 1] = *(const half8*)(Ap + a_off[t] + 64);
-      }
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        bf[2 * t] = *(const half8*)(Bp + b_off[t]);
-        bf[2 * t + 1] = *(const half8*)(Bp + b_off[t] + 64);
-      }
-    };
-    load_frag(0, fa[0], fb[0]);
-    __builtin_amdgcn_sched_barrier(0);
-#ifdef SHF_CONV_TIMING_STEPS
-    unsigned long long ts0 = __builtin_amdgcn_s_memtime(), ts1;
-#endif
-#pragma unroll
-    for (int s_ = 0; s_ < 6; ++s_) {
-      half8* a = fa[s_ & 1];
-      half8* bf = fb[s_ & 1];
-      if (s_ + 1 < 6) load_frag(s_ + 1, fa[(s_ + 1) & 1], fb[(s_ + 1) & 1]);
-      // the stage's side jobs ride under the MFMAs, a few per k-step so that no queue ever fills
-      // 16-row tiles: 3 rounds per k-step; the 8-row tiles' stage is half as long and its weights are late more often:
-      // front-loaded
-      constexpr int DMA_N[6] = {MT == 2 ? 4 : 3, MT == 2 ? 4 : 3, MT == 2 ? 4 : 3, MT == 2 ? 2 : 3, MT == 2 ? 0 : 2, 0};
-      constexpr int DMA_J0[6] = {0, DMA_N[0], DMA_N[0] + DMA_N[1], DMA_N[0] + DMA_N[1] + DMA_N[2],
-                                 DMA_N[0] + DMA_N[1] + DMA_N[2] + DMA_N[3], W_ROUNDS};
-      int n_vmem = DMA_N[s_], n_dsw = 0;
-#ifndef F16X3_EXPERIMENT_NO_DMA  // timing experiment only (stale weights): what the in-loop DMA issue costs
-#ifdef F16X3_EXPERIMENT_HALF_DMA   // timing only (WRONG results): half of the weight pieces -- what 2x weight reuse would buy
-      if (s_ >= F16X3_EXPERIMENT_HALF_DMA) n_vmem = 0;
-      else
-#endif
-      if constexpr (F16X3_W4_WREG && !HANDOVER && !PREFETCH) {
-        // through registers: rounds 0-4 / 5-9 requested in k-steps 0 / 1, parked in k-steps 2 / 3 (two k-steps to
-        // come back), rounds 10-14 take the first batch's registers in k-step 2 and are parked in k-step 4
-        if (s_ == 0) { w_load5(st_next, 0, wA0, wA1, wA2, wA3, wA4); n_vmem = 5; }
-        else if (s_ == 1) { w_load5(st_next, 5, wB0, wB1, wB2, wB3, wB4); n_vmem = 5; }
-        else if (s_ == 2) {
-          w_store5(buf_next, 0, wA0, wA1, wA2, wA3, wA4);
-          w_load5(st_next, 10, wC0, wC1, wC2, wC3, wC4);
-          n_vmem = 5; n_dsw = 5;
-        }
-        else if (s_ == 3) { w_store5(buf_next, 5, wB0, wB1, wB2, wB3, wB4); n_vmem = 0; n_dsw = 5; }
-        else if (s_ == 4) { w_store5(buf_next, 10, wC0, wC1, wC2, wC3, wC4); n_vmem = 0; n_dsw = 5; }
-        else n_vmem = 0;
-      } else {
-        if (DMA_N[s_]) dma_w(st_next, buf_next, DMA_J0[s_], DMA_N[s_]);
-      }
-#endif
-#if F16X3_W4_PREFETCH
-      if constexpr (PREFETCH) {  // a whole stage of slack before the first use
-        if (s_ >= 3 && s_ < 5) {
-#pragma unroll
-          for (int j = (s_ - 3) * 6; j < (s_ == 4 ? ALD : 6); ++j) areg[j] = *(const float4*)((const char*)inc_ + a_gsafe[j]);
-          n_vmem += s_ == 4 ? ALD - 6 : 6;
-        }
-      }
-      if constexpr (HANDOVER) {  // two pieces per k-step: a trickle of VALU work under the MFMAs
-#pragma unroll
-        for (int j = s_ * 2; j < (s_ == 5 ? ALD : s_ * 2 + 2); ++j) split_inplace(areg[j], (a_valid >> j) & 1);
-      }
-#else
-      if constexpr (HANDOVER) {
-        constexpr int HL0 = F16X3_W4_HALO_STEP0;  // halo pieces requested in k-step 0 (the rest in k-step 1)
-        if (s_ < 2) {
-#pragma unroll
-          for (int j = s_ * HL0; j < (s_ ? ALD : HL0); ++j) areg[j] = *(const float4*)((const char*)inc_ + a_gsafe[j]);
-          n_vmem += s_ ? ALD - HL0 : HL0;
-        } else if (F16X3_W4_EARLY_HANDOVER ? s_ == 4 : s_ >= 4) {  // as late as possible: the loads get three k-steps to come back
-#pragma unroll
-          for (int j = F16X3_W4_EARLY_HANDOVER ? 0 : (s_ - 4) * 6; j < (F16X3_W4_EARLY_HANDOVER || s_ == 5 ? ALD : 6); ++j)
-            split_inplace(areg[j], (a_valid >> j) & 1);
-        }
-#if F16X3_W4_EARLY_HANDOVER
-        if (s_ == 5) {
-          // The fragments of this last k-step were read under the previous one: once every wave is here the halo tile
-          // of chunk c is dead, and the next tile is parked UNDER these 24 MFMAs instead of after them (the stage
-          // barrier that follows makes it visible).
-          __syncthreads();
-#pragma unroll
-          for (int j = 0; j < ALD; ++j)
-            if (j + 1 < ALD || a_last) store_piece(areg[j], j);
-        }
-#endif
-      }
-#endif
-      // three sweeps over the 8 output tiles: consecutive MFMAs never chain on one accumulator
-#pragma unroll
-      for (int tm = 0; tm < MT; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < 2; ++tn)
-          accm[tm][tn] = W4_MFMA(a[2 * tm], bf[2 * tn], accm[tm][tn]);
-      if constexpr (NP >= 2) {
-#pragma unroll
-        for (int tm = 0; tm < MT; ++tm)
-#pragma unroll
-          for (int tn = 0; tn < 2; ++tn)
-            accc[tm][tn] = W4_MFMA(a[2 * tm], bf[2 * tn + 1], accc[tm][tn]);
-      }
-      if constexpr (NP >= 3) {
-#pragma unroll
-        for (int tm = 0; tm < MT; ++tm)
-#pragma unroll
-          for (int tn = 0; tn < 2; ++tn)
-            accc[tm][tn] = W4_MFMA(a[2 * tm + 1], bf[2 * tn], accc[tm][tn]);
-      }
-      if (s_ + 1 < 6) {
-        // next step's 12 fragment reads go out under the first 12 MFMAs (12 more to land), the VMEM
-        // issues are spread over the second half
-#pragma unroll
-        for (int g = 0; g < 2 * MT + 4; ++g) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        }
-#pragma unroll
-        for (int g = 0; g < 2 * NP * MT - (2 * MT + 4) - 3; ++g) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          if (g < n_dsw) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-          if (g < n_vmem) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
-        }
-      }
-#if F16X3_W4_EARLY_HANDOVER && !F16X3_W4_PREFETCH
-      if constexpr (HANDOVER) {
-        if (s_ == 5) {
-#pragma unroll
-          for (int g = 0; g < (IN_SPLIT ? ALD : 2 * ALD); ++g) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-          }
-        }
-      }
-#endif
-      __builtin_amdgcn_sched_barrier(0);
-#ifdef SHF_CONV_TIMING_STEPS
-      ts1 = __builtin_amdgcn_s_memtime();
-      tstep[s_] += ts1 - ts0;
-      ts0 = ts1;
-      __builtin_amdgcn_sched_barrier(0);
-#endif
-    }
-#ifdef SHF_CONV_TIMING
-    asm volatile("s_nop 0" ::: "memory");
-    SHF_T(t3);
-    tb += t1 - t0; tc += t3 - t1;
-#endif
-    if constexpr (HANDOVER && !(F16X3_W4_EARLY_HANDOVER && !F16X3_W4_PREFETCH)) {
-      __syncthreads();  // every wave is done reading the halo tile of chunk c
-#pragma unroll
-      for (int j = 0; j < ALD; ++j)
-        if (j + 1 < ALD || a_last) store_piece(areg[j], j);
-    }
-#ifdef SHF_CONV_TIMING
-    SHF_T(t0);
-    tx += t0 - t3;
-#endif
-  };
-  using std::integral_constant;
-  // the last chunk is peeled so that the loop body is one straight path (a hand-over / no-hand-over
-  // branch inside it makes the two arms disagree on accumulator registers and pay for it every turn)
-#pragma unroll 1
-  for (int c = 0; c + 1 < nchunks; ++c) {
-    stage(c, integral_constant<int, 0>{}, integral_constant<int, 0>{});
-    stage(c, integral_constant<int, 1>{}, integral_constant<int, 1>{});
-    stage(c, integral_constant<int, 2>{}, integral_constant<int, 2>{});
-  }
-  stage(nchunks - 1, integral_constant<int, 0>{}, integral_constant<int, 0>{});
-  stage(nchunks - 1, integral_constant<int, 1>{}, integral_constant<int, 0>{});
-  stage(nchunks - 1, integral_constant<int, 2>{}, integral_constant<int, 0>{});
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last stage's (unused) self re-fetch
-#ifdef SHF_CONV_TIMING
-  const unsigned long long t_loop_end = __builtin_amdgcn_s_memtime();
-#endif
-
-  float amax = 0.f;  // fp16 range guard: largest |output| of this lane
-#if F16X3_W4_REGEPI
-  // register epilogue (conv_common.h): the lane's pixel is row_to_pixel(i) of each M tile, its 16 couts follow kh
-  {
-    const bool relu = (p.relu & 1) != 0, write_main = !(p.relu & 8), main_split = (p.relu & 32) != 0,
-               pool_split = (p.relu & 64) != 0;
-    // (opaque copies: what is derived from them is computed HERE -- hipcc otherwise forms the lane's 64-bit channel
-    // offset before the K loop, spills it, and reloads it once per accumulator tile behind the stores already issued)
-    int px_e = px, dy_e = dy, kh_e = kh, i_e = i;
-    asm volatile("" : "+v"(px_e), "+v"(dy_e), "+v"(kh_e), "+v"(i_e));
-    const int Hp = (H + 1) >> 1, Wp = (W + 1) >> 1;
-    const bool interior = ty0 + TH <= H && tx0 + TW <= W;
-    const int x = tx0 + px_e;
-    float4 bias16[2][4];  // both cout tiles' biases up front: no lane address is carried across the stores
-#pragma unroll
-    for (int g = 0; g < 8; ++g)
-      bias16[g >> 2][g & 3] = *(const float4*)(biasL + wn * 64 + (g >> 2) * 32 + kh_e * 16 + 4 * (g & 3));
-#pragma unroll
-    for (int tn = 0; tn < 2; ++tn) {
-      const int cout16 = ct * BN + wn * 64 + tn * 32 + kh_e * 16;
-#pragma unroll
-      for (int tm = 0; tm < MT; ++tm) {
-        const int y = ty0 + wm * 2 * MT + tm * 2 + dy_e;
-        const bool valid = y < H && x < W;
-        float* pm = write_main ? gout + ((size_t)(b * H + y) * W + x) * p.out_stride : nullptr;
-        float* pp = mem.pool ? mem.pool + ((size_t)(b * Hp + (y >> 1)) * Wp + (x >> 1)) * p.pool_stride : nullptr;
-        if (relu)
-          conv_epilogue_regs<true>(accm[tm][tn], accc[tm][tn], LO_INV, bias16[tn], valid, interior, pm, cout16, main_split, pp,
-                                   valid && (i_e & 3) == 0, pool_split, amax);
-        else
-          conv_epilogue_regs<false>(accm[tm][tn], accc[tm][tn], LO_INV, bias16[tn], valid, interior, pm, cout16, main_split, pp,
-                                    valid && (i_e & 3) == 0, pool_split, amax);
-      }
-    }
-  }
-#else
-  if (p.relu & 16) {
-    __syncthreads();  // the K loop's LDS buffers are dead: the output tile is transposed through them
-    float* Cs = (float*)smem;
-#pragma unroll
-    for (int tn = 0; tn < 2; ++tn) {
-      const int cl = wn * 64 + tn * 32 + i;
-      const float bv = p.bias ? p.bias[ct * BN + cl] : 0.f;
-#pragma unroll
-      for (int tm = 0; tm < MT; ++tm) {
-        if (p.relu & 1)
-          conv_stage_tile_pk<BN, true>(Cs, accm[tm][tn], accc[tm][tn], LO_INV, bv, wm * 2 * MT + tm * 2, kh, cl, amax);
-        else
-          conv_stage_tile_pk<BN, false>(Cs, accm[tm][tn], accc[tm][tn], LO_INV, bv, wm * 2 * MT + tm * 2, kh, cl, amax);
-      }
-    }
-#ifdef SHF_CONV_TIMING_STEPS
-    const unsigned long long te1 = __builtin_amdgcn_s_memtime();
-#endif
-    __syncthreads();
-#ifdef SHF_CONV_TIMING_STEPS
-    const unsigned long long te2 = __builtin_amdgcn_s_memtime();
-#endif
-    conv_flush_tile<BN, NT, TH>(Cs, tid, ty0, tx0, H, W, b, ct * BN, gout, p.out_stride, mem.pool, p.pool_stride,
-                            !(p.relu & 8), (p.relu & 32) != 0, (p.relu & 64) != 0);
-#ifdef SHF_CONV_TIMING_STEPS
-    const unsigned long long te3 = __builtin_amdgcn_s_memtime();
-    if (wave == 0 && bid == 0 && lane == 0)
-      printf("[w4 epilogue] stage %llu barrier %llu flush-issue %llu\n", te1 - t_loop_end, te2 - te1, te3 - te2);
-#endif
-  } else {
-#pragma unroll
-    for (int tn = 0; tn < 2; ++tn) {
-      const int cout = ct * BN + wn * 64 + tn * 32 + i;
-      const float bv = p.bias ? p.bias[cout] : 0.f;
-#pragma unroll
-      for (int tm = 0; tm < MT; ++tm) {
-        const f32x16 am = accm[tm][tn], ac = accc[tm][tn];
-        conv_store_tile([&](int r) { return am[r] + ac[r] * LO_INV; }, bv, p.relu, ty0 + wm * 2 * MT + tm * 2, tx0,
-                        kh, H, W, b, cout, gout, p.out_stride, mem.pool, p.pool_stride, &amax);
-      }
-    }
-  }
-#endif
-#if !defined(F16X3_EXPERIMENT_NO_PROLOGUE) && !defined(F16X3_EXPERIMENT_NO_FRAG) && !defined(F16X3_EXPERIMENT_NO_BARRIER) && \
-    !defined(F16X3_EXPERIMENT_NO_HANDOVER) && !defined(F16X3_EXPERIMENT_NO_DMA) && !defined(F16X3_EXPERIMENT_HALF_DMA)
-  conv_raise_range_flag(p.range_flag, amax);
-#endif
-#ifdef SHF_CONV_TIMING
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  const unsigned long long t_exit = __builtin_amdgcn_s_memtime(), r_exit = __builtin_amdgcn_s_memrealtime();
-  // sampled blocks: two of the first round (every CU in its prologue at once) and two of later rounds
-  if (p.dbg && lane == 0 && wave < 4 && (bid == 0 || bid == 100 || bid == 700 || bid == 1500)) {
-    unsigned long long* d = p.dbg + ((bid == 0 ? 0 : bid == 100 ? 1 : bid == 700 ? 2 : 3) * 4 + wave) * 5;
-    d[0] = tb; d[1] = ((t_loop - t_entry) << 32) | (t_exit - t_loop_end); d[2] = tc; d[3] = tx;
-    d[4] = NST | ((t_exit - t_entry) << 16) | ((r_exit - r_entry) << 40);
-#ifdef SHF_CONV_TIMING_STEPS
-    if (wave == 0 && bid == 0)
-      printf("[w4 steps] per-stage cycles by k-step: %llu %llu %llu %llu %llu %llu\n", tstep[0] / NST, tstep[1] / NST,
-             tstep[2] / NST, tstep[3] / NST, tstep[4] / NST, tstep[5] / NST);
-#endif
-  }
-#endif
-}
-
-// PERSISTENT form of the 4-wave kernel (16x16-pixel tiles): one block per CU walks the tiles bid, bid + grid, ...
-// The stage pipeline simply runs on across tiles: the LAST stage of tile t requests the halo tile of tile t+1's first
-// chunk (the same register hand-over a chunk boundary uses) and its weight DMA fetches stage 0 of tile t+1 (grid is a
-// multiple of the cout-tile count, so a block keeps its cout tile and stage 0 is always the same slab), and both land
-// under tile t's epilogue -- the 9-10 k cycles a fresh block spends waiting for its first ~100 KB are paid once per
-// block instead of once per tile.  The epilogue therefore has to leave the halo tile and weight buffer 0 alone: the
-// output tile goes through LDS in four QUARTERS (tile rows {2q, 2q+1, 8+2q, 8+2q+1} = every wave's M-tile q, 64 px x
-// 128 couts = 36 KiB) staged in weight buffer 1, which the last stage (NST is even) has just finished with.
-// Everything tile-dependent is either wave-uniform (SGPRs) or recomputed in place (the 11 halo offsets, from an
-// opaque copy of the thread id so that the tile-invariant half of that arithmetic is not hoisted out of the tile
-// loop into 22 long-lived registers: DESIGN.md, hipcc lessons).
-template <bool IN_SPLIT, int MT_, int NP = 3>
-__global__ __launch_bounds__(256) void conv_mfma_f16x3_w4p_kernel(ConvK p) {
-  using namespace f16x3;
-  static_assert(MT_ == 4, "persistent form: 16-row tiles");
-  constexpr int TH = 4 * MT_, HTH = TH + 2, HP = HTH * HTW;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int BN = 128, MT = MT_, NT = 256;
-  constexpr int ALD = (HP * 8 + NT - 1) / NT;  // float4 halo pieces per thread: 11
-  constexpr int HPITCH = HTW * ROWB + F16X3_W4_ROWPAD;
-  unsigned char* As = smem;                    // [HTH][HPITCH]
-  unsigned char* Bs = smem + HTH * HPITCH;     // [2][3][BN][ROWB]
-  float* biasL = (float*)(Bs + 2 * 3 * BN * ROWB);  // [BN] this block's biases
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wn = wave & 1, wm = wave >> 1;
-  const int G = gridDim.x;                     // a multiple of nct (launcher)
-  int t_cur = blockIdx.x;
-  const int ct = t_cur % p.nct;
-
-  const int nchunks = p.Cin / KC;
-  const int NST = nchunks * 3;                 // even: Cin is a multiple of 64 on this path
-  const _Float16* wsp = (const _Float16*)p.wp;
-  const size_t slab = (size_t)p.Cout * 72;
-  const _Float16* wbase = wsp + (size_t)ct * BN * 72;
-
-  // ---- tile geometry: wave-uniform ----
-  struct Geo { int ty0, tx0, H, W, b; const float* in; float* out; float* pool; };
-  auto geometry = [&](int t) {
-    Geo g;
-    int pt = t / p.nct;
-    const int mi = conv_find_member(p, pt);
-    const ConvMember& mem = p.m[mi];
-    pt -= mem.tile_start;
-    int ty_, tx_;
-    conv_split_tile(mem, pt, g.b, ty_, tx_);
-    g.ty0 = ty_ * TH;
-    g.tx0 = tx_ * TW;
-    g.H = mem.H; g.W = mem.W;
-    g.in = mem.in; g.out = mem.out; g.pool = mem.pool;
-    return g;
-  };
-  // halo piece j of this thread: float4 q of halo pixel hp0 + 32 j.  Out-of-image pieces read the member's first
-  // pixel and are zeroed afterwards (bit j of a_valid).  exists = false: a block without a next tile fetches nothing real.
-  unsigned a_gsafe[ALD];  // BYTE offsets (unsigned: scalar base + 32-bit lane offset addressing, no 64-bit lane math)
-  unsigned a_valid = 0;
-  auto halo_offsets = [&](const Geo& g, bool exists) {
-    int tid_o = tid;
-    asm volatile("" : "+v"(tid_o));  // (opaque: keeps hy / hx / q of the 11 pieces out of the tile loop's live set)
-    a_valid = 0;
-#pragma unroll
-    for (int j = 0; j < ALD; ++j) {
-      const int idx = tid_o + NT * j;
-      const int hp = idx >> 3, q = idx & 7;
-      const int hy = hp / HTW, hx = hp - hy * HTW;
-      const int gy = g.ty0 - 1 + hy, gx = g.tx0 - 1 + hx;
-      const bool in = exists && (idx < HP * 8) && ((unsigned)gy < (unsigned)g.H) && ((unsigned)gx < (unsigned)g.W);
-      a_gsafe[j] = in ? (unsigned)(((g.b * g.H + gy) * g.W + gx) * p.in_stride + q * 4) * 4u : 0u;
-      a_valid |= in ? (1u << j) : 0u;
-    }
-  };
-  Geo go = geometry(t_cur);                    // the tile whose accumulators are live (epilogue geometry)
-  const float* __restrict__ gin = go.in;      // input of the tile whose halo pieces are fetched next
-  halo_offsets(go, true);
-
-  const int a_loff0 = (tid >> 3) * ROWB + (tid & 7) * 8;
-  const bool a_last = tid + NT * (ALD - 1) < HP * 8;
-  auto split_inplace = [&](float4& v, bool valid) {
-    if constexpr (IN_SPLIT) {
-      if (!valid) v = make_float4(0.f, 0.f, 0.f, 0.f);
-      return;
-    }
-    half4 hi, lo;
-    split4(valid ? v : make_float4(0.f, 0.f, 0.f, 0.f), hi, lo);
-    const float2 h2 = __builtin_bit_cast(float2, hi), l2 = __builtin_bit_cast(float2, lo);
-    v = make_float4(h2.x, h2.y, l2.x, l2.y);
-  };
-  auto store_piece = [&](const float4& v, int j) {
-    const int rowpad = (((tid >> 3) + 32 * j) / HTW) * F16X3_W4_ROWPAD;
-    if constexpr (IN_SPLIT) {
-      *(float4*)(As + (tid >> 3) * ROWB + (tid & 7) * 16 + j * 32 * ROWB + rowpad) = v;
-    } else {
-      *(float2*)(As + a_loff0 + j * 32 * ROWB + rowpad) = make_float2(v.x, v.y);
-      *(float2*)(As + a_loff0 + j * 32 * ROWB + rowpad + 64) = make_float2(v.z, v.w);
-    }
-  };
-  constexpr int SLAB_B = BN * ROWB;
-  constexpr int PCS_SLAB = SLAB_B / 1024;
-  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-  constexpr int DMA_ROUNDS_W4 = 15;
-  const unsigned lane16 = (unsigned)lane * 16u;
-  const int last_piece = wave_u + 16 < PCS_SLAB ? wave_u + 16 : PCS_SLAB - 1;
-  auto dma_w = [&](int stage, int buf, int j0, int n) {
-    const unsigned char* ws_ = (const unsigned char*)(wbase + (size_t)stage * 3 * slab);
-    unsigned char* bd_ = Bs + buf * (3 * SLAB_B);
-#pragma unroll
-    for (int j = j0; j < j0 + n; ++j) {
-      const int sl = j / 5, i5 = j % 5;
-      const int within = i5 < 4 ? wave_u + 4 * i5 : last_piece;
-      const unsigned char* ub = ws_ + (size_t)sl * slab * 2 + within * 1024;   // wave-uniform
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ub + lane16),
-                                       (__attribute__((address_space(3))) void*)(bd_ + sl * SLAB_B + within * 1024), 16, 0,
-                                       0);
-    }
-  };
-  // prologue of the block's FIRST tile
-  float4 areg0[ALD];
-  dma_w(0, 0, 0, DMA_ROUNDS_W4);
-#pragma unroll
-  for (int j = 0; j < ALD; ++j) areg0[j] = *(const float4*)((const char*)gin + a_gsafe[j]);
-  if (tid < BN) biasL[tid] = p.bias ? p.bias[ct * BN + tid] : 0.f;  // (visible after the first stage barrier)
-
-  const int i = lane & 31, kh = lane >> 5;
-  int dy, px;
-  row_to_pixel(i, dy, px);
-  int a_off[MT], b_off[2];
-#pragma unroll
-  for (int t = 0; t < MT; ++t) a_off[t] = (wm * 2 * MT + t * 2 + dy) * HPITCH + px * ROWB + kh * 16;
-#pragma unroll
-  for (int t = 0; t < 2; ++t) b_off[t] = (wn * 64 + t * 32 + i) * ROWB + kh * 16;
-  f32x16 accm[MT][2], accc[MT][2];
-#pragma unroll
-  for (int a = 0; a < MT; ++a)
-#pragma unroll
-    for (int c = 0; c < 2; ++c)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { accm[a][c][r] = 0.f; accc[a][c][r] = 0.f; }
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int j = 0; j < ALD; ++j) {
-    split_inplace(areg0[j], (a_valid >> j) & 1);
-    if (j + 1 < ALD || a_last) store_piece(areg0[j], j);
-  }
-
-  // one stage = kernel row KY of chunk c.  MODE 0: plain; 2 (last kernel row of a chunk): fetch, split and park the
-  // halo tile of chunk c+1; 3 (last stage of the tile): the same for chunk 0 of the NEXT tile (gin / a_gsafe already
-  // point there), and the weight DMA wraps to stage 0
-  float4 areg[ALD];
-  auto stage = [&](int c, auto KY_, auto MODE_, bool w0_waited = false) {
-    constexpr int ky = decltype(KY_)::value;
-    constexpr int MODE = decltype(MODE_)::value;
-    constexpr bool HANDOVER = MODE >= 2;
-    const int st = c * 3 + ky;
-    // this wave's share of W(st) has landed (w0_waited, wave-uniform: the first stage of a tile after the block's
-    // first -- W(0) was waited for before the epilogue's stores went out)
-    if (!w0_waited) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    int st_next = st + 1;
-    if constexpr (MODE == 3) {
-      // stage 0 again -- through an opaque zero, or the 15 per-lane DMA addresses of that stage become tile-loop
-      // invariants: 30 hoisted (and spilled) VGPRs whose reloads sit in front of the waits of this stage
-      st_next = 0;
-      asm volatile("" : "+s"(st_next));
-    }
-    const int buf_next = (st + 1) & 1;
-    const float* inc_ = MODE == 3 ? gin : gin + (c + 1) * KC;
-    const unsigned char* Arow = As + ky * HPITCH;
-    const unsigned char* Bst = Bs + (st & 1) * (3 * BN * ROWB);
-    half8 fa[2][2 * MT], fb[2][4];
-    auto load_frag = [&](int s_, half8* a, half8* bf) {
-      const unsigned char* Ap = Arow + (s_ >> 1) * ROWB + (s_ & 1) * 32;
-      const unsigned char* Bp = Bst + (s_ >> 1) * (BN * ROWB) + (s_ & 1) * 32;
-#pragma unroll
-      for (int t = 0; t < MT; ++t) {
-        a[2 * t] = *(const half8*)(Ap + a_off[t]);
-        a[2 * t + 1] = *(const half8*)(Ap + a_off[t] + 64);
-      }
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        bf[2 * t] = *(const half8*)(Bp + b_off[t]);
-        bf[2 * t + 1] = *(const half8*)(Bp + b_off[t] + 64);
-      }
-    };
-    load_frag(0, fa[0], fb[0]);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int s_ = 0; s_ < 6; ++s_) {
-      half8* a = fa[s_ & 1];
-      half8* bf = fb[s_ & 1];
-      if (s_ + 1 < 6) load_frag(s_ + 1, fa[(s_ + 1) & 1], fb[(s_ + 1) & 1]);
-      // (the tile's last stage front-loads its weight DMA: W(0) of the next tile is waited for right after this stage)
-      constexpr int DMA_J0[6] = {0, MODE == 3 ? 5 : 3, MODE == 3 ? 10 : 6, MODE == 3 ? 15 : 9, MODE == 3 ? 15 : 12, 15};
-      constexpr int DMA_N[6] = {MODE == 3 ? 5 : 3, MODE == 3 ? 5 : 3, MODE == 3 ? 5 : 3, MODE == 3 ? 0 : 3, MODE == 3 ? 0 : 3, 0};
-      if (DMA_N[s_]) dma_w(st_next, buf_next, DMA_J0[s_], DMA_N[s_]);
-      int n_vmem = DMA_N[s_];
-      if constexpr (HANDOVER) {
-        if (s_ < 2) {
-#pragma unroll
-          for (int j = s_ * 6; j < (s_ ? ALD : 6); ++j) areg[j] = *(const float4*)((const char*)inc_ + a_gsafe[j]);
-          n_vmem += s_ ? ALD - 6 : 6;
-        } else if (s_ >= 4) {
-#pragma unroll
-          for (int j = (s_ - 4) * 6; j < (s_ == 5 ? ALD : 6); ++j) split_inplace(areg[j], (a_valid >> j) & 1);
-        }
-      }
-#pragma unroll
-      for (int tm = 0; tm < MT; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < 2; ++tn)
-          accm[tm][tn] = W4_MFMA(a[2 * tm], bf[2 * tn], accm[tm][tn]);
-      if constexpr (NP >= 2) {
-#pragma unroll
-        for (int tm = 0; tm < MT; ++tm)
-#pragma unroll
-          for (int tn = 0; tn < 2; ++tn)
-            accc[tm][tn] = W4_MFMA(a[2 * tm], bf[2 * tn + 1], accc[tm][tn]);
-      }
-      if constexpr (NP >= 3) {
-#pragma unroll
-        for (int tm = 0; tm < MT; ++tm)
-#pragma unroll
-          for (int tn = 0; tn < 2; ++tn)
-            accc[tm][tn] = W4_MFMA(a[2 * tm + 1], bf[2 * tn], accc[tm][tn]);
-      }
-      if (s_ + 1 < 6) {
-#pragma unroll
-        for (int g = 0; g < 2 * MT + 4; ++g) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        }
-#pragma unroll
-        for (int g = 0; g < 2 * NP * MT - (2 * MT + 4) - 3; ++g) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          if (g < n_vmem) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    if constexpr (HANDOVER) {
-      __syncthreads();  // every wave is done reading the halo tile (and, MODE 3, weight buffer 1)
-#pragma unroll
-      for (int j = 0; j < ALD; ++j)
-        if (j + 1 < ALD || a_last) store_piece(areg[j], j);
-    }
-  };
-  using std::integral_constant;
-  float amax = 0.f;  // fp16 range guard: largest |output| of this lane
-  const bool relu = (p.relu & 1) != 0;
-  const bool write_main = !(p.relu & 8), main_split = (p.relu & 32) != 0, pool_split = (p.relu & 64) != 0;
-#ifdef SHF_W4P_TIMING
-  unsigned long long tk = 0, tl0 = 0, tg = 0, tl12 = 0, te[4] = {0, 0, 0, 0}, m0, m1;
-  int ntl = 0;
-#define W4P_T(x) x = __builtin_amdgcn_s_memtime()
-#else
-#define W4P_T(x)
-#endif
-#pragma unroll 1
-  for (;;) {
-    W4P_T(m0);
-    // the next tile's geometry (scalar loads + two integer divisions: ~2 k cycles of dependent latency) is requested
-    // here, a whole K loop before its first use
-    const int t_next = t_cur + G;
-    const bool has_next = t_next < p.ntile_blocks;
-    const Geo gn = geometry(has_next ? t_next : t_cur);
-#pragma unroll 1
-    for (int c = 0; c + 1 < nchunks; ++c) {
-      stage(c, integral_constant<int, 0>{}, integral_constant<int, 0>{}, c == 0 && t_cur != (int)blockIdx.x);
-      stage(c, integral_constant<int, 1>{}, integral_constant<int, 0>{});
-      stage(c, integral_constant<int, 2>{}, integral_constant<int, 2>{});
-    }
-    // (opaque: the peeled stages' weight-DMA addresses would otherwise be tile-loop invariants -- 45 hoisted VGPRs)
-    int c_last = nchunks - 1;
-    asm volatile("" : "+s"(c_last));
-#ifdef SHF_W4P_TIMING
-    W4P_T(m1); tk += m1 - m0; m0 = m1;
-#endif
-    stage(c_last, integral_constant<int, 0>{}, integral_constant<int, 0>{});
-#ifdef SHF_W4P_TIMING
-    W4P_T(m1); tl0 += m1 - m0; m0 = m1;
-#endif
-    // the current tile's input is fully in LDS: gin / a_gsafe / a_valid move on to the next tile
-    gin = gn.in;
-    halo_offsets(gn, has_next);
-#ifdef SHF_W4P_TIMING
-    W4P_T(m1); tg += m1 - m0; m0 = m1;
-#endif
-    stage(c_last, integral_constant<int, 1>{}, integral_constant<int, 0>{});
-    stage(c_last, integral_constant<int, 2>{}, integral_constant<int, 3>{});
-#ifdef SHF_W4P_TIMING
-    W4P_T(m1); tl12 += m1 - m0; m0 = m1; ++ntl;
-#endif
-
-    // register epilogue (conv_common.h): no LDS, no barrier -- the halo tile and W(0) of the next tile stay untouched.
-    // This wave's share of W(0) is waited for HERE, before the stores go out: the next tile's first stage then needs
-    // no vmcnt(0), which would sit behind these stores.
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#ifdef SHF_W4P_TIMING
-    W4P_T(m1); te[1] += m1 - m0; m0 = m1;
-#endif
-    {
-      // (opaque copies: the pixel / cout byte offsets derived from them are tile-invariant 64-bit values that would
-      // otherwise live -- spilled -- across the K loop, and every reload here waits behind the stores already issued)
-      int px_e = px, dy_e = dy, kh_e = kh, i_e = i;
-      asm volatile("" : "+v"(px_e), "+v"(dy_e), "+v"(kh_e), "+v"(i_e));
-      const int Hp = (go.H + 1) >> 1, Wp = (go.W + 1) >> 1;
-      const bool interior = go.ty0 + TH <= go.H && go.tx0 + TW <= go.W;
-      const int x = go.tx0 + px_e;
-      float4 bias16[2][4];  // both cout tiles' biases up front: no lane address is carried across the stores
-#pragma unroll
-      for (int g = 0; g < 8; ++g)
-        bias16[g >> 2][g & 3] = *(const float4*)(biasL + wn * 64 + (g >> 2) * 32 + kh_e * 16 + 4 * (g & 3));
-#pragma unroll
-      for (int tn = 0; tn < 2; ++tn) {
-        const int cout16 = ct * BN + wn * 64 + tn * 32 + kh_e * 16;
-#pragma unroll
-        for (int tm = 0; tm < MT; ++tm) {
-          const int y = go.ty0 + wm * 2 * MT + tm * 2 + dy_e;
-          const bool valid = y < go.H && x < go.W;
-          float* pm = write_main ? go.out + ((size_t)(go.b * go.H + y) * go.W + x) * p.out_stride : nullptr;
-          float* pp = go.pool ? go.pool + ((size_t)(go.b * Hp + (y >> 1)) * Wp + (x >> 1)) * p.pool_stride : nullptr;
-          if (relu)
-            conv_epilogue_regs<true>(accm[tm][tn], accc[tm][tn], LO_INV, bias16[tn], valid, interior, pm, cout16, main_split, pp,
-                                     valid && (i_e & 3) == 0, pool_split, amax);
-          else
-            conv_epilogue_regs<false>(accm[tm][tn], accc[tm][tn], LO_INV, bias16[tn], valid, interior, pm, cout16, main_split, pp,
-                                      valid && (i_e & 3) == 0, pool_split, amax);
-#pragma unroll
-          for (int r = 0; r < 16; ++r) { accm[tm][tn][r] = 0.f; accc[tm][tn][r] = 0.f; }
-        }
-#ifdef SHF_W4P_TIMING
-        W4P_T(m1); te[2 + tn] += m1 - m0; m0 = m1;
-#endif
-      }
-    }
-#ifdef SHF_W4P_TIMING
-    W4P_T(m1); te[0] += m1 - m0; m0 = m1;
-#endif
-    if (!has_next) break;
-    t_cur = t_next;
-    go = gn;
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last stage's (unused) weight re-fetch
-#ifdef SHF_W4P_TIMING
-  if (lane == 0 && wave == 0 && (blockIdx.x == 0 || blockIdx.x == 100))
-    printf("[w4p] blk%d tiles %d stages/tile %d: per tile cycles: chunks0..n-2 %llu | last ky0 %llu | geometry %llu | last ky1+ky2 %llu | "
-           "epilogue quarters %llu %llu %llu %llu\n", (int)blockIdx.x, ntl, NST, tk / ntl, tl0 / ntl, tg / ntl, tl12 / ntl, te[0] / ntl,
-           te[1] / ntl, te[2] / ntl, te[3] / ntl);
-#endif
-  conv_raise_range_flag(p.range_flag, amax);
+  conv_publish_amax(mem.out_amax, mem.pool ? mem.pool_amax : nullptr, amax);
 }
 
 // DUAL-TILE form of the 4-wave kernel: a block computes TWO 16x16-pixel tiles (consecutive in the launch's tile order)
@@ -1383,7 +478,7 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4d_kernel(ConvK p) {
   const int pp = bid / p.nct;
   const int ntiles = p.ntile_blocks / p.nct;          // the launch covers pixel tiles [tile_base, ntiles) of the group
 
-  struct Geo { int ty0, tx0, H, W, b; const float* in; float* out; float* pool; };
+  struct Geo { int ty0, tx0, H, W, b; const float* in; float* out; float* pool; const unsigned* in_amax; unsigned* out_amax; unsigned* pool_amax; };
   auto geometry = [&](int t) {
     Geo g;
     int pt = t;
@@ -1396,6 +491,7 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4d_kernel(ConvK p) {
     g.tx0 = tx_ * TW;
     g.H = mem.H; g.W = mem.W;
     g.in = mem.in; g.out = mem.out; g.pool = mem.pool;
+    g.in_amax = mem.in_amax; g.out_amax = mem.out_amax; g.pool_amax = mem.pool_amax;
     return g;
   };
   const int t0 = p.tile_base + NTILE * pp;
@@ -1433,31 +529,48 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4d_kernel(ConvK p) {
   auto chunk_off = [&](int c16) -> unsigned {
     return IN_SPLIT ? (unsigned)((c16 >> 1) * 128 + (c16 & 1) * 32) : (unsigned)(c16 * 64);
   };
+  // ACTIVATION EXPONENT (conv_common.h): the tile's unit publishes max |input| (its producers' epilogues); the halo
+  // staging multiplies hi by 2^e and the format's lo (which carries 2^11) by 2^(e - 11), exactly, in fp16 -- the top of
+  // the unit's input lands in [2^13, 2^14), so the UNSCALED low parts the single accumulator needs are normal fp16
+  // numbers whatever the layer's magnitude (without it a layer living around 1e-3 kept 14 bits, not 22) -- and the
+  // epilogue multiplies 2^-e back together with the weights' scale.  e = e1 + e2 with both factors representable in
+  // fp16 (2^15 is the largest power of two); a scale-down (e < 11, the lo factor) is never followed by a scale-up.
+  // e is a function of the unit alone, so every grouping of tiles into launches / blocks forms the same bits.
+  const int e_t0 = __builtin_amdgcn_readfirstlane(conv_act_exponent(g0.in_amax));
+  const int e_t1 = NTILE == 2 ? __builtin_amdgcn_readfirstlane(conv_act_exponent(g1.in_amax)) : 0;
+  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+  // pk_f1 = this thread's first factor for a split-format piece (its pieces are all hi or all lo: q = tid & 3), hi1 / lo1
+  // = the two first factors of an fp32 piece, f2 = the common second factor -- plain registers, no struct (hipcc parks a
+  // struct that is indexed by a lane-dependent select in scratch memory)
+  struct ActScale { unsigned pk_f1, hi1, lo1, f2; };
+  const int lo_shift = (tid & 2) ? 11 : 0;
+  auto act_scale = [&](int e) {
+    const int e1 = e < 15 ? e : 15;
+    return ActScale{conv_pk_pow2_f16(e1 - lo_shift), conv_pk_pow2_f16(e1), conv_pk_pow2_f16(e1 - 11), conv_pk_pow2_f16(e - e1)};
+  };
+  const ActScale as0 = act_scale(e_t0), as1 = act_scale(e_t1);
   // piece as fetched -> the 16 bytes (split input) / the hi half4 | lo half4 pair (fp32 input) that go to LDS
-  const float lo_unscale = (tid & 2) ? 1.0f / LO_SCALE : 1.0f;   // (q = tid & 3 for every piece of this thread)
-  auto convert = [&](float4& v, bool valid) {
+  auto convert = [&](float4& v, bool valid, const ActScale& sc_) {
     if (!valid) v = make_float4(0.f, 0.f, 0.f, 0.f);
+    struct { h2 hi1, lo1, f2; } sc = {__builtin_bit_cast(h2, sc_.hi1), __builtin_bit_cast(h2, sc_.lo1), __builtin_bit_cast(h2, sc_.f2)};
     if constexpr (IN_SPLIT) {
-      typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-      const h2 f = {(_Float16)lo_unscale, (_Float16)lo_unscale};
+      const h2 f1 = __builtin_bit_cast(h2, sc_.pk_f1);
       float* e = &v.x;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         h2 x = __builtin_bit_cast(h2, e[k]);
-        x = x * f;
+        x = (x * f1) * sc.f2;
         e[k] = __builtin_bit_cast(float, x);
       }
     } else {
-      typedef _Float16 h2 __attribute__((ext_vector_type(2)));
       const f32x2 x01 = {v.x, v.y}, x23 = {v.z, v.w};
+      // (lo through the split activation format's 2^11, like a producer's epilogue + the staging above would: the two
+      // input formats then give the same bits even where hi or lo is an fp16 subnormal)
       const h2 h01 = __builtin_convertvector(x01, h2), h23 = __builtin_convertvector(x23, h2);
-      // (lo through the split activation format's 2^11, like a producer's epilogue + the unscale above would: the two
-      // input formats then give the same bits even where lo is an fp16 subnormal)
-      const h2 un = {(_Float16)(1.0f / LO_SCALE), (_Float16)(1.0f / LO_SCALE)};
-      const h2 l01 = __builtin_convertvector((x01 - __builtin_convertvector(h01, f32x2)) * LO_SCALE, h2) * un;
-      const h2 l23 = __builtin_convertvector((x23 - __builtin_convertvector(h23, f32x2)) * LO_SCALE, h2) * un;
-      v = make_float4(__builtin_bit_cast(float, h01), __builtin_bit_cast(float, h23), __builtin_bit_cast(float, l01),
-                      __builtin_bit_cast(float, l23));
+      const h2 l01 = __builtin_convertvector((x01 - __builtin_convertvector(h01, f32x2)) * LO_SCALE, h2);
+      const h2 l23 = __builtin_convertvector((x23 - __builtin_convertvector(h23, f32x2)) * LO_SCALE, h2);
+      v = make_float4(__builtin_bit_cast(float, (h01 * sc.hi1) * sc.f2), __builtin_bit_cast(float, (h23 * sc.hi1) * sc.f2),
+                      __builtin_bit_cast(float, (l01 * sc.lo1) * sc.f2), __builtin_bit_cast(float, (l23 * sc.lo1) * sc.f2));
     }
   };
   auto store_piece = [&](const float4& v, int t, int j) {
@@ -1521,13 +634,13 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4d_kernel(ConvK p) {
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int j = 0; j < ALD; ++j) {
-    convert(areg0[j], (a_valid >> j) & 1);
+    convert(areg0[j], (a_valid >> j) & 1, as0);
     if (j + 1 < ALD || a_last) store_piece(areg0[j], 0, j);
   }
   if constexpr (NTILE == 2) {
 #pragma unroll
     for (int j = 0; j < ALD; ++j) {
-      convert(areg1[j], (a_valid >> (8 + j)) & 1);
+      convert(areg1[j], (a_valid >> (8 + j)) & 1, as1);
       if (j + 1 < ALD || a_last) store_piece(areg1[j], 1, j);
     }
   }
@@ -1536,15 +649,9 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4d_kernel(ConvK p) {
   // convert and park both halo tiles of chunk c + 1
   auto stage = [&](int c, auto KY_, auto HAND_) {
     constexpr int ky = decltype(KY_)::value;
-#ifdef F16X3_EXPERIMENT_NO_HANDOVER   // timing only (WRONG results)
-    constexpr bool HANDOVER = false;
-#else
     constexpr bool HANDOVER = decltype(HAND_)::value != 0;
-#endif
     const int st = c * 3 + ky;
-#ifndef F16X3_EXPERIMENT_NO_WAIT   // timing only (racy weights): what waiting for the weight DMA costs
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of W(st) has landed
-#endif
     __syncthreads();
     const int st_next = st + 1 < NST ? st + 1 : st;   // the last stage re-fetches itself (unused) instead of branching
     const int buf_next = (st + 1) & 1;
@@ -1582,11 +689,7 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4d_kernel(ConvK p) {
       int n_ds = 0;
       if (h + 1 < NH) { load_a(h + 1, fa[(h + 1) & 1]); n_ds += 2 * MT; }
       if (tl == 0 && kx + 1 < 3) { load_b(kx + 1, fb[(kx + 1) & 1]); n_ds += 4; }
-#if defined(F16X3_EXPERIMENT_ONE_DMA)   // timing only (WRONG results): one round per stage
-      if (h == 0) dma_w(st_next, buf_next, 0, 1);
-#elif !defined(F16X3_EXPERIMENT_NO_DMA)   // timing only (WRONG results)
       if (dma_n) dma_w(st_next, buf_next, dma_j, dma_n);
-#endif
       int n_vmem = dma_n;
       if constexpr (HANDOVER) {
         // tile 0's / tile 1's pieces of the next chunk are requested in the first half-steps (converted and parked
@@ -1643,13 +746,13 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4d_kernel(ConvK p) {
       __syncthreads();  // every wave is done reading the halo tiles of chunk c
 #pragma unroll
       for (int j = 0; j < ALD; ++j) {
-        convert(areg0[j], (a_valid >> j) & 1);
+        convert(areg0[j], (a_valid >> j) & 1, as0);
         if (j + 1 < ALD || a_last) store_piece(areg0[j], 0, j);
       }
       if constexpr (NTILE == 2) {
 #pragma unroll
         for (int j = 0; j < ALD; ++j) {
-          convert(areg1[j], (a_valid >> (8 + j)) & 1);
+          convert(areg1[j], (a_valid >> (8 + j)) & 1, as1);
           if (j + 1 < ALD || a_last) store_piece(areg1[j], 1, j);
         }
       }
@@ -1667,8 +770,8 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4d_kernel(ConvK p) {
   stage(nchunks - 1, integral_constant<int, 2>{}, integral_constant<int, 0>{});
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last stage's (unused) self re-fetch
 
-  // register epilogue, one tile after the other
-  float amax = 0.f;
+  // register epilogue, one tile after the other (each with its unit's scale and its unit's max |output| slot)
+  float amax0 = 0.f, amax1 = 0.f;
   {
     const bool relu = (p.relu & 1) != 0, write_main = !(p.relu & 8), main_split = (p.relu & 32) != 0,
                pool_split = (p.relu & 64) != 0;
@@ -1678,7 +781,8 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4d_kernel(ConvK p) {
 #pragma unroll
     for (int g = 0; g < 8; ++g)
       bias16[g >> 2][g & 3] = *(const float4*)(biasL + wn * 64 + (g >> 2) * 32 + kh_e * 16 + 4 * (g & 3));
-    auto tile_out = [&](f32x16 (&acc)[MT][2], const Geo& g, bool exists) {
+    auto tile_out = [&](f32x16 (&acc)[MT][2], const Geo& g, bool exists, int e_act, float& amax) {
+      const float out_scale = p.wscale_inv * __builtin_bit_cast(float, (unsigned)(127 - e_act) << 23);   // 2^-e, exact
       const int Hp = (g.H + 1) >> 1, Wp = (g.W + 1) >> 1;
       const bool interior = exists && g.ty0 + TH <= g.H && g.tx0 + TW <= g.W;
       const int x = g.tx0 + px_e;
@@ -1692,20 +796,22 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4d_kernel(ConvK p) {
           float* pm = write_main ? g.out + ((size_t)(g.b * g.H + y) * g.W + x) * p.out_stride : nullptr;
           float* pq = g.pool ? g.pool + ((size_t)(g.b * Hp + (y >> 1)) * Wp + (x >> 1)) * p.pool_stride : nullptr;
           if (relu)
-            conv_epilogue_regs1<true>(acc[tm][tn], p.wscale_inv, bias16[tn], valid, interior, pm, cout16, main_split, pq,
+            conv_epilogue_regs1<true>(acc[tm][tn], out_scale, bias16[tn], valid, interior, pm, cout16, main_split, pq,
                                       valid && (i_e & 3) == 0, pool_split, amax);
           else
-            conv_epilogue_regs1<false>(acc[tm][tn], p.wscale_inv, bias16[tn], valid, interior, pm, cout16, main_split, pq,
+            conv_epilogue_regs1<false>(acc[tm][tn], out_scale, bias16[tn], valid, interior, pm, cout16, main_split, pq,
                                        valid && (i_e & 3) == 0, pool_split, amax);
         }
       }
     };
-    tile_out(acc0, g0, true);
-    if constexpr (NTILE == 2) tile_out(acc1, g1, has1);
+    tile_out(acc0, g0, true, e_t0, amax0);
+    if constexpr (NTILE == 2) tile_out(acc1, g1, has1, e_t1, amax1);
   }
-#if !defined(F16X3_EXPERIMENT_NO_DMA) && !defined(F16X3_EXPERIMENT_NO_HANDOVER) && !defined(F16X3_EXPERIMENT_NO_WAIT) && !defined(F16X3_EXPERIMENT_ONE_DMA)
-  conv_raise_range_flag(p.range_flag, amax);
-#endif
+  conv_raise_range_flag(p.range_flag, fmaxf(amax0, amax1));
+  conv_publish_amax(g0.out_amax, g0.pool ? g0.pool_amax : nullptr, amax0);
+  if constexpr (NTILE == 2) {
+    if (has1) conv_publish_amax(g1.out_amax, g1.pool ? g1.pool_amax : nullptr, amax1);   // (wave-uniform)
+  }
 }
 
 // Producer / consumer variant of the fused first pair (conv1_1 -> conv1_2, Cin = Cout = 64).  With only
@@ -1958,7 +1064,7 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
   // epilogue: transposed through LDS (conv_common.h), all 512 threads flush
   __syncthreads();
   float* Cs = (float*)smem;
-  float amax = amax1;  // fp16 range guard: conv1_1's outputs (prologue) and this layer's
+  float amax = 0.f;  // this layer's stored outputs: fp16 range guard (with conv1_1's, amax1) + activation exponent
   if (consumer) {
 #pragma unroll
     for (int tn = 0; tn < 2; ++tn) {
@@ -1967,16 +1073,17 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
 #pragma unroll
       for (int tm = 0; tm < MT; ++tm) {
         if (p.relu & 1)
-          conv_stage_tile_pk<BN, true>(Cs, accm[tm][tn], accc[tm][tn], LO_INV, bv, wm * 2 * MT + tm * 2, kh, cl, amax);
+          conv_stage_tile_pk<BN, true>(Cs, accm[tm][tn], accc[tm][tn], LO_INV, bv, wm * 2 * MT + tm * 2, kh, cl, amax, H - ty0, W - tx0);
         else
-          conv_stage_tile_pk<BN, false>(Cs, accm[tm][tn], accc[tm][tn], LO_INV, bv, wm * 2 * MT + tm * 2, kh, cl, amax);
+          conv_stage_tile_pk<BN, false>(Cs, accm[tm][tn], accc[tm][tn], LO_INV, bv, wm * 2 * MT + tm * 2, kh, cl, amax, H - ty0, W - tx0);
       }
     }
   }
   __syncthreads();
   conv_flush_tile<BN, 512>(Cs, tid, ty0, tx0, H, W, b, 0, gout, p.out_stride, mem.pool, p.pool_stride, !(p.relu & 8),
                            (p.relu & 32) != 0, (p.relu & 64) != 0);
-  conv_raise_range_flag(p.range_flag, amax);
+  conv_raise_range_flag(p.range_flag, fmaxf(amax, amax1));
+  conv_publish_amax(mem.out_amax, mem.pool ? mem.pool_amax : nullptr, amax);
   PC_T();
 #ifdef SHF_CONV_TIMING
   if (bid == 100 && lane == 0 && (wave == 0 || wave == 4 || wave == 7))
@@ -2042,22 +1149,55 @@ float pack_conv_weights_split16h(const float* w, int Cout, int Cin, int k, void*
   return 1.0f / s;
 }
 
-// (net.cpp: will launch_conv_f16x3_group(as, n) take the dual-tile family?  Then the sub-launch hook does the profiling.)
-bool conv_f16x3_group_is_dual(const ConvArgs* as, int n) {
-  if (!conv_f16x3_w4_dual() || !as[0].wsplit16h || as[0].img || as[0].k != 3 || as[0].dil != 1 || as[0].out.C % 128) return false;
-  if (!conv_f16x3_uses_w4(as[0].in.C)) return false;
+
+// Environment knobs (experiments; the defaults are the measured best), read ONCE: none of them is consulted per launch.
+namespace {
+struct Knobs {
+  int w4_mode;         // SHF_F16X3_W4: -1 auto (Cin >= 128), 0 never, 1 always -- which layers take the 4-wave dual-tile family
+  int w4_mt;           // SHF_F16X3_W4_MT: 0 auto, 2 / 4 force 8- / 16-row tiles
+  int w4d_ntile;       // SHF_F16X3_W4D_NTILE: 0 auto (hybrid launches), 1 / 2 force single- / two-tile blocks
+  bool pc, dilated, k1, scalar_epilogue;   // SHF_F16X3_PC, SHF_F16X3_DILATED, SHF_F16X3_1X1 (default on), SHF_CONV_SCALAR_EPILOGUE (off)
+  int cus;
+};
+int env_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
+const Knobs& knobs() {
+  static const Knobs k = [] {
+    Knobs q;
+    q.w4_mode = env_int("SHF_F16X3_W4", -1);
+    q.w4_mt = env_int("SHF_F16X3_W4_MT", 0);
+    q.w4d_ntile = env_int("SHF_F16X3_W4D_NTILE", 0);
+    q.pc = env_int("SHF_F16X3_PC", 1) != 0;
+    q.dilated = env_int("SHF_F16X3_DILATED", 1) != 0;
+    q.k1 = env_int("SHF_F16X3_1X1", 1) != 0;
+    q.scalar_epilogue = env_int("SHF_CONV_SCALAR_EPILOGUE", 0) != 0;
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 4)
+      cus = 256;
+    q.cus = cus;
+    return q;
+  }();
+  return k;
+}
+// 16-byte aligned channel views: what the vector epilogues (LDS-transposed and register) need
+bool views_aligned(const ConvArgs* as, int n) {
   for (int i = 0; i < n; ++i) {
     const ConvArgs& q = as[i];
     if ((q.out.cstride % 4) || (q.out.coff % 4) || ((uintptr_t)q.out.p & 15)) return false;
     if (q.pool.p && ((q.pool.cstride % 4) || (q.pool.coff % 4) || ((uintptr_t)q.pool.p & 15))) return false;
-    if ((unsigned long long)q.in.B * q.in.H * q.in.W * q.in.cstride * 4ull >= (1ull << 32)) return false;
   }
-  return !(getenv("SHF_CONV_SCALAR_EPILOGUE") && atoi(getenv("SHF_CONV_SCALAR_EPILOGUE")));
+  return true;
 }
+}  // namespace
 
-bool conv_f16x3_w4_dual() {
-  static const int v = getenv("SHF_F16X3_W4D") ? atoi(getenv("SHF_F16X3_W4D")) : 1;
-  return v != 0;
+// (net.cpp: will launch_conv_f16x3_group(as, n) take the dual-tile family?  Then the sub-launch hook does the profiling.)
+// The family addresses its input with 32-bit BYTE offsets from the member's base: inputs of 4 GiB and more, and
+// unaligned views (scalar epilogue), take the 8-wave kernel.
+bool conv_f16x3_group_is_dual(const ConvArgs* as, int n) {
+  if (!as[0].wsplit16h || as[0].img || as[0].k != 3 || as[0].dil != 1 || as[0].out.C % 128) return false;
+  if (!conv_f16x3_uses_w4(as[0].in.C) || knobs().scalar_epilogue || !views_aligned(as, n)) return false;
+  for (int i = 0; i < n; ++i)
+    if ((unsigned long long)as[i].in.B * as[i].in.H * as[i].in.W * as[i].in.cstride * 4ull >= (1ull << 32)) return false;
+  return true;
 }
 
 void pack_first_conv_frags(const float* w, void* dst_) {
@@ -2075,42 +1215,22 @@ void pack_first_conv_frags(const float* w, void* dst_) {
         }
 }
 
-bool conv_f16x3_uses_pc() {
-  static const bool on = !(getenv("SHF_F16X3_PC") && atoi(getenv("SHF_F16X3_PC")) == 0);
-  return on;
-}
+bool conv_f16x3_uses_pc() { return knobs().pc; }
 
-bool conv_f16x3_uses_w4(int Cin) {
-  static const int w4_mode = getenv("SHF_F16X3_W4") ? atoi(getenv("SHF_F16X3_W4")) : -1;
-  return w4_mode < 0 ? Cin >= 128 : w4_mode != 0;
-}
+bool conv_f16x3_uses_w4(int Cin) { return knobs().w4_mode < 0 ? Cin >= 128 : knobs().w4_mode != 0; }
 
 bool conv_f16x3_eligible(int Cin, int Cout, int k, int pad, int dil) {
-  static const bool heads = !(getenv("SHF_F16X3_DILATED") && atoi(getenv("SHF_F16X3_DILATED")) == 0);
-  const bool dil_ok = dil == 1 || (heads && (dil == 2 || dil == 4));
-  static const bool k1 = !(getenv("SHF_F16X3_1X1") && atoi(getenv("SHF_F16X3_1X1")) == 0);
-  if (k == 1) return k1 && pad == 0 && Cin % 32 == 0 && Cout % 64 == 0;
+  const bool dil_ok = dil == 1 || (knobs().dilated && (dil == 2 || dil == 4));
+  if (k == 1) return knobs().k1 && pad == 0 && Cin % 32 == 0 && Cout % 64 == 0;
   return k == 3 && dil_ok && pad == dil && Cin % 32 == 0 && Cout % 64 == 0;
 }
 
-// 4-wave kernel: 16-row tiles (MT 4) or 8-row tiles (MT 2)?  A launch runs in ceil(blocks / CUs) rounds of one block
+// 4-wave family: 16-row tiles (MT 4) or 8-row tiles (MT 2)?  A launch runs in ceil(blocks / CUs) rounds of one block
 // per CU; an 8-row block costs ~0.56 of a 16-row one (half the MFMAs, the same weight traffic per stage and the same
 // prologue / epilogue latencies).  SHF_F16X3_W4_MT = 2 / 4 forces the choice (experiments).
-// persistent 4-wave kernel for the 16-row launches (SHF_F16X3_W4P = 0 / 1)
-bool conv_f16x3_w4_persistent() {
-  static const int v = getenv("SHF_F16X3_W4P") ? atoi(getenv("SHF_F16X3_W4P")) : 0;
-  return v != 0;
-}
-
 static int w4_pick_mt(const ConvArgs* as, int n, int nct) {
-  static const int forced = getenv("SHF_F16X3_W4_MT") ? atoi(getenv("SHF_F16X3_W4_MT")) : 0;
-  if (forced == 2 || forced == 4) return forced;
-  static int cus = 0;
-  if (!cus) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
-      cus = 256;
-  }
+  if (knobs().w4_mt == 2 || knobs().w4_mt == 4) return knobs().w4_mt;
+  const int cus = knobs().cus;
   long long t4 = 0, t2 = 0;
   for (int i = 0; i < n; ++i) {
     const long long tx = (as[i].in.W + f16x3::TW - 1) / f16x3::TW, B = as[i].in.B;
@@ -2134,6 +1254,7 @@ static int launch_f16x3_t(const ConvArgs* as, int n, hipStream_t s) {
   p.wph = nullptr;
   p.wscale_inv = 1.f;
   p.tile_base = 0;
+  p.ntile_blocks = 0;
   p.bias = a.bias;
   p.Cin = a.in.C; p.Cout = a.out.C;
   p.in_stride = a.in.cstride; p.out_stride = a.out.cstride;
@@ -2148,21 +1269,10 @@ static int launch_f16x3_t(const ConvArgs* as, int n, hipStream_t s) {
   p.w1f = a.w1f;
   p.b1 = a.b1;
   long long tiles = 0;
-  bool vec_ok = !(getenv("SHF_CONV_SCALAR_EPILOGUE") && atoi(getenv("SHF_CONV_SCALAR_EPILOGUE")));
-  for (int i = 0; i < n; ++i) {
-    const ConvArgs& q = as[i];
-    vec_ok = vec_ok && (q.out.cstride % 4 == 0) && (q.out.coff % 4 == 0) && (((uintptr_t)q.out.p & 15) == 0) &&
-             (!q.pool.p || ((q.pool.cstride % 4 == 0) && (q.pool.coff % 4 == 0) && (((uintptr_t)q.pool.p & 15) == 0)));
-  }
-  // tile height: 16 rows, or 8 for the 4-wave kernel when that quantises better on this chip (w4_pick_mt).  The 4-wave
-  // kernels write 16-byte pieces from registers: unaligned views go through the 8-wave kernel's scalar epilogue.
-  // (... and address their input with 32-bit BYTE offsets from the member's base: inputs of 4 GiB and more take the 8-wave path)
-  bool in_fits32 = true;
-  for (int i = 0; i < n; ++i)
-    in_fits32 = in_fits32 && (unsigned long long)as[i].in.B * as[i].in.H * as[i].in.W * as[i].in.cstride * 4ull < (1ull << 32);
-  const bool w4_path = BN == 128 && !FUSE1 && DIL == 1 && KS == 3 && conv_f16x3_uses_w4(p.Cin) && (vec_ok || !F16X3_W4_REGEPI) &&
-                       in_fits32;
-  const int mt = w4_path ? w4_pick_mt(as, n, p.nct) : 4;
+  const bool vec_ok = !knobs().scalar_epilogue && views_aligned(as, n);
+  // the dual-tile 4-wave family (16- or 8-row tiles, w4_pick_mt) or this template's 8-wave kernel
+  const bool dual = BN == 128 && !FUSE1 && DIL == 1 && KS == 3 && conv_f16x3_group_is_dual(as, n);
+  const int mt = dual ? w4_pick_mt(as, n, p.nct) : 4;
   const int th = 4 * mt;
   for (int i = 0; i < n; ++i) {
     const ConvArgs& q = as[i];
@@ -2178,6 +1288,7 @@ static int launch_f16x3_t(const ConvArgs* as, int n, hipStream_t s) {
     m.out = q.out.p + q.out.coff;
     m.pool = q.pool.p ? q.pool.p + q.pool.coff : nullptr;
     m.img = q.img;
+    m.in_amax = q.in_amax; m.out_amax = q.out_amax; m.pool_amax = q.pool.p ? q.pool_amax : nullptr;
     m.B = q.in.B; m.H = q.in.H; m.W = q.in.W;
     m.tiles_x = (m.W + TW - 1) / TW;
     m.tiles_per_img = m.tiles_x * ((m.H + th - 1) / th);
@@ -2186,7 +1297,13 @@ static int launch_f16x3_t(const ConvArgs* as, int n, hipStream_t s) {
     m.tile_start = (int)tiles;
     p.tile_starts[i] = (int)tiles;
     tiles += (long long)m.tiles_per_img * m.B;
+    // conv_split_tile's multiply-high quotients are exact while tile index x divisor < 2^32
+    if ((unsigned long long)m.tiles_per_img * m.B * (unsigned long long)m.tiles_per_img >= (1ull << 32)) {
+      set_error("conv f16x3: more than 2^32 / tiles-per-image pixel tiles in one member (shrink the batch or the map)");
+      return -1;
+    }
   }
+  if (tiles * p.nct >= (1ll << 31)) { set_error("conv f16x3: grid too large"); return -1; }
   if (vec_ok) p.relu |= 16;
   if (a.out_split || a.pool_split) {
     if (!vec_ok) { set_error("conv f16x3: split-format output needs the aligned epilogue"); return -1; }
@@ -2201,124 +1318,70 @@ static int launch_f16x3_t(const ConvArgs* as, int n, hipStream_t s) {
   hipMemset(dbg_dev, 0, 16 * 5 * 8);
   p.dbg = dbg_dev;
 #endif
-  // the 4-wave kernel has the faster K loop (~6.2 k cycles per stage against ~7 k) but the dearer
-  // prologue / epilogue (half the waves to fetch the first tiles and to write the result): it wins from
-  // 4 input-channel chunks (Cin 128) up.  SHF_F16X3_W4 = 0 / 1 forces never / always (experiments).
   if (FUSE1 && BN == 64 && conv_f16x3_uses_pc() && vec_ok && p.Cin == 64 && p.Cout == 64 && p.w1f) {
     // two halo tiles (both channel chunks of conv1_1's output) + the weight double buffer + the image patch
     constexpr size_t HPP = (HP + 31) / 32 * 32;
     const size_t lds_pc = 2 * HPP * ROWB + 2 * 3 * (size_t)BN * ROWB + 3 * (TH + 4) * (TW + 4) * sizeof(float) + HPP;
     hipLaunchKernelGGL(conv_mfma_f16x3_pc_kernel, dim3((unsigned)tiles), dim3(512), lds_pc, s, p);
-  }
-  else if (w4_path) {
-    const size_t lds4 = std::max((size_t)(th + 2) * ((TW + 2) * ROWB + F16X3_W4_ROWPAD) + 2 * 3 * (size_t)BN * ROWB + BN * sizeof(float),
-                                 F16X3_W4_REGEPI ? (size_t)0 : (size_t)16 * th * (BN + CS_PAD) * sizeof(float));
-    const dim3 grid((unsigned)(tiles * p.nct));
-    p.ntile_blocks = (int)(tiles * p.nct);
-    const bool dual = vec_ok && conv_f16x3_w4_dual() && a.wsplit16h;
-    if (dual) {
-      // dual-tile family (conv_mfma_f16x3_w4d_kernel<.., MT, NTILE, ..>): every variant forms an output with the same
-      // operations in the same order, so the choice below -- two tiles per block where that fills whole rounds of one
-      // block per CU, single tiles for the rest -- never changes a result.
-      p.wph = a.wsplit16h;
-      p.wscale_inv = a.wscale_inv;
-      static int cus = 0;
-      if (!cus) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 4)
-          cus = 256;
-      }
-      const long long per_round = cus / p.nct;                    // pixel tiles (single) or pairs (dual) per round
-      const long long pairs = (tiles + 1) / 2;
-      const double c1 = mt == 4 ? 1.0 : 0.56, c2 = mt == 4 ? 1.82 : 1.02;   // block cost: one / two tiles (w4_pick_mt's unit)
-      const long long full2 = pairs / per_round;                  // whole rounds of dual blocks
-      const long long rest = std::max(0LL, tiles - 2 * full2 * per_round);
-      const double cost_all1 = c1 * (double)((tiles + per_round - 1) / per_round);
-      const double cost_all2 = c2 * (double)((pairs + per_round - 1) / per_round);
-      const double cost_hyb = c2 * (double)full2 + c1 * (double)((rest + per_round - 1) / per_round);
-      long long n2 = 0;                                           // pixel tiles covered by the dual launch
-      if (cost_all2 <= cost_all1 && cost_all2 <= cost_hyb) n2 = tiles;
-      else if (cost_hyb < cost_all1) n2 = 2 * full2 * per_round;
-      static const int force = getenv("SHF_F16X3_W4D_NTILE") ? atoi(getenv("SHF_F16X3_W4D_NTILE")) : 0;
-      if (force == 1) n2 = 0;
-      if (force == 2) n2 = tiles;
-      const size_t as_b = (size_t)(th + 2) * (18 * 80 + 224);
-      const size_t lds1 = as_b + 2 * 3 * (size_t)BN * 64 + BN * sizeof(float), lds2 = lds1 + as_b;
+  } else if (dual) {
+    // dual-tile family (conv_mfma_f16x3_w4d_kernel<.., MT, NTILE, ..>): every variant forms an output with the same
+    // operations in the same order, so the choice below -- two tiles per block where that fills whole rounds of one
+    // block per CU, single tiles for the rest -- never changes a result.
+    p.wph = a.wsplit16h;
+    p.wscale_inv = a.wscale_inv;
+    const long long per_round = knobs().cus / p.nct > 0 ? knobs().cus / p.nct : 1;   // pixel tiles (single) or pairs (dual) per round
+    const long long pairs = (tiles + 1) / 2;
+    const double c1 = mt == 4 ? 1.0 : 0.56, c2 = mt == 4 ? 1.82 : 1.02;   // block cost: one / two tiles (w4_pick_mt's unit)
+    const long long full2 = pairs / per_round;                  // whole rounds of dual blocks
+    const long long rest = std::max(0LL, tiles - 2 * full2 * per_round);
+    const double cost_all1 = c1 * (double)((tiles + per_round - 1) / per_round);
+    const double cost_all2 = c2 * (double)((pairs + per_round - 1) / per_round);
+    const double cost_hyb = c2 * (double)full2 + c1 * (double)((rest + per_round - 1) / per_round);
+    long long n2 = 0;                                           // pixel tiles covered by the dual launch
+    if (cost_all2 <= cost_all1 && cost_all2 <= cost_hyb) n2 = tiles;
+    else if (cost_hyb < cost_all1) n2 = 2 * full2 * per_round;
+    if (knobs().w4d_ntile == 1) n2 = 0;
+    if (knobs().w4d_ntile == 2) n2 = tiles;
+    const size_t as_b = (size_t)(th + 2) * (18 * 80 + 224);
+    const size_t lds1 = as_b + 2 * 3 * (size_t)BN * 64 + BN * sizeof(float), lds2 = lds1 + as_b;
 #define SHF_W4D_LAUNCH(SPLIT, MTV, NTV, GRID, LDS)                                                                        \
-      {                                                                                                                    \
-        if (a.nprod >= 3) hipLaunchKernelGGL((conv_mfma_f16x3_w4d_kernel<SPLIT, MTV, NTV, 3>), GRID, dim3(256), LDS, s, p);    \
-        else if (a.nprod == 2) hipLaunchKernelGGL((conv_mfma_f16x3_w4d_kernel<SPLIT, MTV, NTV, 2>), GRID, dim3(256), LDS, s, p); \
-        else hipLaunchKernelGGL((conv_mfma_f16x3_w4d_kernel<SPLIT, MTV, NTV, 1>), GRID, dim3(256), LDS, s, p);                 \
-      }
+    {                                                                                                                    \
+      if (a.nprod >= 3) hipLaunchKernelGGL((conv_mfma_f16x3_w4d_kernel<SPLIT, MTV, NTV, 3>), GRID, dim3(256), LDS, s, p);    \
+      else if (a.nprod == 2) hipLaunchKernelGGL((conv_mfma_f16x3_w4d_kernel<SPLIT, MTV, NTV, 2>), GRID, dim3(256), LDS, s, p); \
+      else hipLaunchKernelGGL((conv_mfma_f16x3_w4d_kernel<SPLIT, MTV, NTV, 1>), GRID, dim3(256), LDS, s, p);                 \
+    }
 #define SHF_W4D_PICK(NTV, GRID, LDS)                                       \
-      {                                                                     \
-        if (mt == 4 && a.in_split) SHF_W4D_LAUNCH(true, 4, NTV, GRID, LDS)  \
-        else if (mt == 4) SHF_W4D_LAUNCH(false, 4, NTV, GRID, LDS)          \
-        else if (a.in_split) SHF_W4D_LAUNCH(true, 2, NTV, GRID, LDS)        \
-        else SHF_W4D_LAUNCH(false, 2, NTV, GRID, LDS)                       \
-      }
-      const int vbase = (a.in_split ? 4 : 0) + (mt == 2 ? 2 : 0);
-      if (n2 > 0) {
-        p.tile_base = 0;
-        p.ntile_blocks = (int)(n2 * p.nct);
-        const dim3 g2((unsigned)(((n2 + 1) / 2) * p.nct));
-        if (a.sub_hook) a.sub_hook(a.sub_ctx, 0, vbase, (double)n2 / (double)tiles);
-        SHF_W4D_PICK(2, g2, lds2)
-        if (a.sub_hook) a.sub_hook(a.sub_ctx, 1, vbase, (double)n2 / (double)tiles);
-      }
-      if (n2 < tiles) {
-        p.tile_base = (int)n2;
-        p.ntile_blocks = (int)(tiles * p.nct);
-        const dim3 g1((unsigned)((tiles - n2) * p.nct));
-        if (a.sub_hook) a.sub_hook(a.sub_ctx, 0, vbase + 1, (double)(tiles - n2) / (double)tiles);
-        SHF_W4D_PICK(1, g1, lds1)
-        if (a.sub_hook) a.sub_hook(a.sub_ctx, 1, vbase + 1, (double)(tiles - n2) / (double)tiles);
-      }
+    {                                                                     \
+      if (mt == 4 && a.in_split) SHF_W4D_LAUNCH(true, 4, NTV, GRID, LDS)  \
+      else if (mt == 4) SHF_W4D_LAUNCH(false, 4, NTV, GRID, LDS)          \
+      else if (a.in_split) SHF_W4D_LAUNCH(true, 2, NTV, GRID, LDS)        \
+      else SHF_W4D_LAUNCH(false, 2, NTV, GRID, LDS)                       \
+    }
+    const int vbase = (a.in_split ? 4 : 0) + (mt == 2 ? 2 : 0);
+    if (n2 > 0) {
+      p.tile_base = 0;
+      p.ntile_blocks = (int)(n2 * p.nct);
+      const dim3 g2((unsigned)(((n2 + 1) / 2) * p.nct));
+      if (a.sub_hook) a.sub_hook(a.sub_ctx, 0, vbase, (double)n2 / (double)tiles);
+      SHF_W4D_PICK(2, g2, lds2)
+      if (a.sub_hook) a.sub_hook(a.sub_ctx, 1, vbase, (double)n2 / (double)tiles);
+    }
+    if (n2 < tiles) {
+      p.tile_base = (int)n2;
+      p.ntile_blocks = (int)(tiles * p.nct);
+      const dim3 g1((unsigned)((tiles - n2) * p.nct));
+      if (a.sub_hook) a.sub_hook(a.sub_ctx, 0, vbase + 1, (double)(tiles - n2) / (double)tiles);
+      SHF_W4D_PICK(1, g1, lds1)
+      if (a.sub_hook) a.sub_hook(a.sub_ctx, 1, vbase + 1, (double)(tiles - n2) / (double)tiles);
+    }
 #undef SHF_W4D_PICK
 #undef SHF_W4D_LAUNCH
-      SHF_HIP_OK(hipGetLastError());
-      return 0;
-    }
-    if (mt == 4 && vec_ok && conv_f16x3_w4_persistent()) {
-      // persistent form: one block per CU walks the tiles; the grid stays a multiple of the cout-tile count
-      static int cus = 0;
-      if (!cus) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 4)
-          cus = 256;
-      }
-      const int gmax = cus / p.nct * p.nct;
-      const dim3 gp((unsigned)std::min<long long>(tiles * p.nct, gmax));
-      const size_t ldsp = (size_t)(th + 2) * ((TW + 2) * ROWB + F16X3_W4_ROWPAD) + 2 * 3 * (size_t)BN * ROWB + BN * sizeof(float);
-#define SHF_W4P_LAUNCH(SPLIT)                                                                                           \
-      {                                                                                                                 \
-        if (a.nprod >= 3) hipLaunchKernelGGL((conv_mfma_f16x3_w4p_kernel<SPLIT, 4, 3>), gp, dim3(256), ldsp, s, p);      \
-        else if (a.nprod == 2) hipLaunchKernelGGL((conv_mfma_f16x3_w4p_kernel<SPLIT, 4, 2>), gp, dim3(256), ldsp, s, p); \
-        else hipLaunchKernelGGL((conv_mfma_f16x3_w4p_kernel<SPLIT, 4, 1>), gp, dim3(256), ldsp, s, p);                   \
-      }
-      if (a.in_split) SHF_W4P_LAUNCH(true)
-      else SHF_W4P_LAUNCH(false)
-#undef SHF_W4P_LAUNCH
-      SHF_HIP_OK(hipGetLastError());
-      return 0;
-    }
-#define SHF_W4_LAUNCH(SPLIT, MTV)                                                                                      \
-    {                                                                                                                   \
-      if (a.nprod >= 3) hipLaunchKernelGGL((conv_mfma_f16x3_w4_kernel<SPLIT, MTV, 3>), grid, dim3(256), lds4, s, p);     \
-      else if (a.nprod == 2) hipLaunchKernelGGL((conv_mfma_f16x3_w4_kernel<SPLIT, MTV, 2>), grid, dim3(256), lds4, s, p); \
-      else hipLaunchKernelGGL((conv_mfma_f16x3_w4_kernel<SPLIT, MTV, 1>), grid, dim3(256), lds4, s, p);                   \
-    }
-    if (mt == 4 && a.in_split) SHF_W4_LAUNCH(true, 4)
-    else if (mt == 4) SHF_W4_LAUNCH(false, 4)
-    else if (a.in_split) SHF_W4_LAUNCH(true, 2)
-    else SHF_W4_LAUNCH(false, 2)
-#undef SHF_W4_LAUNCH
   } else if (a.in_split) {
-    set_error("conv f16x3: split-format input reached a kernel other than the 4-wave one (unaligned views, or an input of 4 GiB or more)");
+    set_error("conv f16x3: split-format input reached a kernel other than the 4-wave family (unaligned views, or an input of 4 GiB or more)");
     return -1;
-  }
-  else
+  } else {
     hipLaunchKernelGGL((conv_mfma_f16x3_kernel<BN, FUSE1, DIL, KS>), dim3((unsigned)(tiles * p.nct)), dim3(512), lds, s, p);
+  }
   SHF_HIP_OK(hipGetLastError());
 #ifdef SHF_CONV_TIMING
   {
@@ -2326,62 +1389,34 @@ static int launch_f16x3_t(const ConvArgs* as, int n, hipStream_t s) {
     hipStreamSynchronize(s);
     hipMemcpy(h, dbg_dev, sizeof(h), hipMemcpyDeviceToHost);
     for (int w = 0; w < 16; w += 3)
-      if (h[w * 5 + 4]) {
-        const unsigned long long nst = h[w * 5 + 4] & 0xffff, tot = (h[w * 5 + 4] >> 16) & 0xffffff, rt = h[w * 5 + 4] >> 40;
-        if (tot)
-          fprintf(stderr, "[f16x3 timing] blk%d wave%d stages %llu: per-stage cycles barrier %.0f compute %.0f tail %.0f | "
-                  "prologue %llu epilogue %llu total %llu cycles, %.2f GHz\n", w / 8 ? 100 : 0, w % 8, nst,
-                  (double)h[w * 5] / nst, (double)h[w * 5 + 2] / nst, (double)h[w * 5 + 3] / nst, h[w * 5 + 1] >> 32,
-                  h[w * 5 + 1] & 0xffffffffull, tot, rt ? tot / (rt * 10.0) : 0.0);
-        else
-          fprintf(stderr, "[f16x3 timing] blk%d wave%d stages %llu: per-stage cycles barrier %.0f issue %.0f compute %.0f tail %.0f\n",
-                  w / 8 ? 100 : 0, w % 8, nst, (double)h[w * 5] / nst, (double)h[w * 5 + 1] / nst,
-                  (double)h[w * 5 + 2] / nst, (double)h[w * 5 + 3] / nst);
-      }
+      if (h[w * 5 + 4])
+        fprintf(stderr, "[f16x3 timing] blk%d wave%d stages %llu: per-stage cycles barrier %.0f issue %.0f compute %.0f tail %.0f\n",
+                w / 8 ? 100 : 0, w % 8, h[w * 5 + 4], (double)h[w * 5] / h[w * 5 + 4], (double)h[w * 5 + 1] / h[w * 5 + 4],
+                (double)h[w * 5 + 2] / h[w * 5 + 4], (double)h[w * 5 + 3] / h[w * 5 + 4]);
   }
 #endif
   return 0;
 }
 
 int conv_f16x3_init_attributes() {
-  SHF_HIP_OK(hipFuncSetAttribute((const void*)conv_mfma_f16x3_kernel<128, false, 1, 3>,
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  SHF_HIP_OK(hipFuncSetAttribute((const void*)conv_mfma_f16x3_kernel<128, false, 1, 1>,
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  SHF_HIP_OK(hipFuncSetAttribute((const void*)conv_mfma_f16x3_kernel<64, false, 1, 1>,
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  SHF_HIP_OK(hipFuncSetAttribute((const void*)conv_mfma_f16x3_kernel<64, false, 2, 3>,
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  SHF_HIP_OK(hipFuncSetAttribute((const void*)conv_mfma_f16x3_kernel<64, false, 4, 3>,
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-#define SHF_W4_ATTR(SPLIT, MTV, NPV)                                                                  \
-  SHF_HIP_OK(hipFuncSetAttribute((const void*)conv_mfma_f16x3_w4_kernel<SPLIT, MTV, NPV>,              \
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  SHF_W4_ATTR(false, 4, 3) SHF_W4_ATTR(true, 4, 3) SHF_W4_ATTR(false, 2, 3) SHF_W4_ATTR(true, 2, 3)
-  SHF_W4_ATTR(false, 4, 2) SHF_W4_ATTR(true, 4, 2) SHF_W4_ATTR(false, 2, 2) SHF_W4_ATTR(true, 2, 2)
-  SHF_W4_ATTR(false, 4, 1) SHF_W4_ATTR(true, 4, 1) SHF_W4_ATTR(false, 2, 1) SHF_W4_ATTR(true, 2, 1)
-#undef SHF_W4_ATTR
-#define SHF_W4D_ATTR(SPLIT, MTV, NTV)                                                                     \
-  SHF_HIP_OK(hipFuncSetAttribute((const void*)conv_mfma_f16x3_w4d_kernel<SPLIT, MTV, NTV, 3>,                \
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                   \
-  SHF_HIP_OK(hipFuncSetAttribute((const void*)conv_mfma_f16x3_w4d_kernel<SPLIT, MTV, NTV, 2>,                \
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                   \
-  SHF_HIP_OK(hipFuncSetAttribute((const void*)conv_mfma_f16x3_w4d_kernel<SPLIT, MTV, NTV, 1>,                \
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  (void)knobs();
+#define SHF_LDS_ATTR(K) SHF_HIP_OK(hipFuncSetAttribute((const void*)(K), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  SHF_LDS_ATTR((conv_mfma_f16x3_kernel<128, false, 1, 3>))
+  SHF_LDS_ATTR((conv_mfma_f16x3_kernel<128, false, 1, 1>))
+  SHF_LDS_ATTR((conv_mfma_f16x3_kernel<64, false, 1, 1>))
+  SHF_LDS_ATTR((conv_mfma_f16x3_kernel<64, false, 2, 3>))
+  SHF_LDS_ATTR((conv_mfma_f16x3_kernel<64, false, 4, 3>))
+  SHF_LDS_ATTR((conv_mfma_f16x3_kernel<64, false, 1, 3>))
+  SHF_LDS_ATTR((conv_mfma_f16x3_kernel<64, true, 1, 3>))
+  SHF_LDS_ATTR(conv_mfma_f16x3_pc_kernel)
+#define SHF_W4D_ATTR(SPLIT, MTV, NTV)                                      \
+  SHF_LDS_ATTR((conv_mfma_f16x3_w4d_kernel<SPLIT, MTV, NTV, 3>))           \
+  SHF_LDS_ATTR((conv_mfma_f16x3_w4d_kernel<SPLIT, MTV, NTV, 2>))           \
+  SHF_LDS_ATTR((conv_mfma_f16x3_w4d_kernel<SPLIT, MTV, NTV, 1>))
   SHF_W4D_ATTR(false, 4, 2) SHF_W4D_ATTR(true, 4, 2) SHF_W4D_ATTR(false, 4, 1) SHF_W4D_ATTR(true, 4, 1)
   SHF_W4D_ATTR(false, 2, 2) SHF_W4D_ATTR(true, 2, 2) SHF_W4D_ATTR(false, 2, 1) SHF_W4D_ATTR(true, 2, 1)
 #undef SHF_W4D_ATTR
-#define SHF_W4P_ATTR(SPLIT, NPV)                                                                       \
-  SHF_HIP_OK(hipFuncSetAttribute((const void*)conv_mfma_f16x3_w4p_kernel<SPLIT, 4, NPV>,                \
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  SHF_W4P_ATTR(false, 3) SHF_W4P_ATTR(true, 3) SHF_W4P_ATTR(false, 2) SHF_W4P_ATTR(true, 2) SHF_W4P_ATTR(false, 1) SHF_W4P_ATTR(true, 1)
-#undef SHF_W4P_ATTR
-  SHF_HIP_OK(hipFuncSetAttribute((const void*)conv_mfma_f16x3_pc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 160 * 1024));
-  SHF_HIP_OK(hipFuncSetAttribute((const void*)conv_mfma_f16x3_kernel<64, false, 1, 3>,
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  SHF_HIP_OK(hipFuncSetAttribute((const void*)conv_mfma_f16x3_kernel<64, true, 1, 3>,
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#undef SHF_LDS_ATTR
   return 0;
 }
 

@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <type_traits>
 
+#include "conv_common.h"
 #include "shf_internal.h"
 
 namespace shf {
@@ -63,12 +64,12 @@ int launch_maxpool(const View& in, const View& out, int k, int stride, int pad, 
 __global__ void deconv_dw_kernel(const float* __restrict__ in, const float* __restrict__ w,
                                  const float* __restrict__ bias, float* __restrict__ out, int B, int H, int W, int C,
                                  int Ho, int Wo, int k, int stride, int pad, int in_stride, int out_stride,
-                                 int* range_flag) {
+                                 int* range_flag, unsigned* out_amax) {
   const unsigned C4 = (unsigned)C >> 2;
   const unsigned n = blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= (unsigned)Wo * C4) return;
-  const int c4 = (int)(n % C4), ox = (int)(n / C4), oy = blockIdx.y, b = blockIdx.z;
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  if (n < (unsigned)Wo * C4) {   // (no early return: every lane takes part in the wave reduction below)
+  const int c4 = (int)(n % C4), ox = (int)(n / C4), oy = blockIdx.y, b = blockIdx.z;
   // only the taps a = (oy+pad) mod stride, +stride, ... hit an integral source row (same for columns): walk
   // exactly those, in the same ascending (a, bb) order as the full k x k scan
   for (int a = (oy + pad) % stride; a < k; a += stride) {
@@ -90,9 +91,12 @@ __global__ void deconv_dw_kernel(const float* __restrict__ in, const float* __re
   if (bias)
     for (int j = 0; j < 4; ++j) acc[j] += bias[c4 * 4 + j];
   *(float4*)(out + ((size_t)(b * Ho + oy) * Wo + ox) * out_stride + c4 * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-  // split-fp16 mode: the consumer of this map splits it to fp16 hi/lo -- raise the range flag beyond 65504
-  if (range_flag && !(fmaxf(fmaxf(fabsf(acc[0]), fabsf(acc[1])), fmaxf(fabsf(acc[2]), fabsf(acc[3]))) <= 65504.0f))
-    atomicOr(range_flag, 1);
+  }
+  // split-fp16 mode: the consumer of this map splits it to fp16 hi/lo -- raise the range flag beyond 65504, and the
+  // unit's max |value| for the consumer's activation exponent (conv_common.h)
+  const float amax = fmaxf(fmaxf(fabsf(acc[0]), fabsf(acc[1])), fmaxf(fabsf(acc[2]), fabsf(acc[3])));
+  if (range_flag && !(amax <= 65504.0f)) atomicOr(range_flag, 1);
+  conv_publish_amax(out_amax, nullptr, amax);
 }
 
 // the same for a GROUP of maps sharing the layer (the units of an image's pyramid): one launch, the members stacked
@@ -101,6 +105,7 @@ struct DeconvGM {
   const float* in;
   float* out;
   int H, W, Ho, Wo, in_stride, out_stride, row_start;
+  unsigned* out_amax;   // activation-exponent slot of the member's output blob (conv_common.h) or null
 };
 struct DeconvGK {
   int n, C, k, stride, pad;
@@ -120,7 +125,8 @@ __global__ void deconv_dw_group_kernel(DeconvGK g) {
   const DeconvGM& p = g.m[mi];
   const unsigned C4 = (unsigned)g.C >> 2;
   const unsigned n = blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= (unsigned)p.Wo * C4) return;
+  float amax = 0.f;
+  if (n < (unsigned)p.Wo * C4) {   // (no early return: every lane takes part in the wave reduction at the end)
   const int c4 = (int)(n % C4), ox = (int)(n / C4);
   // the thread's 4 channels x 16 taps, fetched ONCE for all its rows (re-fetching them per output pixel was 1.8 GB of
   // cache traffic per image: the whole cost of this kernel)
@@ -189,13 +195,16 @@ __global__ void deconv_dw_group_kernel(DeconvGK g) {
   if (g.bias)
     for (int j = 0; j < 4; ++j) acc[j] += g.bias[c4 * 4 + j];
   *(float4*)(p.out + ((size_t)oy * p.Wo + ox) * p.out_stride + c4 * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-  if (g.range_flag && !(fmaxf(fmaxf(fabsf(acc[0]), fabsf(acc[1])), fmaxf(fabsf(acc[2]), fabsf(acc[3]))) <= 65504.0f))
-    atomicOr(g.range_flag, 1);
+  amax = fmaxf(amax, fmaxf(fmaxf(fabsf(acc[0]), fabsf(acc[1])), fmaxf(fabsf(acc[2]), fabsf(acc[3]))));
+  if (acc[0] != acc[0] || acc[1] != acc[1] || acc[2] != acc[2] || acc[3] != acc[3]) amax = __builtin_inff();  // (fmaxf drops NaNs)
   }
+  }
+  if (g.range_flag && !(amax <= 65504.0f)) atomicOr(g.range_flag, 1);
+  conv_publish_amax(p.out_amax, nullptr, amax);
 }
 
 int launch_deconv_depthwise_group(const View* ins, const View* outs, int n, const float* w, const float* bias, int k,
-                                  int stride, int pad, hipStream_t s, int* range_flag) {
+                                  int stride, int pad, hipStream_t s, int* range_flag, unsigned* const* out_amax) {
   if (n < 1 || n > 16) { set_error("deconv group: 1..16 members"); return -1; }
   DeconvGK g;
   g.n = n; g.C = ins[0].C; g.k = k; g.stride = stride; g.pad = pad;
@@ -214,6 +223,7 @@ int launch_deconv_depthwise_group(const View* ins, const View* outs, int n, cons
     m.in = in.p + in.coff; m.out = out.p + out.coff;
     m.H = in.H; m.W = in.W; m.Ho = out.H; m.Wo = out.W;
     m.in_stride = in.cstride; m.out_stride = out.cstride;
+    m.out_amax = out_amax ? out_amax[i] : nullptr;
     m.row_start = rows;
     rows += (out.H + g.rows_per_block - 1) / g.rows_per_block;
     per_row_max = std::max(per_row_max, ((unsigned)out.W * (unsigned)(in.C / 4) + 255) / 256);
@@ -227,7 +237,7 @@ int launch_deconv_depthwise_group(const View* ins, const View* outs, int n, cons
 }
 
 int launch_deconv_depthwise(const View& in, const View& out, const float* w, const float* bias, int k, int stride,
-                            int pad, hipStream_t s, int* range_flag) {
+                            int pad, hipStream_t s, int* range_flag, unsigned* out_amax) {
   if (in.C % 4 || in.cstride % 4 || in.coff % 4 || out.cstride % 4 || out.coff % 4) {
     set_error("deconv: channel count / views must be multiples of 4");
     return -1;
@@ -235,7 +245,7 @@ int launch_deconv_depthwise(const View& in, const View& out, const float* w, con
   const unsigned per_row = (unsigned)out.W * (unsigned)(in.C / 4);
   hipLaunchKernelGGL(deconv_dw_kernel, dim3((per_row + 255) / 256, out.H, out.B), dim3(256), 0, s, in.p + in.coff, w,
                      bias, out.p + out.coff, in.B, in.H, in.W, in.C, out.H, out.W, k, stride, pad, in.cstride,
-                     out.cstride, range_flag);
+                     out.cstride, range_flag, out_amax);
   SHF_HIP_OK(hipGetLastError());
   return 0;
 }

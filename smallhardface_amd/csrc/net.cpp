@@ -90,6 +90,7 @@ struct ParamBlob {
   DevBuf raw, packed, packed16, packed16h, first_t, first_frag;
   float wscale_inv = 1.f;  // packed16h: the power of two its weights were scaled by, inverted
   bool dirty = true;
+  bool split_stale = false;  // committed while the net was in fp32 mode: packed16 / packed16h hold OLDER weights
   size_t count() const {
     size_t c = 1;
     for (int d : shape) c *= (size_t)d;
@@ -470,6 +471,18 @@ struct shf_net {
   bool pipelined = false;   // shf_net_set_pipeline: convolutions go to sh->conv_stream, the rest stays on `stream`
   hipStream_t cstream() { return pipelined && sh->conv_stream ? sh->conv_stream : stream; }
   int* flag_ptr = nullptr;  // the flag this net's kernels raise: its own, or the head's during a grouped pass
+  // activation-exponent slots (conv_common.h): one u32 per blob of THIS lane = bit pattern of max |value| of the unit
+  // it currently holds; zeroed at the start of every forward / unit, raised by the producers' epilogues, read by the
+  // single-accumulator split-fp16 kernels.  Concat members share their owner's slot.
+  DevBuf amax_slots;
+  unsigned* amax_slot(int bi) {
+    if (!amax_slots.p || conv_mode < 1) return nullptr;
+    const int o = blobs[bi].owner >= 0 ? blobs[bi].owner : bi;
+    return (unsigned*)amax_slots.p + o;
+  }
+  void reset_amax(hipStream_t st) {
+    if (conv_mode >= 1 && amax_slots.p) HIP_THROW(hipMemsetAsync(amax_slots.p, 0, blobs.size() * 4, st));
+  }
   DevBuf range_flag;  // device int: raised by a split-fp16 conv epilogue that produced |x| > 65504 (fp16 hi overflows)
   TailWork tw;
   DevBuf tw_logits, tw_rec, tw_keys, tw_counters;
@@ -899,6 +912,8 @@ void shf_net::build(const std::string& text, const char* caffemodel) {
     }
   }
   alloc_buffers();
+  amax_slots.ensure(std::max<size_t>(blobs.size(), 1) * 4);
+  HIP_THROW(hipMemset(amax_slots.p, 0, std::max<size_t>(blobs.size(), 1) * 4));
   if (clone_src) {
     wgen = clone_src->wgen;
     return;
@@ -1062,6 +1077,8 @@ void shf_net::commit_params(int li) {
       pack_conv_weights(p.host.data(), p.shape[0], p.shape[1], p.shape[2], packed.data());
       p.packed.ensure(packed.size() * 4);
       HIP_THROW(hipMemcpy(p.packed.p, packed.data(), packed.size() * 4, hipMemcpyHostToDevice));
+      // a commit in fp32 mode leaves the split-fp16 packs behind: shf_net_set_conv_mode re-packs them on the way back
+      p.split_stale = p.packed16.p != nullptr;
       if (conv_mode >= 1 && conv_f16x3_eligible(p.shape[1], p.shape[0], L.k, L.pad, L.dil)) {
         // split-fp16 keeps hi = fp16(w): a weight beyond the fp16 range would become inf (the reference is fp32
         // everywhere, caffe/python/caffe/_caffe.cpp:46-48) -- refuse the mode instead of computing garbage
@@ -1073,7 +1090,8 @@ void shf_net::commit_params(int li) {
         pack_conv_weights_split16(p.host.data(), p.shape[0], p.shape[1], p.shape[2], sp.data());
         p.packed16.ensure(sp.size() * 2);
         HIP_THROW(hipMemcpy(p.packed16.p, sp.data(), sp.size() * 2, hipMemcpyHostToDevice));
-        if (conv_f16x3_w4_dual() && L.k == 3 && L.dil == 1 && conv_f16x3_uses_w4(p.shape[1]) && p.shape[0] % 128 == 0 &&
+        p.split_stale = false;
+        if (L.k == 3 && L.dil == 1 && conv_f16x3_uses_w4(p.shape[1]) && p.shape[0] % 128 == 0 &&
             p.shape[1] % 32 == 0) {
           std::vector<uint16_t> sh(split16h_conv_weight_halfs(p.shape[0], p.shape[1], p.shape[2]));
           p.wscale_inv = pack_conv_weights_split16h(p.host.data(), p.shape[0], p.shape[1], p.shape[2], sh.data());
@@ -1166,6 +1184,9 @@ void shf_net::forward_ops(bool fused_path, float im_h, float im_w, float im_scal
         }
         // split-fp16 mode: every producer of a map that a split-fp16 conv may read guards the fp16 range
         a.range_flag = conv_mode >= 1 ? (flag_ptr ? flag_ptr : (int*)range_flag.p) : nullptr;
+        a.in_amax = amax_slot(L.bottoms[0]);
+        a.out_amax = amax_slot(L.tops[0]);
+        if (a.pool.p) a.pool_amax = amax_slot(layers[L.fuse_pool].tops[0]);
         if (split16) {  // how many of the three fp16 products this layer forms
           a.nprod = conv_mode == 1 ? 3 : conv_mode == 2 ? 2 : 1;
           auto it = sh->layer_products.find(L.name);
@@ -1221,6 +1242,8 @@ void shf_net::forward_ops(bool fused_path, float im_h, float im_w, float im_scal
         if (fused_path && L.fused_into >= 0) break;  // done by the producing conv's epilogue
         ProfScope ps(pf, st, PC_POOL, 0, 4.0 * (blobs[L.bottoms[0]].count() + blobs[L.tops[0]].count()));
         CHECK_RC(launch_maxpool(view_of(L.bottoms[0]), view_of(L.tops[0]), L.k, L.stride, L.pad, st));
+        if (amax_slot(L.tops[0]))  // max |pooled| <= max |input|: the bound serves as the pooled blob's activation exponent
+          HIP_THROW(hipMemcpyAsync(amax_slot(L.tops[0]), amax_slot(L.bottoms[0]), 4, hipMemcpyDeviceToDevice, st));
         break;
       }
       case OP_DECONV: {
@@ -1229,7 +1252,8 @@ void shf_net::forward_ops(bool fused_path, float im_h, float im_w, float im_scal
         CHECK_RC(launch_deconv_depthwise(view_of(L.bottoms[0]), view_of(L.tops[0]), (const float*)L.params[0]->raw.p,
                                          L.params.size() > 1 ? (const float*)L.params[1]->raw.p : nullptr, L.k,
                                          L.stride, L.pad, st,
-                                         conv_mode >= 1 ? (flag_ptr ? flag_ptr : (int*)range_flag.p) : nullptr));
+                                         conv_mode >= 1 ? (flag_ptr ? flag_ptr : (int*)range_flag.p) : nullptr,
+                                         amax_slot(L.tops[0])));
         break;
       }
       case OP_TAIL: {
@@ -1267,6 +1291,7 @@ void shf_net::forward() {
     memcpy(ii, blobs[im_info_blob].host.p, 12);
   for (int attempt = 0; attempt < 2; ++attempt) {
     if (conv_mode >= 1) HIP_THROW(hipMemsetAsync(range_flag.p, 0, 4, stream));
+    reset_amax(stream);
     forward_ops(false, ii[0], ii[1], ii[2]);
     int cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, flag = 0;
     if (tail_layer >= 0) HIP_THROW(hipMemcpyAsync(cnt, tw.counters, sizeof(cnt), hipMemcpyDeviceToHost, stream));
@@ -1497,11 +1522,13 @@ int shf_net_set_conv_mode(shf_net* net, int mode) {
   HIP_THROW(hipDeviceSynchronize());  // the mode is shared with every lane: nothing may be in flight while it flips
   net->conv_mode = mode;
   if (mode >= 1) {
-    // the fp32 packs always exist; the split-fp16 packs are made on first use (and re-made by every commit)
+    // the fp32 packs always exist; the split-fp16 packs are made on first use, re-made by every commit in a split
+    // mode, and re-made here when a commit in fp32 mode left them stale (also re-runs the |w| <= 65504 check)
     try {
       for (size_t li = 0; li < net->layers.size(); ++li) {
         Layer& L = net->layers[li];
-        if (L.type == "Convolution" && L.kclass == 0 && !L.params.empty() && !L.params[0]->packed16.p &&
+        if (L.type == "Convolution" && L.kclass == 0 && !L.params.empty() &&
+            (!L.params[0]->packed16.p || L.params[0]->split_stale) &&
             conv_f16x3_eligible(L.params[0]->shape[1], L.params[0]->shape[0], L.k, L.pad, L.dil))
           net->commit_params((int)li);
       }
@@ -1619,6 +1646,7 @@ void shf_net::prepare_unit(const float* data, int data_on_device, int H, int W, 
     d.dev.ensure(d.count() * 4);
     HIP_THROW(hipMemcpyAsync(d.dev.p, data, d.count() * 4, hipMemcpyHostToDevice, st));
   }
+  reset_amax(st);
 }
 
 void shf_net::ensure_img_cap(int units_after) {
@@ -1843,12 +1871,14 @@ int shf_detect_add_levels(shf_net* net, int n, shf_net** members, const float* c
     } else if (L.op == OP_DECONV && n > 1) {
       // the units' depthwise up-samplings as one launch (ten serial 5..60-us launches otherwise)
       View dins[kMaxGroup], douts[kMaxGroup];
+      unsigned* dslots[kMaxGroup];
       double fl = 0, by = 0;
       bool ok = true;
       for (int m = 0; m < n; ++m) {
         shf_net* mb = members[m];
         dins[m] = mb->view_of(L.bottoms[0]);
         douts[m] = mb->view_of(L.tops[0]);
+        dslots[m] = mb->amax_slot(L.tops[0]);
         ok = ok && dins[m].B == 1;
         fl += 2.0 * mb->blobs[L.tops[0]].count() * 4;
         by += 4.0 * (mb->blobs[L.bottoms[0]].count() + mb->blobs[L.tops[0]].count());
@@ -1858,7 +1888,7 @@ int shf_detect_add_levels(shf_net* net, int n, shf_net** members, const float* c
         CHECK_RC(launch_deconv_depthwise_group(dins, douts, n, (const float*)L.params[0]->raw.p,
                                                L.params.size() > 1 ? (const float*)L.params[1]->raw.p : nullptr, L.k,
                                                L.stride, L.pad, cs,
-                                               net->conv_mode >= 1 ? (int*)net->range_flag.p : nullptr));
+                                               net->conv_mode >= 1 ? (int*)net->range_flag.p : nullptr, dslots));
       } else {
         for (int m = 0; m < n; ++m)
           members[m]->forward_ops(true, (float)im_h[m], (float)im_w[m], im_scale[m], cs, &net->prof, (int)li, nullptr);

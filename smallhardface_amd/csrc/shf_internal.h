@@ -49,6 +49,11 @@ struct ConvArgs {
   int nprod = 3;  // split-fp16 kernels: fp16 products formed per fp32 product -- 3 (hi*hi + hi*lo + lo*hi: fp32-class),
                   // 2 (drops a_lo*b_hi: activations effectively fp16) or 1 (hi*hi only: plain fp16 operands)
   int* range_flag = nullptr;  // split-fp16 kernels raise it when an output leaves the fp16 range (net.cpp: fp32 re-run)
+  // activation-exponent slots (conv_common.h ConvMember): max |value| of the input blob as left by its producers, and
+  // where this launch raises the max of what it writes (main output / fused pool output); null = not tracked
+  const unsigned* in_amax = nullptr;
+  unsigned* out_amax = nullptr;
+  unsigned* pool_amax = nullptr;
   // dual-tile family: a layer may take two launches (two tiles per block, then single tiles); the profiler wants one
   // record per KERNEL: hook(ctx, 0, variant, share) before and hook(ctx, 1, ..) after each, variant = in_split * 4 +
   // (rows == 8) * 2 + (tiles per block == 1), share = its fraction of the launch's pixel tiles
@@ -67,16 +72,14 @@ int conv_init_attributes();
 // split-fp16 (3 x fp16 MFMA, fp32-class accuracy) variant for 3x3 / dilation 1 layers
 bool conv_f16x3_eligible(int Cin, int Cout, int k, int pad, int dil);
 bool conv_f16x3_uses_pc();         // fused first pair: producer/consumer kernel (SHF_F16X3_PC=0 disables)
-bool conv_f16x3_uses_w4(int Cin);
-bool conv_f16x3_w4_persistent();  // 16-row launches of the 4-wave kernel in the persistent (block-walks-tiles) form
-int conv_f16x3_w4_mt(const ConvArgs* as, int n);  // 4-wave kernel: 16-row (4) or 8-row (2) tiles for this launch  // Cout % 128 == 0 layers: 4-wave (one per SIMD) kernel or the 8-wave one
+bool conv_f16x3_uses_w4(int Cin);  // Cout % 128 == 0, 3x3 / dilation 1 layers: the 4-wave dual-tile family (Cin >= 128) or the 8-wave kernel
+int conv_f16x3_w4_mt(const ConvArgs* as, int n);  // 4-wave family: 16-row (4) or 8-row (2) tiles for this launch
 int conv_f16x3_init_attributes();
 int launch_conv_f16x3_group(const ConvArgs* as, int n, hipStream_t s);
 size_t split16_conv_weight_halfs(int Cout, int Cin, int k);
 size_t split16h_conv_weight_halfs(int Cout, int Cin, int k);
 float pack_conv_weights_split16h(const float* w, int Cout, int Cin, int k, void* dst);  // returns 1 / scale
 bool conv_f16x3_group_is_dual(const ConvArgs* as, int n);
-bool conv_f16x3_w4_dual();  // two pixel tiles per block sharing every weight slab (SHF_F16X3_W4D)
 void pack_conv_weights_split16(const float* w, int Cout, int Cin, int k, void* dst);
 // first layer (64, 27) as the B operand of v_mfma_f32_32x32x16_f16: [n 2][kk 2][hi/lo 2][lane 64][8 halfs], K padded 27 -> 32
 constexpr size_t kFirstConvFragHalfs = 2 * 2 * 2 * 64 * 8;
@@ -89,9 +92,10 @@ size_t packed_conv_weight_floats(int Cout, int Cin, int k);
 int launch_maxpool(const View& in, const View& out, int k, int stride, int pad, hipStream_t s);
 // depthwise transposed conv (group == C), weights (C,1,k,k) Caffe layout
 int launch_deconv_depthwise(const View& in, const View& out, const float* w, const float* bias, int k,
-                            int stride, int pad, hipStream_t s, int* range_flag = nullptr);
+                            int stride, int pad, hipStream_t s, int* range_flag = nullptr, unsigned* out_amax = nullptr);
 int launch_deconv_depthwise_group(const View* ins, const View* outs, int n, const float* w, const float* bias, int k,
-                                  int stride, int pad, hipStream_t s, int* range_flag = nullptr);
+                                  int stride, int pad, hipStream_t s, int* range_flag = nullptr,
+                                  unsigned* const* out_amax = nullptr);
 int launch_copy_view(const View& in, const View& out, hipStream_t s);       // concat fallback
 int launch_nhwc_to_nchw(const View& in, float* out_nchw, hipStream_t s);    // blob.data read-back
 int launch_nchw_to_nhwc(const float* in_nchw, const View& out, hipStream_t s);

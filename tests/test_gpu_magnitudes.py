@@ -1,0 +1,121 @@
+"""Split-fp16 mode at SMALL magnitudes and after weight changes made in fp32 mode.
+
+The reference computes in fp32 at any magnitude (caffe/python/caffe/_caffe.cpp:46-48).  The dual-tile 4-wave family
+keeps ONE accumulator per output, which needs the low parts unscaled in LDS: lo = fp16(x - hi) of |x| < 0.25 is an fp16
+subnormal, and a layer whose activations live around 1e-3 would keep ~14 bits instead of 22 (numpy emulation of the
+scheme: 6.8e-5 relative error per layer at 2^-12, 1e-3 at 2^-16).  The kernels therefore lift every unit's input to the
+top of the fp16 range with an exact power of two taken from the producer's running max |output| (conv_common.h
+conv_act_exponent) -- these tests hold the same 2e-5 / 1e-4 bars as the O(1) cases at 2^-8, 2^-12 and 2^-16."""
+import numpy as np
+import pytest
+
+from smallhardface_amd import prototxt as P
+from smallhardface_amd.config import cfg
+from tests import helpers as H
+from tests.test_gpu_parity import conv_layer
+
+pytestmark = pytest.mark.gpu
+
+ACT_TOL = 2e-5
+SCORE_TOL = 1e-4
+
+
+@pytest.mark.parametrize("log2_scale", [-8, -12, -16])
+@pytest.mark.parametrize("cin,cout,k,dil,h,w", [
+    (128, 256, 3, 1, 35, 41),    # dual-tile family, fp32 input (Net.forward path), an odd tile count
+    (512, 512, 3, 1, 16, 24),    # 32 chunks of 16 channels
+    (256, 128, 3, 1, 9, 70),     # 8-row tiles preferred by the launcher's cost model on wide, flat maps
+    (64, 128, 3, 1, 32, 48),     # 8-wave two-accumulator kernel (scaled low parts: magnitude-proof by construction)
+    (128, 128, 3, 2, 22, 26),    # dilated head
+    (512, 256, 1, 1, 9, 13),     # 1x1
+])
+def test_conv_small_magnitudes(cin, cout, k, dil, h, w, log2_scale):
+    pad = dil if k == 3 else 0
+    txt = H.single_layer_net(conv_layer("c0", "data", cin, 3, 1) + conv_layer("c1", "c0", cout, k, pad, dil) +
+                             conv_layer("c2", "c1", 128, 3, 1), 3, h, w)
+    gnet, onet = H.make_pair(P.parse(txt), seed=5)
+    gnet.set_conv_mode("f16x3")
+    rng = np.random.default_rng(3)
+    sc = np.float32(2.0 ** log2_scale)
+    for name in ("c0", "c1", "c2"):   # biases of the layer's own magnitude
+        onet.params[name][1][...] = (rng.normal(0, 0.5, onet.params[name][1].shape) * sc).astype(np.float32)
+    H.load_params(gnet, onet.params)
+    data = (rng.normal(0, 1, (1, 3, h, w)) * sc).astype(np.float32)
+    go, oo = H.run_both(gnet, onet, data, np.array([[h, w, 1]], np.float32))
+    assert 0 < np.abs(onet.blobs["c0"].data).max() < 64 * sc      # the case really is small
+    for name in ("c0", "c1", "c2"):
+        assert H.rel_err(gnet.blobs[name].data, onet.blobs[name].data) < ACT_TOL, name
+    assert gnet.range_fallbacks == 0
+
+
+@pytest.mark.parametrize("log2_scale", [-8, -12])
+def test_detector_with_small_activations_fused_path(log2_scale):
+    """The whole detector with the input blob and every bias scaled by 2^k: every activation up to the head
+    feature maps sits 2^k lower (conv + ReLU + max-pool + bilinear upsampling are positively homogeneous), the logits
+    are restored by scaling the 1x1 predictors' weights back.  Fused path (split activation format, grouped launches,
+    dual-tile kernels) vs the oracle: every anchor score within 1e-4."""
+    from oracle import oracle as O
+    from smallhardface_amd import caffe, test as T
+    msg = H.detector_msg(True)
+    params = O.synth_params(msg, seed=1234, cls_bias=1.0)
+    sc = np.float32(2.0 ** log2_scale)
+    tail = [n for n in params if n.startswith("cls_score") or n.startswith("bbox_pred")]
+    seen = set()                                   # (layers sharing a `param { name }` hold ONE array)
+    for name, blobs in params.items():
+        if name in tail:
+            blobs[0][...] = blobs[0] / sc          # predictors read features that are 2^k smaller
+        elif len(blobs) > 1 and id(blobs[1]) not in seen:
+            seen.add(id(blobs[1]))
+            blobs[1][...] = blobs[1] * sc          # biases follow their layer's magnitude
+    onet = O.OracleNet(msg, params=params)
+    gnet = caffe.Net(None, prototxt_text=P.dumps(msg))
+    H.load_params(gnet, params)
+    gnet.set_conv_mode("f16x3")
+    data = H.synth_image_blob(96, 128, seed=21) * sc
+    info = np.array([[96, 128, 1.0]], np.float32)
+    go, oo = H.run_both(gnet, onet, data, info)
+    assert np.abs(onet.blobs["conv4_fuse_final"].data).max() < 4096 * sc
+    gp, op = gnet.blobs["cls_prob_reshape_output"].data, onet.blobs["cls_prob_reshape_output"].data
+    assert float(np.abs(gp - op).max()) < SCORE_TOL
+    assert H.rel_err(gnet.blobs["conv5_3"].data, onet.blobs["conv5_3"].data) < 5e-5
+    # the fused, device-resident form (what bench.py times) on the same unit
+    od = np.hstack([oo["boxes"][:, 1:5], oo["cls_prob"][:, 1:2]]).astype(np.float32)
+    od = od[od[:, 4] > 0.05]
+    want = np.asarray(O.bbox_vote(od, cfg.TEST.NMS_THRESH), dtype=np.float64)
+    got = T.detect_fused(gnet, [(data, 96, 128, 96, 128, 1.0, False)], thresh=0.05)[0]
+    assert abs(len(got) - len(want)) <= 2
+    n = min(len(got), len(want))
+    assert n > 0 and np.abs(got[:n, 4] - want[:n, 4]).max() < SCORE_TOL
+
+
+def test_weights_changed_in_fp32_mode_reach_the_split_packs():
+    """f16x3 -> fp32 -> new weights (commit in fp32 mode) -> f16x3: the split-fp16 packs must be rebuilt from the new
+    weights on the way back (and the |w| <= 65504 check re-run), not convolve with the old ones."""
+    h, w = 24, 40
+    txt = H.single_layer_net(conv_layer("c0", "data", 128, 3, 1) + conv_layer("c1", "c0", 256, 3, 1) +
+                             conv_layer("c2", "c1", 64, 1, 0), 3, h, w)
+    gnet, onet = H.make_pair(P.parse(txt), seed=7)
+    data = np.random.default_rng(1).normal(0, 1, (1, 3, h, w)).astype(np.float32)
+    info = np.array([[h, w, 1]], np.float32)
+    gnet.set_conv_mode("f16x3")
+    go, oo = H.run_both(gnet, onet, data, info)
+    assert H.rel_err(go["c2"], oo["c2"]) < ACT_TOL
+    gnet.set_conv_mode("fp32")
+    rng = np.random.default_rng(9)
+    for name in ("c1", "c2"):
+        onet.params[name][0][...] = (onet.params[name][0] * rng.uniform(0.5, 1.5, onet.params[name][0].shape)).astype(np.float32)
+    H.load_params(gnet, onet.params)          # committed while the net is in fp32 mode
+    go, oo = H.run_both(gnet, onet, data, info)
+    assert H.rel_err(go["c2"], oo["c2"]) < ACT_TOL
+    gnet.set_conv_mode("f16x3")
+    go, oo = H.run_both(gnet, onet, data, info)
+    assert H.rel_err(go["c2"], oo["c2"]) < ACT_TOL, "stale split-fp16 weight packs"
+    # ... and the range refusal is re-run on that path too
+    gnet.set_conv_mode("fp32")
+    big = onet.params["c1"][0].copy()
+    big[0, 0, 0, 0] = 1.0e5
+    gnet.params["c1"][0].data[...] = big
+    gnet.commit_params()
+    with pytest.raises(Exception, match="fp16 range"):
+        gnet.set_conv_mode("f16x3")
+    assert gnet.conv_mode == "fp32"
