@@ -29,48 +29,86 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+def _contribution(rank, image, scenario):
+    """Rows rank `rank` holds for window image `image` (seeded: the checker regenerates them)."""
+    rng = np.random.default_rng(100 * rank + image)
+    n = int(rng.integers(0, 7))
+    if scenario == "overflow":
+        n = int(rng.integers(0, 40))                      # more rows than the (shrunk) block capacity
+    if rank == 1 and image == 0:
+        n = 0                                             # an empty contribution
+    if scenario == "strict8" and (rank >= 5 or image == 2):
+        n = 0                                             # ranks beyond the 5 levels run nothing; image 2: no detections anywhere
+    return rng.normal(size=(n, 5)).astype(np.float32)
+
+
+def _worker(rank, world, port, q, n_images, scenario):
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        n_images = world
-        local = {}
-        for i in range(n_images):
-            rng = np.random.default_rng(100 * rank + i)
-            n = int(rng.integers(0, 7)) if not (rank == 1 and i == 0) else 0  # an empty contribution too
-            local[i] = torch.from_numpy(rng.normal(size=(n, 5)).astype(np.float32))
-        got = pyramid.gather_window(local, n_images, rank, world)
-        q.put((rank, {i: t.numpy() for i, t in got.items()}))
+        if scenario == "overflow":
+            pyramid._GATHER_CAP["rows"] = 4               # forces the agreed second exchange with a larger capacity
+        got = {}
+        for window in range(2):                           # twice: the grown capacity persists, results stay the same
+            local = {i: torch.from_numpy(_contribution(rank, i, scenario)) for i in range(n_images)}
+            got = pyramid.gather_window(local, n_images, rank, world)
+        q.put((rank, {i: t.numpy() for i, t in got.items()}, pyramid._GATHER_CAP["rows"]))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.timeout(120)
-def test_gather_window_gloo_world2():
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world,n_images,scenario", [(2, 2, "plain"), (3, 5, "plain"), (2, 2, "overflow"),
+                                                     (8, 8, "strict8")])
+def test_gather_window_gloo(world, n_images, scenario):
+    """One all_to_all per window, rows to the image's owner only: uneven ownership (5 images on 3 ranks), contributions
+    larger than the block capacity (agreed re-exchange), and the strict one-scale-per-GPU form on 8 ranks with 5
+    levels -- three ranks contribute nothing, one image has no detection on any rank."""
     import torch.multiprocessing as mp
-    world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, n_images, scenario)) for r in range(world)]
     for p in procs:
         p.start()
-    res = dict(q.get(timeout=90) for _ in procs)
+    res, caps = {}, set()
+    for _ in procs:
+        r, got, cap = q.get(timeout=240)
+        res[r] = got
+        caps.add(cap)
     for p in procs:
         p.join(timeout=30)
         assert p.exitcode == 0
-    for i in range(world):
+    assert len(caps) == 1                                  # every rank ended with the same capacity
+    if scenario == "overflow":
+        assert caps.pop() >= 32
+    for i in range(n_images):
         owner = pyramid.image_owner(i, world)
-        assert i in res[owner] and i not in res[1 - owner]
-        exp = []
         for r in range(world):
-            rng = np.random.default_rng(100 * r + i)
-            n = int(rng.integers(0, 7)) if not (r == 1 and i == 0) else 0
-            exp.append(rng.normal(size=(n, 5)).astype(np.float32))
-        np.testing.assert_array_equal(res[owner][i], np.concatenate(exp, 0))
+            assert (i in res[r]) == (r == owner)
+        exp = np.concatenate([_contribution(r, i, scenario) for r in range(world)], 0)
+        assert res[owner][i].shape == exp.shape and res[owner][i].dtype == np.float32
+        np.testing.assert_array_equal(res[owner][i], exp)
+
+
+def test_strict_sharding_with_more_ranks_than_levels():
+    """8 ranks, 5 pyramid levels x 2 flips: levels land on ranks 0..4 (both flips together, every image of the window),
+    ranks 5..7 hold nothing and only take part in the gather; every unit is run exactly once."""
+    world, n_units = 8, 10
+    seen = []
+    for r in range(world):
+        mine = pyramid.my_units(r, world, world, n_units, shard="strict")
+        if r >= 5:
+            assert mine == []
+        else:
+            assert sorted(set(u for _, u in mine)) == [2 * r, 2 * r + 1] and len(mine) == 2 * world
+        seen += mine
+    assert sorted(seen) == [(i, u) for i in range(world) for u in range(n_units)]
+    with pytest.raises(ValueError):
+        pyramid.my_units(0, 2, 2, 10, shard="columns")
 
 
 def test_gather_window_single():

@@ -52,6 +52,52 @@ def test_cli_writes_wider_detections(tmp_path):
             assert fa[:4] == fb[:4] and abs(float(fa[4]) - float(fb[4])) <= 1e-4
 
 
+def _run_cli(tmp_path, data, model, gpu_id, exp_name, scales="[100, 300]"):
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    exp = tmp_path / exp_name
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "train_test.py"), "--train", "false", "--conf",
+                        os.path.join(ROOT, "configs", "smallhardface.toml"), "--amend", "TEST.MODEL", model,
+                        "DATA_DIR", str(data), "TEST.GPU_ID", gpu_id, "TEST.SCALES", scales, "EXP_DIR", str(exp)],
+                       cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    found = {}
+    for root, _, files in os.walk(str(exp)):
+        for f in files:
+            if f.endswith(".txt") and "img" in f:
+                found[f] = open(os.path.join(root, f)).read()
+    return found, r
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_images,gpu_id", [(4, "[0,0]"), (3, "[0,0,0,0]")])
+def test_cli_one_process_per_gpu_id(tmp_path, n_images, gpu_id):
+    """The reference's own multi-GPU mode (lib/test.py:327-345): one process per TEST.GPU_ID entry, contiguous image
+    ranges of ceil(N / workers), results gathered through a Queue in rank order, `len(dets[0]) == len(imdb)` asserted.
+    Two (resp. four: the last one gets an EMPTY range) spawn workers on the one test GPU must write the same detection
+    files as the single-process run."""
+    from PIL import Image
+    from smallhardface_amd import caffemodel, weights
+    from tests import helpers as H
+    data = tmp_path / "data"
+    (data / "images" / "0--Parade").mkdir(parents=True)
+    rng = np.random.default_rng(3)
+    names = []
+    for i in range(n_images):
+        h, w = 80 + 12 * i, 150 - 9 * i
+        Image.fromarray(rng.integers(0, 256, (h, w, 3)).astype(np.uint8)).save(
+            data / "images" / "0--Parade" / ("img%d.jpg" % i))
+        names.append("images/0--Parade/img%d.jpg" % i)
+    (data / "wider_val.txt").write_text("\n".join(names) + "\n")
+    model = str(tmp_path / "synthetic.caffemodel")
+    caffemodel.write_caffemodel(model, weights.synth_params(H.detector_msg(True), cls_bias=1.0))
+    one, _ = _run_cli(tmp_path, data, model, "[0]", "exp_one")
+    many, r = _run_cli(tmp_path, data, model, gpu_id, "exp_many")
+    assert len(one) == n_images and sorted(one) == sorted(many), (sorted(one), sorted(many), r.stderr[-1500:])
+    for f in one:
+        assert one[f] == many[f], f           # same process-independent arithmetic: byte-identical files
+        assert int(one[f].splitlines()[1]) >= 1
+
+
 def test_cli_refuses_training():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "train_test.py"), "--train", "true"],
                        env=dict(os.environ, PYTHONPATH=ROOT), capture_output=True, text=True, timeout=120)
