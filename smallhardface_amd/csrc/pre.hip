@@ -3,11 +3,13 @@
 // (lib/utils/test_utils.py:29-46 _get_image_blob, lib/utils/blob.py:16-32 im_list_to_blob,
 // lib/test.py:35-38 pad, :150 flip), one thread per output pixel.
 //
-// The arithmetic is the host mirror's (smallhardface_amd/test_utils.py resize_bilinear): the
-// mean-subtracted image is float64 (uint8 -> f32 minus f64 PIXEL_MEANS), the interpolation
-// weights are f32 fractions widened to f64, products and sums are separate roundings (this file
-// is built with -ffp-contract=off), and only the finished level is narrowed to f32.  HBM-bound
-// and tiny next to the convolutions: 3 bytes in (x4 taps, L2-served), 12 bytes out per pixel.
+// The arithmetic is the host mirror's (smallhardface_amd/test_utils.py resize_bilinear), which restates OpenCV's
+// published INTER_LINEAR path for a CV_64F image (cv::resize / hal::resize / HResizeLinear / VResizeLinear in
+// modules/imgproc/src/resize.cpp): scale = 1 / f once in double; the source coordinate is narrowed to FLOAT before its
+// floor is subtracted (in float); the weights 1.f - fx and fx are floats widened to double; the mean-subtracted image
+// is float64 (uint8 -> f32 minus f64 PIXEL_MEANS); products and sums are separate roundings (this file is built with
+// -ffp-contract=off), and only the finished level is narrowed to f32.  HBM-bound and tiny next to the convolutions:
+// 3 bytes in (x4 taps, L2-served), 12 bytes out per pixel.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -17,26 +19,26 @@ namespace {
 
 struct AxisCoef {
   int i0, i1;
-  double w;
+  double a0, a1;
 };
 
-__device__ inline AxisCoef axis_coef(int d, int n_src, double f) {
-  double s = ((double)d + 0.5) / f - 0.5;
-  double fl = floor(s);
-  long long i0 = (long long)fl;
-  float frac = (float)(s - fl);
-  if (i0 < 0) {
-    i0 = 0;
-    frac = 0.f;
+__device__ inline AxisCoef axis_coef(int d, int n_src, double inv_f) {
+  float fx = (float)(((double)d + 0.5) * inv_f - 0.5);   // (float)((dx + 0.5) * scale_x - 0.5)
+  int sx = (int)floorf(fx);                              // cvFloor
+  fx -= (float)sx;
+  if (sx < 0) {
+    sx = 0;
+    fx = 0.f;
   }
-  if (i0 >= n_src - 1) {
-    i0 = n_src - 1;
-    frac = 0.f;
+  if (sx >= n_src - 1) {
+    sx = n_src - 1;
+    fx = 0.f;
   }
   AxisCoef c;
-  c.i0 = (int)i0;
-  c.i1 = (int)(i0 + 1 < n_src ? i0 + 1 : n_src - 1);
-  c.w = (double)frac;
+  c.i0 = sx;
+  c.i1 = sx + 1 < n_src ? sx + 1 : n_src - 1;
+  c.a0 = (double)(1.f - fx);
+  c.a1 = (double)fx;
   return c;
 }
 
@@ -55,21 +57,21 @@ __global__ void __launch_bounds__(256) pyramid_level_kernel(const uint8_t* __res
     o[2 * plane] = 0.f;
     return;
   }
-  const AxisCoef cy = axis_coef(y, im_h, scale);
-  const AxisCoef cx = axis_coef(flip ? lvl_w - 1 - x : x, im_w, scale);
+  const double inv_f = 1.0 / scale;
+  const AxisCoef cy = axis_coef(y, im_h, inv_f);
+  const AxisCoef cx = axis_coef(flip ? lvl_w - 1 - x : x, im_w, inv_f);
   const uint8_t* r0 = im + (size_t)cy.i0 * im_w * 3;
   const uint8_t* r1 = im + (size_t)cy.i1 * im_w * 3;
   const double mean[3] = {m0, m1, m2};
-  const double ux = 1.0 - cx.w, uy = 1.0 - cy.w;
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
     const double a00 = (double)(float)r0[cx.i0 * 3 + c] - mean[c];
     const double a01 = (double)(float)r0[cx.i1 * 3 + c] - mean[c];
     const double a10 = (double)(float)r1[cx.i0 * 3 + c] - mean[c];
     const double a11 = (double)(float)r1[cx.i1 * 3 + c] - mean[c];
-    const double top = a00 * ux + a01 * cx.w;
-    const double bot = a10 * ux + a11 * cx.w;
-    o[c * plane] = (float)(top * uy + bot * cy.w);
+    const double top = a00 * cx.a0 + a01 * cx.a1;
+    const double bot = a10 * cx.a0 + a11 * cx.a1;
+    o[c * plane] = (float)(top * cy.a0 + bot * cy.a1);
   }
 }
 

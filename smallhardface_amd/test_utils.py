@@ -3,12 +3,23 @@
 Mirrors /root/reference/lib/utils/test_utils.py:8-46 (``_compute_scaling_factor``,
 ``_get_image_blob``) and lib/utils/blob.py:16-32 (``im_list_to_blob``).
 
-The reference resizes with ``cv2.resize(..., INTER_LINEAR)``; OpenCV is not in
-this image and no reference test covers it, so ``resize_bilinear`` below is our
-own restatement of OpenCV's documented INTER_LINEAR rule (half-pixel centres,
-``dsize = round(src * f)``, source coordinate ``(d + 0.5) / f - 0.5``, replicated
-border).  Resize parity is therefore UNPINNED; the benchmarks and
-GPU parity tests start from blobs *after* the resize.
+The reference resizes with ``cv2.resize(im, None, None, fx=s, fy=s, interpolation=INTER_LINEAR)`` on a float64
+image (test_utils.py:43-44).  OpenCV is not in this image and no reference test covers it, so resize parity stays
+UNPINNED -- but ``resize_bilinear`` is not an arbitrary bilinear filter: it restates, operation for
+operation, what OpenCV 4.x publishes for this call (modules/imgproc/src/resize.cpp; line numbers cannot be checked
+offline, the functions are named instead):
+
+* ``cv::resize``: with an empty dsize, ``dsize = (cvRound(src_w * fx), cvRound(src_h * fy))`` and the given factors
+  are used as they are (``inv_scale = fx``, NOT dst / src);
+* ``hal::resize`` coefficient loop: ``scale = 1. / inv_scale`` once, in double; per destination index
+  ``fx = (float)((dx + 0.5) * scale - 0.5); sx = cvFloor(fx); fx -= sx;`` -- the source coordinate is narrowed to
+  FLOAT before the floor is subtracted, in float; ``sx < 0 -> (fx, sx) = (0, 0)``; ``sx >= src_w - 1 -> (fx, sx) =
+  (0, src_w - 1)``; ``cbuf[0] = 1.f - fx; cbuf[1] = fx`` (a float subtraction);
+* ``HResizeLinear<double, double, float, 1>`` / ``VResizeLinear<double, double, float>`` (the CV_64F instantiation):
+  ``S[sx] * a0 + S[sx + cn] * a1`` with the float coefficients widened to double, rows first, then
+  ``S0[x] * b0 + S1[x] * b1``; products and sums are separate roundings.
+
+The benchmarks and GPU parity tests start from blobs *after* the resize; csrc/pre.hip is kept bit-equal to this file.
 """
 import numpy as np
 
@@ -37,25 +48,27 @@ def pyramid_scales(im_shape):
 
 
 def _axis_coeffs(n_src, n_dst, f):
+    """OpenCV's INTER_LINEAR coefficient table for one axis (hal::resize, see the module docstring):
+    -> (i0, i1, a0, a1) with float32 weights a0 = 1.f - fx, a1 = fx."""
+    scale = 1.0 / float(f)                                    # double scale_x = 1. / inv_scale_x
     d = np.arange(n_dst, dtype=np.float64)
-    s = (d + 0.5) / f - 0.5
-    i0 = np.floor(s).astype(np.int64)
-    frac = (s - i0).astype(np.float32)
-    # replicate border the way OpenCV does: clamp the index, zero the weight
-    lo = i0 < 0
+    fx = ((d + 0.5) * scale - 0.5).astype(np.float32)         # fx = (float)((dx + 0.5) * scale_x - 0.5)
+    i0 = np.floor(fx).astype(np.int64)                        # sx = cvFloor(fx)
+    fx = fx - i0.astype(np.float32)                           # fx -= sx   (float arithmetic)
+    lo = i0 < 0                                               # if (sx < 0) fx = 0, sx = 0
     i0[lo] = 0
-    frac[lo] = 0.0
-    hi = i0 >= n_src - 1
+    fx[lo] = 0.0
+    hi = i0 >= n_src - 1                                      # if (sx >= src_width - 1) fx = 0, sx = src_width - 1
     i0[hi] = n_src - 1
-    frac[hi] = 0.0
+    fx[hi] = 0.0
     i1 = np.minimum(i0 + 1, n_src - 1)
-    return i0, i1, frac
+    a0 = (np.float32(1.0) - fx).astype(np.float32)            # cbuf[0] = 1.f - fx
+    return i0, i1, a0, fx.astype(np.float32)
 
 
 def resize_bilinear(im, fx, fy):
-    """Bilinear resize of an HxWxC float image by factors (fx, fy).
-
-    Computes in the image's own dtype: the reference hands cv2 a float64 image
+    """cv2.resize(im, None, None, fx=fx, fy=fy, interpolation=cv2.INTER_LINEAR) of an HxWxC float image, restated
+    (module docstring).  Computes in the image's own dtype: the reference hands cv2 a float64 image
     (uint8.astype(f32) - float64 PIXEL_MEANS -> f64, test_utils.py:36)."""
     im = np.asarray(im)
     if im.dtype not in (np.float32, np.float64):
@@ -63,14 +76,15 @@ def resize_bilinear(im, fx, fy):
     h, w = im.shape[:2]
     nh = int(np.round(h * fy))  # cvRound: round-half-to-even, same as np.round
     nw = int(np.round(w * fx))
-    y0, y1, wy = _axis_coeffs(h, nh, fy)
-    x0, x1, wx = _axis_coeffs(w, nw, fx)
-    wx = wx[None, :, None].astype(im.dtype)
-    wy = wy[:, None, None].astype(im.dtype)
-    one = im.dtype.type(1)
-    top = im[y0][:, x0] * (one - wx) + im[y0][:, x1] * wx
-    bot = im[y1][:, x0] * (one - wx) + im[y1][:, x1] * wx
-    return top * (one - wy) + bot * wy
+    y0, y1, b0, b1 = _axis_coeffs(h, nh, fy)
+    x0, x1, a0, a1 = _axis_coeffs(w, nw, fx)
+    a0 = a0[None, :, None].astype(im.dtype)
+    a1 = a1[None, :, None].astype(im.dtype)
+    b0 = b0[:, None, None].astype(im.dtype)
+    b1 = b1[:, None, None].astype(im.dtype)
+    top = im[y0][:, x0] * a0 + im[y0][:, x1] * a1             # HResizeLinear on source row sy
+    bot = im[y1][:, x0] * a0 + im[y1][:, x1] * a1             # ... and sy + 1 (replicated at the border)
+    return top * b0 + bot * b1                                # VResizeLinear
 
 
 def im_list_to_blob(ims):

@@ -1,0 +1,79 @@
+"""The resize restatement against OpenCV's published INTER_LINEAR coefficient rule.
+
+cv2 is not in this image and the reference has no test for ``cv2.resize`` (lib/utils/test_utils.py:43-44), so resize
+parity stays unpinned; what this file pins is that ``smallhardface_amd.test_utils._axis_coeffs`` follows
+``hal::resize``'s arithmetic (modules/imgproc/src/resize.cpp: ``scale = 1. / f``; ``fx = (float)((dx + 0.5) * scale -
+0.5)``; ``sx = cvFloor(fx)``; ``fx -= sx`` in float; border rules; ``1.f - fx``) and not merely "some" bilinear filter.
+The tables below were derived OUTSIDE the implementation -- plain Python floats (IEEE double) with struct-packed
+float32 roundings -- and are kept as hexadecimal literals: destination index -> (source index, 1.f - fx, fx).
+
+What the rule implies and a textbook half-pixel filter would not do: the source coordinate loses its low bits to its
+integer part before the fraction is taken (f = 25/256, d = 50: the coordinate 516.62 leaves the fraction 12 bits)."""
+import numpy as np
+
+from smallhardface_amd import test_utils as TU
+
+H = float.fromhex
+
+# f -> (n_src, n_dst, {d: (sx, a0, a1)})
+TABLES = {
+    0.09765625: (1024, 100, {
+        0: (4, H('0x1.851ec00000000p-2'), H('0x1.3d70a00000000p-1')),
+        1: (14, H('0x1.1eb8800000000p-3'), H('0x1.b851e00000000p-1')),
+        2: (25, H('0x1.ccccc00000000p-1'), H('0x1.999a000000000p-4')),
+        3: (35, H('0x1.51eb800000000p-1'), H('0x1.5c29000000000p-2')),
+        50: (516, H('0x1.8520000000000p-2'), H('0x1.3d70000000000p-1')),
+        97: (997, H('0x1.9980000000000p-4'), H('0x1.ccd0000000000p-1')),
+        98: (1008, H('0x1.b850000000000p-1'), H('0x1.1ec0000000000p-3')),
+        99: (1018, H('0x1.3d70000000000p-1'), H('0x1.8520000000000p-2')),
+    }),
+    1.0 / 3.0: (30, 10, {d: (3 * d + 1, 1.0, 0.0) for d in (0, 1, 2, 3, 5, 7, 8, 9)}),   # lands on pixel centres exactly
+    1.3671875: (1024, 1400, {
+        0: (0, 1.0, 0.0),                                       # sx = -1 -> (0, fx = 0): replicated left border
+        1: (0, H('0x1.9c86940000000p-2'), H('0x1.31bcb60000000p-1')),
+        2: (1, H('0x1.57c57c0000000p-1'), H('0x1.5075080000000p-2')),
+        3: (2, H('0x1.e147b00000000p-1'), H('0x1.eb85000000000p-5')),
+        700: (511, H('0x1.1300000000000p-3'), H('0x1.bb40000000000p-1')),
+        1397: (1021, H('0x1.5070000000000p-2'), H('0x1.57c8000000000p-1')),
+        1398: (1022, H('0x1.31c0000000000p-1'), H('0x1.9c80000000000p-2')),
+        1399: (1023, 1.0, 0.0),                                 # sx >= src - 1 -> (src - 1, fx = 0): right border
+    }),
+}
+
+
+def test_axis_coefficients_follow_opencv_rule():
+    for f, (n_src, n_dst, rows) in TABLES.items():
+        assert int(np.round(n_src * f)) == n_dst                # dsize = cvRound(src * f)
+        i0, i1, a0, a1 = TU._axis_coeffs(n_src, n_dst, f)
+        assert a0.dtype == np.float32 and a1.dtype == np.float32
+        for d, (sx, w0, w1) in rows.items():
+            assert (int(i0[d]), float(a0[d]), float(a1[d])) == (sx, w0, w1), (f, d)
+            assert int(i1[d]) == min(sx + 1, n_src - 1)
+        assert i0.min() >= 0 and i1.max() <= n_src - 1 and np.all(a1 >= 0) and np.all(a1 < 1)
+
+
+def test_resize_is_rows_then_columns_in_the_image_dtype():
+    """HResizeLinear then VResizeLinear: S[sx] * a0 + S[sx + 1] * a1 per row, then S0 * b0 + S1 * b1, float weights
+    widened to the image's float64 -- checked element by element against a scalar restatement."""
+    rng = np.random.default_rng(0)
+    im = rng.integers(0, 256, (23, 31, 3)).astype(np.float32) - np.array([102.9801, 115.9465, 122.7717])
+    assert im.dtype == np.float64
+    for f in (0.09765625 * 4, 1.0 / 3.0, 1.3671875):
+        out = TU.resize_bilinear(im, f, f)
+        nh, nw = int(np.round(23 * f)), int(np.round(31 * f))
+        assert out.shape == (nh, nw, 3) and out.dtype == np.float64
+        y0, y1, b0, b1 = TU._axis_coeffs(23, nh, f)
+        x0, x1, a0, a1 = TU._axis_coeffs(31, nw, f)
+        for (y, x, c) in [(0, 0, 0), (nh - 1, nw - 1, 2), (nh // 2, nw // 3, 1), (1, nw - 2, 0)]:
+            top = im[y0[y], x0[x], c] * float(a0[x]) + im[y0[y], x1[x], c] * float(a1[x])
+            bot = im[y1[y], x0[x], c] * float(a0[x]) + im[y1[y], x1[x], c] * float(a1[x])
+            assert out[y, x, c] == top * float(b0[y]) + bot * float(b1[y])
+
+
+def test_scale_one_is_not_resized():
+    """test_utils.py:40-41: `if scale == 1.0` the image goes in as it is (no cv2 call)."""
+    from smallhardface_amd.config import cfg
+    im = np.random.default_rng(1).integers(0, 256, (9, 11, 3)).astype(np.uint8)
+    blob = TU._get_image_blob(im, [1.0])[0]['data']
+    want = (im.astype(np.float32) - np.array(cfg.PIXEL_MEANS)).astype(np.float32).transpose(2, 0, 1)[None]
+    np.testing.assert_array_equal(blob, want.reshape(blob.shape))
