@@ -519,12 +519,14 @@ np.save(sys.argv[1], fd.detect(list(T.pyramid_units(im)), thresh=0.05)[0])
     assert not bad, bad
     # other kernels for the same layers (8-wave two-accumulator arithmetic, the pre-dual 4-wave kernels, conv1_1 on the
     # vector ALUs): fp32-class agreement
+    # (~1500 voted boxes of a noise image: a handful of clusters sit within the 1e-5 arithmetic difference of the
+    # IoU >= 0.4 / score > 0.05 cuts -- tools/diag_arith.py: the exact fp32 mode gives 1524 boxes, the dual-tile family
+    # 1524, the 8-wave kernels everywhere 1520 -- so rows are matched by score and coordinates, not by rank)
     for name in ("no_w4", "scalar_epilogue", "no_pc"):
         a, b = outs["default"], outs[name]
-        assert abs(len(a) - len(b)) <= 2, name
-        n = min(len(a), len(b))
-        assert np.abs(a[:n, 4] - b[:n, 4]).max() < SCORE_TOL, name
-        assert unmatched_rows(a, b) <= 2, name
+        slack = max(2, len(a) // 200)
+        assert abs(len(a) - len(b)) <= slack, name
+        assert unmatched_rows(a, b) <= slack and unmatched_rows(b, a) <= slack, name
 
 
 def test_full_bench_pyramid_properties(conv_mode):

@@ -1,6 +1,7 @@
 """Diagnostic: how far are the split-fp16 kernel families from the exact fp32 mode on one small pyramid?
 usage: python tools/diag_arith.py   (env knobs select the kernels: SHF_F16X3_W4=0 -> 8-wave two-accumulator everywhere)"""
-import sys
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from smallhardface_amd.config import cfg
 from smallhardface_amd import test as T
