@@ -40,6 +40,8 @@ struct ConvK {
   int nct, nmem;
   int ntile_blocks;  // persistent / dual-tile kernels: (pixel tiles of the group this launch ends at) x cout tiles
   int tile_base;     // dual-tile kernels: first pixel tile of this launch (a group may be covered by two launches)
+  int xcd_remap;     // dual-tile kernels: 1 = block b works on virtual block start(b % 8) + b / 8, so that the blocks an XCD
+                     // (b % 8) receives are CONSECUTIVE virtual blocks: all cout tiles of a pixel tile share one XCD's L2
   const float* w1t;  // FUSE1: first-layer weights transposed to [27][64]
   const void* w1f;   // FUSE1 (producer/consumer kernel): the same as split-fp16 MFMA B fragments (pack_first_conv_frags)
   const float* b1;   // FUSE1: first-layer bias [64]

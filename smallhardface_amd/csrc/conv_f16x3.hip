@@ -473,7 +473,11 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4d_kernel(ConvK p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wn = wave & 1, wm = wave >> 1;
-  const int bid = blockIdx.x;
+  int bid = blockIdx.x;
+  if (p.xcd_remap) {   // (experiment, SHF_F16X3_XCD_REMAP=1) blocks go to XCDs round-robin: give XCD x one contiguous run
+    const int G = gridDim.x, q = G >> 3, r = G & 7, x = bid & 7;
+    bid = x * q + (x < r ? x : r) + (bid >> 3);
+  }
   const int ct = bid % p.nct;
   const int pp = bid / p.nct;
   const int ntiles = p.ntile_blocks / p.nct;          // the launch covers pixel tiles [tile_base, ntiles) of the group
@@ -1156,6 +1160,7 @@ struct Knobs {
   int w4_mode;         // SHF_F16X3_W4: -1 auto (Cin >= 128), 0 never, 1 always -- which layers take the 4-wave dual-tile family
   int w4_mt;           // SHF_F16X3_W4_MT: 0 auto, 2 / 4 force 8- / 16-row tiles
   int w4d_ntile;       // SHF_F16X3_W4D_NTILE: 0 auto (hybrid launches), 1 / 2 force single- / two-tile blocks
+  int xcd_remap;       // SHF_F16X3_XCD_REMAP: 1 = all cout tiles of a pixel tile on one XCD (experiment)
   bool pc, dilated, k1, scalar_epilogue;   // SHF_F16X3_PC, SHF_F16X3_DILATED, SHF_F16X3_1X1 (default on), SHF_CONV_SCALAR_EPILOGUE (off)
   int cus;
 };
@@ -1166,6 +1171,7 @@ const Knobs& knobs() {
     q.w4_mode = env_int("SHF_F16X3_W4", -1);
     q.w4_mt = env_int("SHF_F16X3_W4_MT", 0);
     q.w4d_ntile = env_int("SHF_F16X3_W4D_NTILE", 0);
+    q.xcd_remap = env_int("SHF_F16X3_XCD_REMAP", 0);
     q.pc = env_int("SHF_F16X3_PC", 1) != 0;
     q.dilated = env_int("SHF_F16X3_DILATED", 1) != 0;
     q.k1 = env_int("SHF_F16X3_1X1", 1) != 0;
@@ -1228,8 +1234,17 @@ bool conv_f16x3_eligible(int Cin, int Cout, int k, int pad, int dil) {
 // 4-wave family: 16-row tiles (MT 4) or 8-row tiles (MT 2)?  A launch runs in ceil(blocks / CUs) rounds of one block
 // per CU; an 8-row block costs ~0.56 of a 16-row one (half the MFMAs, the same weight traffic per stage and the same
 // prologue / epilogue latencies).  SHF_F16X3_W4_MT = 2 / 4 forces the choice (experiments).
+// Short K loops (Cin <= 128: 24 stages) are the exception: there a block's prologue (first ~50 KB of weights and halo)
+// and epilogue (the output tile's store burst) are a third of its life, and the single-tile 8-row variant -- 66 KB of
+// LDS, 200 registers: TWO blocks per CU, one's epilogue under the other's K loop -- wins although it moves four times
+// the weight bytes per MFMA of a two-tile 16-row block.  Measured per layer on one box (tools/variant_layers.sh, us under
+// rocprofv3): conv2_2 1212 vs 1278, conv3_1 625 vs 672, head_1 102 vs 109; from Cin 256 up it loses (conv3_2 1186 vs 1134,
+// conv4_2 1196 vs 1072).
+static bool w4_short_k(const ConvArgs* as) { return as[0].in.C <= 128; }
+
 static int w4_pick_mt(const ConvArgs* as, int n, int nct) {
   if (knobs().w4_mt == 2 || knobs().w4_mt == 4) return knobs().w4_mt;
+  if (w4_short_k(as)) return 2;
   const int cus = knobs().cus;
   long long t4 = 0, t2 = 0;
   for (int i = 0; i < n; ++i) {
@@ -1255,6 +1270,7 @@ static int launch_f16x3_t(const ConvArgs* as, int n, hipStream_t s) {
   p.wscale_inv = 1.f;
   p.tile_base = 0;
   p.ntile_blocks = 0;
+  p.xcd_remap = knobs().xcd_remap;
   p.bias = a.bias;
   p.Cin = a.in.C; p.Cout = a.out.C;
   p.in_stride = a.in.cstride; p.out_stride = a.out.cstride;
@@ -1340,6 +1356,7 @@ static int launch_f16x3_t(const ConvArgs* as, int n, hipStream_t s) {
     long long n2 = 0;                                           // pixel tiles covered by the dual launch
     if (cost_all2 <= cost_all1 && cost_all2 <= cost_hyb) n2 = tiles;
     else if (cost_hyb < cost_all1) n2 = 2 * full2 * per_round;
+    if (w4_short_k(as) && knobs().w4_mt == 0) n2 = 0;          // two single-tile blocks per CU (w4_pick_mt)
     if (knobs().w4d_ntile == 1) n2 = 0;
     if (knobs().w4d_ntile == 2) n2 = tiles;
     const size_t as_b = (size_t)(th + 2) * (18 * 80 + 224);

@@ -1006,6 +1006,8 @@ void shf_net::ensure_tail_workspace(size_t total) {
   tw.rec = (float*)tw_rec.p;
   tw.keys = (unsigned long long*)tw_keys.p;
   tw.counters = (int*)tw_counters.p;
+  tw.amax = conv_mode >= 1 ? (unsigned*)amax_slots.p : nullptr;   // (the tail's reset kernel zeroes the slots for the next pass)
+  tw.n_amax = (int)blobs.size();
   tw.cap_anchors = total;
   tw.cap_keys = npad;
   const size_t rmax = (pre_nms_topN > 0) ? std::min<size_t>(total, (size_t)pre_nms_topN) : total;
@@ -1646,7 +1648,7 @@ void shf_net::prepare_unit(const float* data, int data_on_device, int H, int W, 
     d.dev.ensure(d.count() * 4);
     HIP_THROW(hipMemcpyAsync(d.dev.p, data, d.count() * 4, hipMemcpyHostToDevice, st));
   }
-  reset_amax(st);
+  // (the activation-exponent slots are zero here: zeroed at build, by Net.forward(), and by every pass's tail reset)
 }
 
 void shf_net::ensure_img_cap(int units_after) {

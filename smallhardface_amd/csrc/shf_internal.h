@@ -132,6 +132,10 @@ struct TailWork {  // device workspace owned by the net, sized for the largest l
   unsigned long long* keys = nullptr;  // [pow2 >= K*A]
   int* counters = nullptr;           // [8]: 0 = n candidates, 1 = overflow flag, 2 = R, 3 = argmax idx
   size_t cap_anchors = 0, cap_keys = 0;
+  // the lane's activation-exponent slots (conv_common.h): the tail's reset kernel runs behind the last convolution of
+  // a pass and zeroes them for the next one (ten 6-us fill kernels per image otherwise)
+  unsigned* amax = nullptr;
+  int n_amax = 0;
 };
 // runs logits -> decode -> select -> sort; leaves R (device counters[2]) rows in out_boxes/out_probs
 int launch_tail(const TailArgs& a, TailWork& ws, float* out_boxes5, float* out_probs2, hipStream_t s,

@@ -43,11 +43,17 @@ __device__ __forceinline__ bool delta_overflows(float v, float anchor_extent) {
 //      launch per stage instead of one per unit and stage (~100 five-microsecond launches per image) --------------
 struct TailResetK {
   int* counters[TG];
+  unsigned* amax[TG];   // activation-exponent slots of the member lanes (null: none): consumed by this pass's convolutions,
+  int n_amax[TG];       // zeroed here for the next pass
   int n;
 };
 __global__ void tail_reset_kernel(TailResetK p) {
   const int m = threadIdx.x >> 3, j = threadIdx.x & 7;
-  if (m < p.n) p.counters[m][j] = 0;
+  if (m < p.n) {
+    p.counters[m][j] = 0;
+    if (p.amax[m])
+      for (int i = j; i < p.n_amax[m]; i += 8) p.amax[m][i] = 0u;
+  }
 }
 
 struct TailGM {  // per member
@@ -457,7 +463,11 @@ int launch_tail_group(const TailArgs* as, TailWork* const* wss, float* const* ou
   if (phase != 2) {
     TailResetK rk;
     rk.n = n;
-    for (int m = 0; m < n; ++m) rk.counters[m] = wss[m]->counters;
+    for (int m = 0; m < n; ++m) {
+      rk.counters[m] = wss[m]->counters;
+      rk.amax[m] = wss[m]->amax;
+      rk.n_amax[m] = wss[m]->n_amax;
+    }
     hipLaunchKernelGGL(tail_reset_kernel, dim3(1), dim3(TG * 8), 0, s, rk);
     TailGK lk;
     fill_logits_shared(a0, lk);
