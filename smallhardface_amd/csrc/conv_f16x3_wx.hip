@@ -1,0 +1,537 @@
+// Winograd F(2,3) ALONG X on the split-fp16 matrix cores: 1.5x fewer MFMAs than the direct 3x3 kernels for the same
+// fp32-class result (experiment of round 3, VERDICT r2 #2 -- see DESIGN.md for why 1-D and not F(2x2,3x3)).
+//
+//   Y[y][2j]   = M0 + M1 + M2          M_p[y][j] = sum over ky, c of  U_p[ky][c][o] * V_p[y + ky - 1][j][c]
+//   Y[y][2j+1] = M1 - M2 - M3
+//   V0 = d0 - d2,  V1 = d1 + d2,  V2 = d2 - d1,  V3 = d1 - d3        (d_k = input column 2j - 1 + k of that row)
+//   U0 = g0,  U1 = (g0 + g1 + g2) / 2,  U2 = (g0 - g1 + g2) / 2,  U3 = g2     (g_k = weight tap kx = k of that kernel row)
+//
+// A pair of neighbouring output pixels costs 3 x 4 = 12 multiplies per (cin, cout) instead of 18.  The kernel is the
+// single-tile member of the dual-tile 4-wave family with the roles re-cast: the four "taps" of a stage are the four
+// Winograd positions, the halo tile in LDS is the TRANSFORMED tile V[position][halo row][pair] (built from the fp32 /
+// split-format input in the hand-over: adds in fp32, THEN the hi / lo split, so the split error is that of a direct conv's
+// operand), the weights come pre-transformed (in double) and pre-split from their own pack, and the 16 accumulator tiles
+// a lone wave owns are 4 positions x (2 x 2) MFMA tiles = a 16x16-pixel x 128-cout block tile.  The output transform
+// is two adds per pixel on the accumulators, then the family's register epilogue, once for the even and once for the odd
+// column of the pair.  Same single-accumulator arithmetic as the family (unscaled low parts, activation exponent).
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+
+#include "conv_common.h"
+
+namespace shf {
+
+typedef _Float16 wx_half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 wx_h2 __attribute__((ext_vector_type(2)));
+typedef float wx_f32x16 __attribute__((ext_vector_type(16)));
+typedef float wx_f32x2 __attribute__((ext_vector_type(2)));
+
+template <bool IN_SPLIT, int NP>
+__global__ __launch_bounds__(256) void conv_mfma_f16x3_wx_kernel(ConvK p) {
+  constexpr int TH = 16, TW = 16, HTH = TH + 2, NJ = TW / 2, KC = 16;
+  constexpr int ROWB = 80;                  // [hi 16 halfs | lo 16 halfs | 16 B pad] per (halo row, pair)
+  constexpr int VROW = NJ * ROWB;           // 640 B per halo row: 40 sixteen-byte groups = 8 (mod 16) -> the 4-row x 8-pair
+                                            // fragment of a ds_read_b128 lane group covers 16 different bank groups
+  constexpr int PLANE = HTH * VROW;         // 11 520 B per position
+  constexpr int BN = 128, NT = 256, WROWB = 64, SLAB_B = BN * WROWB, STAGE_B = 4 * SLAB_B;   // 32 KiB of weights per stage
+  constexpr int NITEMS = HTH * NJ * 2;      // hand-over work items: (halo row, pair, 8-channel half of the chunk) = 288
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* Vs = smem;                 // [2 buffers: chunk parity][4][HTH][NJ][ROWB]
+  unsigned char* Bs = smem + 8 * PLANE;     // [2 buffers: stage parity][4 positions][BN][WROWB]
+  float* biasL = (float*)(Bs + 2 * STAGE_B);
+  unsigned char* dump = (unsigned char*)(biasL + BN);   // 64 B: where lanes without an item park their (meaningless) pieces --
+                                                        // a branch around the stores would split the MFMA scheduling region
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave & 1, wm = wave >> 1;
+  const int bid = blockIdx.x;
+  const int ct = bid % p.nct;
+  int pt = bid / p.nct;
+  const int mi = conv_find_member(p, pt);
+  const ConvMember& mem = p.m[mi];
+  pt -= mem.tile_start;
+  int b, ty_, tx_;
+  conv_split_tile(mem, pt, b, ty_, tx_);
+  const int ty0 = ty_ * TH, tx0 = tx_ * TW;
+  const int H = mem.H, W = mem.W;
+
+  const int nchunks = p.Cin / KC;
+  const int NST = nchunks * 3;
+  const size_t slab_h = (size_t)p.Cout * 32;            // halfs per (chunk, ky, position) slab of the whole layer
+  const _Float16* wbase = (const _Float16*)p.wph + (size_t)ct * BN * 32;
+
+  // ---- hand-over items: thread t owns item t (all) and item 256 + t (t < 32)
+  //      item -> halo row hy, pair j, channel half g; its four input pixels are columns 2j - 1 .. 2j + 2 of row hy - 1
+  const int e_act = __builtin_amdgcn_readfirstlane(conv_act_exponent(mem.in_amax));
+  const float act_scale = __builtin_bit_cast(float, (unsigned)(127 + e_act) << 23);                     // 2^e
+  const float act_scale_lo = __builtin_bit_cast(float, (unsigned)(127 + e_act - 11) << 23);             // 2^(e - 11)
+  // 288 items, 72 per wave: lane l of wave w owns item 72 w + l and, for l < 8, item 72 w + 64 + l -- every wave runs
+  // the same two passes (a lone wave with a second pass would hold the other three at every barrier)
+  struct Item { unsigned off[4]; float sk[4]; int loff; };   // sk[k] = 2^e for a pixel inside the image, else 0
+  auto make_item = [&](int it, bool exists) {
+    Item q;
+    const int hy = it >> 4, j = (it >> 1) & 7, g = it & 1;
+    const int gy = ty0 - 1 + hy, gx0 = tx0 - 1 + 2 * j;
+    const bool row_ok = exists && (unsigned)gy < (unsigned)H;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const bool ok = row_ok && (unsigned)(gx0 + k) < (unsigned)W;
+      q.sk[k] = ok ? act_scale : 0.f;
+      // byte offset (chunk 0) of pixel (gy, gx0 + k) + this half's first channel; pixels outside the image read the
+      // member's first pixel (in bounds, finite; multiplied by sk = 0 in prep), so that every load is unconditional
+      q.off[k] = (ok ? (unsigned)(((b * H + gy) * W + gx0 + k) * p.in_stride) * 4u : 0u) + (IN_SPLIT ? (unsigned)(g * 16) : (unsigned)(g * 32));
+    }
+    q.loff = exists ? hy * VROW + j * ROWB + g * 16 : -1;
+    return q;
+  };
+  const Item it0 = make_item(72 * wave + lane, true), it1 = make_item(72 * wave + 64 + (lane & 7), lane < 8);
+  auto chunk_off = [&](int c16) -> unsigned {
+    return IN_SPLIT ? (unsigned)((c16 >> 1) * 128 + (c16 & 1) * 32) : (unsigned)(c16 * 64);
+  };
+  // the eight 16-byte pieces of an item: pixel k -> (r[2k], r[2k+1]) = fp32: channels 0-3 / 4-7; split: hi / lo piece
+  auto load_item = [&](const Item& q, unsigned coff, float4 (&r)[8]) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const char* a = (const char*)mem.in + (q.off[k] + coff);
+      r[2 * k] = *(const float4*)a;
+      r[2 * k + 1] = *(const float4*)(a + (IN_SPLIT ? 64 : 16));
+    }
+  };
+  // hand-over arithmetic, in three steps so that the vector work can ride under a stage's MFMAs position by position:
+  //   prep:   d[k][c] = the unit's input lifted by 2^e (exact), as fp32, zero outside the image
+  //   xform:  one position's V = B^T d for the item's 8 channels, split hi / lo (unscaled), as two 16-byte pieces
+  //   park:   the eight pieces to LDS (after the barrier that retires the previous chunk's tile)
+  struct Dv { float d[4][8]; };
+  struct Vv { float4 hi[4], lo[4]; };
+  auto prep = [&](const Item& q, const float4 (&r)[8], Dv& o) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float sk = q.sk[k];
+      if constexpr (IN_SPLIT) {
+        const float sk_lo = sk * (1.0f / 2048.0f);
+        const float* hp = &r[2 * k].x;
+        const float* lp = &r[2 * k + 1].x;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const wx_h2 h = __builtin_bit_cast(wx_h2, hp[t]), l = __builtin_bit_cast(wx_h2, lp[t]);
+          // (two v_fma_mix_f32 per value: f16 x f32 + f32)
+          o.d[k][2 * t] = __builtin_fmaf((float)l[0], sk_lo, (float)h[0] * sk);
+          o.d[k][2 * t + 1] = __builtin_fmaf((float)l[1], sk_lo, (float)h[1] * sk);
+        }
+      } else {
+        const float v[8] = {r[2 * k].x, r[2 * k].y, r[2 * k].z, r[2 * k].w, r[2 * k + 1].x, r[2 * k + 1].y, r[2 * k + 1].z, r[2 * k + 1].w};
+#pragma unroll
+        for (int t = 0; t < 8; ++t) o.d[k][t] = v[t] * sk;
+      }
+    }
+  };
+  auto xform = [&](const Dv& o, auto POS_, Vv& out) {
+    constexpr int pos = decltype(POS_)::value;
+    float hi4[4], lo4[4];
+#pragma unroll
+    for (int t = 0; t < 8; t += 2) {
+      wx_f32x2 v;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const float d0 = o.d[0][t + u], d1 = o.d[1][t + u], d2 = o.d[2][t + u], d3 = o.d[3][t + u];
+        v[u] = pos == 0 ? d0 - d2 : pos == 1 ? d1 + d2 : pos == 2 ? d2 - d1 : d1 - d3;
+      }
+      const wx_h2 h = __builtin_convertvector(v, wx_h2);
+      // lo = v - hi as one mixed-precision FMA per value (v_fma_mix_f32: f16 x f32 + f32)
+      const wx_f32x2 rem = {__builtin_fmaf((float)h[0], -1.0f, v[0]), __builtin_fmaf((float)h[1], -1.0f, v[1])};
+      const wx_h2 l = __builtin_convertvector(rem, wx_h2);
+      hi4[t >> 1] = __builtin_bit_cast(float, h);
+      lo4[t >> 1] = __builtin_bit_cast(float, l);
+    }
+    out.hi[pos] = make_float4(hi4[0], hi4[1], hi4[2], hi4[3]);
+    out.lo[pos] = make_float4(lo4[0], lo4[1], lo4[2], lo4[3]);
+  };
+  auto park = [&](const Item& q, const Vv& v, int vbuf) {
+    unsigned char* base = q.loff >= 0 ? Vs + vbuf * (4 * PLANE) + q.loff : dump;
+    const int plane = q.loff >= 0 ? PLANE : 0;
+#pragma unroll
+    for (int pos = 0; pos < 4; ++pos) {
+      unsigned char* dst = base + pos * plane;
+      *(float4*)dst = v.hi[pos];
+      *(float4*)(dst + 32) = v.lo[pos];
+    }
+  };
+  // hipcc places pure arithmetic right behind its operands' definition, across barriers and sched_barriers alike: without
+  // these opaque "uses" the whole transform lands behind the loads of the FIRST stage and waits for them there
+  auto pin4 = [](float4& v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); };
+  auto pin_regs = [&](float4 (&r)[8]) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) pin4(r[k]);
+  };
+  auto pin_dv = [&](Dv& o) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      asm volatile("" : "+v"(o.d[k][0]), "+v"(o.d[k][1]), "+v"(o.d[k][2]), "+v"(o.d[k][3]));
+      asm volatile("" : "+v"(o.d[k][4]), "+v"(o.d[k][5]), "+v"(o.d[k][6]), "+v"(o.d[k][7]));
+    }
+  };
+  auto pin_vv = [&](Vv& v) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { pin4(v.hi[k]); pin4(v.lo[k]); }
+  };
+  using std::integral_constant;
+  auto transform_store = [&](const Item& q, float4 (&r)[8], int vbuf) {
+    Dv dv;
+    Vv vv;
+    prep(q, r, dv);
+    xform(dv, integral_constant<int, 0>{}, vv);
+    xform(dv, integral_constant<int, 1>{}, vv);
+    xform(dv, integral_constant<int, 2>{}, vv);
+    xform(dv, integral_constant<int, 3>{}, vv);
+    park(q, vv, vbuf);
+  };
+
+  // ---- weight DMA: a stage is 32 one-KiB pieces (4 position slabs of 8); round r of a wave moves piece wave + 4 r
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const unsigned lane16 = (unsigned)lane * 16u;
+  auto dma_w = [&](int stage, int buf, int r0, int n) {
+    const unsigned char* ws_ = (const unsigned char*)(wbase + (size_t)stage * 4 * slab_h);
+    unsigned char* bd_ = Bs + buf * STAGE_B;
+#pragma unroll
+    for (int r = r0; r < r0 + n; ++r) {
+      const unsigned char* ub = ws_ + (size_t)(r >> 1) * slab_h * 2 + (size_t)(4 * (r & 1) + wave_u) * 1024;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ub + lane16),
+                                       (__attribute__((address_space(3))) void*)(bd_ + (4 * r + wave_u) * 1024), 16, 0, 0);
+    }
+  };
+
+  // ---- prologue
+  float4 ra[8], rb[8];
+  load_item(it0, 0u, ra);
+  load_item(it1, 0u, rb);
+  dma_w(0, 0, 0, 8);
+  if (tid < BN) biasL[tid] = p.bias ? p.bias[ct * BN + tid] : 0.f;
+
+  const int i = lane & 31, kh = lane >> 5;
+  int a_off[2], b_off[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) a_off[t] = (wm * 8 + t * 4 + (i >> 3)) * VROW + (i & 7) * ROWB + kh * 16;
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+    b_off[t] = (wn * 64 + t * 32 + i) * WROWB + ((kh + ((wn * 64 + t * 32 + i) >> 2)) & 3) * 16;
+  wx_f32x16 acc[4][2][2];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][a][c][r] = 0.f;
+  __builtin_amdgcn_sched_barrier(0);
+  transform_store(it0, ra, 0);
+  transform_store(it1, rb, 0);
+
+  // A stage = kernel row ky of chunk c = 4 positions x 12 MFMAs per wave, ONE barrier at its top: the weights of stage
+  // st + 1 are requested during stage st into the other weight buffer, and the transformed tile is double-buffered by
+  // chunk parity, so the hand-over never waits for the readers of the current tile.  A lone wave hides ~5 other
+  // instructions per MFMA, so the hand-over of chunk c + 1 is spread over all three stages of chunk c: MODE 1 (first
+  // kernel row) requests the two items' pixels, MODE 2 / 3 (middle / last row) transform item 0 / item 1 and park the
+  // pieces in the other tile buffer -- all of it under the stages' MFMAs, no extra barrier.
+  Dv dv0;
+  Vv vv0;
+#ifdef SHF_WX_TIMING
+  unsigned long long tw[3] = {0, 0, 0}, tb[3] = {0, 0, 0}, tm_[3] = {0, 0, 0}, tp = 0, t_a, t_b, t_c, t_d;
+  const unsigned long long t_loop0 = __builtin_amdgcn_s_memtime();
+#define WX_T(x) x = __builtin_amdgcn_s_memtime()
+#else
+#define WX_T(x)
+#endif
+  auto stage = [&](int c, auto KY_, auto MODE_) {
+    constexpr int ky = decltype(KY_)::value, MODE = decltype(MODE_)::value;
+    const int st = c * 3 + ky;
+    WX_T(t_a);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of W(st) (and, in a transform stage, its items) landed
+    WX_T(t_b);
+    __syncthreads();
+    WX_T(t_c);
+    const int st_pre = st + 1 < NST ? st + 1 : st;   // the last stage re-fetches itself (unused) instead of branching
+    const int buf_pre = (st + 1) & 1;
+    const unsigned char* Bst = Bs + (st & 1) * STAGE_B;
+    const unsigned char* Vc = Vs + (c & 1) * (4 * PLANE);
+    wx_half8 fa[2][4], fb[2][4];
+    auto load_frag = [&](int pos, wx_half8* a, wx_half8* bf) {
+      const unsigned char* Ap = Vc + pos * PLANE + ky * VROW;
+      const unsigned char* Bp = Bst + pos * SLAB_B;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        a[2 * t] = *(const wx_half8*)(Ap + a_off[t]);
+        a[2 * t + 1] = *(const wx_half8*)(Ap + a_off[t] + 32);
+        bf[2 * t] = *(const wx_half8*)(Bp + b_off[t]);
+        bf[2 * t + 1] = *(const wx_half8*)(Bp + (b_off[t] ^ 32));
+      }
+    };
+    load_frag(0, fa[0], fb[0]);
+    __builtin_amdgcn_sched_barrier(0);
+    auto position = [&](auto POS_) {
+      constexpr int pos = decltype(POS_)::value;
+      wx_half8* a = fa[pos & 1];
+      wx_half8* bf = fb[pos & 1];
+      if (pos + 1 < 4) load_frag(pos + 1, fa[(pos + 1) & 1], fb[(pos + 1) & 1]);
+      if constexpr (MODE == 1) {   // (before this stage's weight requests: vmcnt is in-order)
+        if (pos == 0) load_item(it0, chunk_off(c + 1), ra);
+        if (pos == 1) load_item(it1, chunk_off(c + 1), rb);
+      }
+      dma_w(st_pre, buf_pre, 2 * pos, 2);
+      if constexpr (MODE >= 2) {   // item 0 under the middle kernel row's MFMAs, item 1 under the last one's
+        const Item& q = MODE == 2 ? it0 : it1;
+        float4 (&r)[8] = MODE == 2 ? ra : rb;
+        if (pos == 0) {
+          pin_regs(r);
+          prep(q, r, dv0);
+          xform(dv0, integral_constant<int, 0>{}, vv0);
+        } else if (pos == 1) {
+          pin_dv(dv0);
+          xform(dv0, integral_constant<int, 1>{}, vv0);
+          xform(dv0, integral_constant<int, 2>{}, vv0);
+        } else if (pos == 2) {
+          pin_dv(dv0);
+          xform(dv0, integral_constant<int, 3>{}, vv0);
+        } else {
+          pin_vv(vv0);
+          park(q, vv0, (c + 1) & 1);
+        }
+      }
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+          acc[pos][tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[2 * tn], a[2 * tm], acc[pos][tm][tn], 0, 0, 0);
+      if constexpr (NP >= 2) {
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < 2; ++tn)
+            acc[pos][tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[2 * tn + 1], a[2 * tm], acc[pos][tm][tn], 0, 0, 0);
+      }
+      if constexpr (NP >= 3) {
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < 2; ++tn)
+            acc[pos][tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[2 * tn], a[2 * tm + 1], acc[pos][tm][tn], 0, 0, 0);
+      }
+      // per MFMA: one of the next position's 8 fragment reads (first 8), one of the two DMA issues (next 2), and in a
+      // transform stage a few of this position's vector instructions
+#pragma unroll
+      for (int g = 0; g < 4 * NP; ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (pos + 1 < 4 && g < 8) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        if (MODE == 1 && pos < 2 && g < 8) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // an item's 8 loads
+        if (g >= 4 * NP - 2) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+        if (MODE >= 2 && pos < 3) __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+        if (MODE >= 2 && pos == 3 && g < 8) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);     // the item's 8 LDS stores
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    position(integral_constant<int, 0>{});
+    position(integral_constant<int, 1>{});
+    position(integral_constant<int, 2>{});
+    position(integral_constant<int, 3>{});
+#ifdef SHF_WX_TIMING
+    asm volatile("s_nop 0" ::: "memory");
+    WX_T(t_d);
+    tw[MODE % 3] += t_b - t_a; tb[MODE % 3] += t_c - t_b; tm_[MODE % 3] += t_d - t_c;
+#endif
+    if constexpr (MODE == 3) {
+#ifdef SHF_WX_TIMING
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      WX_T(t_a);
+      tp += t_a - t_d;
+#endif
+    }
+  };
+#pragma unroll 1
+  for (int c = 0; c + 1 < nchunks; ++c) {
+    stage(c, integral_constant<int, 0>{}, integral_constant<int, 1>{});
+    stage(c, integral_constant<int, 1>{}, integral_constant<int, 2>{});
+    stage(c, integral_constant<int, 2>{}, integral_constant<int, 3>{});
+  }
+  stage(nchunks - 1, integral_constant<int, 0>{}, integral_constant<int, 0>{});
+  stage(nchunks - 1, integral_constant<int, 1>{}, integral_constant<int, 0>{});
+  stage(nchunks - 1, integral_constant<int, 2>{}, integral_constant<int, 0>{});
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the last stage's (unused) self re-fetch
+#ifdef SHF_WX_TIMING
+  const unsigned long long t_loop1 = __builtin_amdgcn_s_memtime();
+  if (lane == 0 && (bid == 0 || bid == 300) && (wave == 0 || wave == 1))
+    printf("[wx] blk%d wave%d chunks %d loop %llu | per stage (mode 0/1/2): vmwait %llu %llu %llu barrier %llu %llu %llu body %llu %llu %llu | park per chunk %llu\n",
+           bid, wave, nchunks, t_loop1 - t_loop0, tw[0] / (nchunks + 2), tw[1] / (nchunks - 1), tw[2] / (nchunks - 1), tb[0] / (nchunks + 2),
+           tb[1] / (nchunks - 1), tb[2] / (nchunks - 1), tm_[0] / (nchunks + 2), tm_[1] / (nchunks - 1), tm_[2] / (nchunks - 1), tp / (nchunks - 1));
+#endif
+
+  // ---- output transform + register epilogue: lane column i = (tile row i >> 3, pair i & 7)
+  float amax = 0.f;
+  {
+    const bool relu = (p.relu & 1) != 0, main_split = (p.relu & 32) != 0;
+    const float out_scale = p.wscale_inv * __builtin_bit_cast(float, (unsigned)(127 - e_act) << 23);
+    int i_e = i, kh_e = kh;
+    asm volatile("" : "+v"(i_e), "+v"(kh_e));
+    float4 bias16[2][4];
+#pragma unroll
+    for (int g = 0; g < 8; ++g)
+      bias16[g >> 2][g & 3] = *(const float4*)(biasL + wn * 64 + (g >> 2) * 32 + kh_e * 16 + 4 * (g & 3));
+    const int x0 = tx0 + 2 * (i_e & 7);
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) {
+      const int cout16 = ct * BN + wn * 64 + tn * 32 + kh_e * 16;
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm) {
+        const int y = ty0 + wm * 8 + tm * 4 + (i_e >> 3);
+        float* pm = mem.out + ((size_t)(b * H + y) * W + x0) * p.out_stride;
+        const wx_f32x16 m0 = acc[0][tm][tn], m1 = acc[1][tm][tn], m2 = acc[2][tm][tn], m3 = acc[3][tm][tn];
+        const wx_f32x16 ye = (m0 + m1) + m2, yo = (m1 - m2) - m3;
+        const bool v0 = y < H && x0 < W, v1 = y < H && x0 + 1 < W;
+        if (relu) {
+          conv_epilogue_regs1<true>(ye, out_scale, bias16[tn], v0, false, pm, cout16, main_split, nullptr, false, false, amax);
+          conv_epilogue_regs1<true>(yo, out_scale, bias16[tn], v1, false, pm + p.out_stride, cout16, main_split, nullptr, false, false, amax);
+        } else {
+          conv_epilogue_regs1<false>(ye, out_scale, bias16[tn], v0, false, pm, cout16, main_split, nullptr, false, false, amax);
+          conv_epilogue_regs1<false>(yo, out_scale, bias16[tn], v1, false, pm + p.out_stride, cout16, main_split, nullptr, false, false, amax);
+        }
+      }
+    }
+  }
+  conv_raise_range_flag(p.range_flag, amax);
+  conv_publish_amax(mem.out_amax, nullptr, amax);
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+size_t wx_conv_weight_halfs(int Cout, int Cin) { return (size_t)Cout * (Cin / 16) * 3 * 4 * 32; }
+
+// (Cout, Cin, 3, 3) fp32 -> [Cin/16][ky][position][Cout][4 x 8 halfs]: the Winograd-transformed weights (formed in double),
+// scaled by one power of two per layer and split hi / lo UNSCALED like pack_conv_weights_split16h (same 64-byte rows, same
+// rotation of the four 16-byte pieces by row / 4).  Returns 1 / scale.
+float pack_conv_weights_wx16h(const float* w, int Cout, int Cin, void* dst_) {
+  _Float16* dst = (_Float16*)dst_;
+  auto U = [&](int co, int ci, int ky, int pos) -> double {
+    const float* g = w + (((size_t)co * Cin + ci) * 3 + ky) * 3;
+    const double g0 = g[0], g1 = g[1], g2 = g[2];
+    return pos == 0 ? g0 : pos == 1 ? 0.5 * (g0 + g1 + g2) : pos == 2 ? 0.5 * (g0 - g1 + g2) : g2;
+  };
+  double amax = 0.0;
+  for (int co = 0; co < Cout; ++co)
+    for (int ci = 0; ci < Cin; ++ci)
+      for (int ky = 0; ky < 3; ++ky)
+        for (int pos = 0; pos < 4; ++pos) amax = std::max(amax, std::fabs(U(co, ci, ky, pos)));
+  int e = 0;
+  if (amax > 0.0) e = (int)std::floor(std::log2(8.0 / amax));
+  e = std::max(-14, std::min(14, e));
+  const double s = std::ldexp(1.0, e);
+  memset(dst_, 0, wx_conv_weight_halfs(Cout, Cin) * 2);
+  for (int co = 0; co < Cout; ++co)
+    for (int ci = 0; ci < Cin; ++ci)
+      for (int ky = 0; ky < 3; ++ky)
+        for (int pos = 0; pos < 4; ++pos) {
+          const float x = (float)(U(co, ci, ky, pos) * s);
+          const _Float16 h = (_Float16)x;
+          const _Float16 l = (_Float16)(x - (float)h);
+          const size_t row = ((((size_t)(ci / 16) * 3 + ky) * 4 + pos) * Cout + co) * 32;
+          const int kk = ci % 16, rot = ((co & 127) >> 2) & 3;
+          dst[row + (((kk >> 3) + rot) & 3) * 8 + (kk & 7)] = h;
+          dst[row + ((2 + (kk >> 3) + rot) & 3) * 8 + (kk & 7)] = l;
+        }
+  return (float)(1.0 / s);
+}
+
+bool conv_f16x3_wx_enabled() {
+  static const bool on = getenv("SHF_F16X3_WX") && atoi(getenv("SHF_F16X3_WX")) != 0;
+  return on;
+}
+
+// which layers the Winograd kernel takes when it is enabled: 3x3 / dilation 1, Cin a multiple of 16 and >= SHF_F16X3_WX_MIN_CIN
+// (default 256), Cout a multiple of 128, no fused pool (v1)
+bool conv_f16x3_wx_shape_ok(int Cin, int Cout, int k, int pad, int dil) {
+  static const int min_cin = getenv("SHF_F16X3_WX_MIN_CIN") ? atoi(getenv("SHF_F16X3_WX_MIN_CIN")) : 256;
+  return k == 3 && dil == 1 && pad == 1 && Cin % 16 == 0 && Cin >= min_cin && Cout % 128 == 0;
+}
+
+int conv_f16x3_wx_init_attributes() {
+#define SHF_WX_ATTR(SPLIT, NPV)                                                                                    \
+  SHF_HIP_OK(hipFuncSetAttribute((const void*)conv_mfma_f16x3_wx_kernel<SPLIT, NPV>,                              \
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  SHF_WX_ATTR(false, 3) SHF_WX_ATTR(true, 3) SHF_WX_ATTR(false, 2) SHF_WX_ATTR(true, 2) SHF_WX_ATTR(false, 1) SHF_WX_ATTR(true, 1)
+#undef SHF_WX_ATTR
+  return 0;
+}
+
+bool conv_f16x3_group_is_wx(const ConvArgs* as, int n) {
+  if (!as[0].wsplitwx || as[0].img || as[0].pool.p) return false;
+  for (int i = 0; i < n; ++i) {
+    const ConvArgs& q = as[i];
+    if (q.pool.p) return false;
+    if ((q.out.cstride % 4) || (q.out.coff % 4) || ((uintptr_t)q.out.p & 15)) return false;
+    if ((unsigned long long)q.in.B * q.in.H * q.in.W * q.in.cstride * 4ull >= (1ull << 32)) return false;
+  }
+  return true;
+}
+
+int launch_conv_f16x3_wx_group(const ConvArgs* as, int n, hipStream_t s) {
+  const ConvArgs& a = as[0];
+  ConvK p;
+  memset(&p, 0, sizeof(p));
+  p.wph = a.wsplitwx;
+  p.wscale_inv = a.wscale_inv_wx;
+  p.bias = a.bias;
+  p.Cin = a.in.C; p.Cout = a.out.C;
+  p.in_stride = a.in.cstride; p.out_stride = a.out.cstride;
+  p.dil = 1;
+  p.relu = a.relu | 16 | (a.out_split ? 32 : 0);
+  p.nct = p.Cout / 128;
+  p.nmem = n;
+  p.range_flag = a.range_flag;
+  for (int i = 0; i < MAX_GROUP; ++i) p.tile_starts[i] = 0x7fffffff;
+  long long tiles = 0;
+  for (int i = 0; i < n; ++i) {
+    const ConvArgs& q = as[i];
+    if (q.in.C != p.Cin || q.out.C != p.Cout || q.in.cstride != p.in_stride || q.out.cstride != p.out_stride ||
+        q.wsplitwx != a.wsplitwx || q.in_split != a.in_split || q.out_split != a.out_split) {
+      set_error("conv group: members must share the layer");
+      return -1;
+    }
+    ConvMember& m = p.m[i];
+    m.in = q.in.p + q.in.coff;
+    m.out = q.out.p + q.out.coff;
+    m.pool = nullptr;
+    m.img = nullptr;
+    m.in_amax = q.in_amax; m.out_amax = q.out_amax; m.pool_amax = nullptr;
+    m.B = q.in.B; m.H = q.in.H; m.W = q.in.W;
+    m.tiles_x = (m.W + 15) / 16;
+    m.tiles_per_img = m.tiles_x * ((m.H + 15) / 16);
+    m.inv_tiles_x = conv_inv32(m.tiles_x);
+    m.inv_tiles_per_img = conv_inv32(m.tiles_per_img);
+    m.tile_start = (int)tiles;
+    p.tile_starts[i] = (int)tiles;
+    tiles += (long long)m.tiles_per_img * m.B;
+    if ((unsigned long long)m.tiles_per_img * m.B * (unsigned long long)m.tiles_per_img >= (1ull << 32)) {
+      set_error("conv f16x3 wx: too many pixel tiles in one member");
+      return -1;
+    }
+  }
+  const size_t lds = 2 * 4 * 18 * 640 + 2 * 4 * 128 * 64 + 128 * sizeof(float) + 64;
+  const dim3 grid((unsigned)(tiles * p.nct));
+  if (a.sub_hook) a.sub_hook(a.sub_ctx, 0, 8 + (a.in_split ? 1 : 0), 1.0);
+#define SHF_WX_LAUNCH(SPLIT)                                                                                              \
+  {                                                                                                                       \
+    if (a.nprod >= 3) hipLaunchKernelGGL((conv_mfma_f16x3_wx_kernel<SPLIT, 3>), grid, dim3(256), lds, s, p);             \
+    else if (a.nprod == 2) hipLaunchKernelGGL((conv_mfma_f16x3_wx_kernel<SPLIT, 2>), grid, dim3(256), lds, s, p);        \
+    else hipLaunchKernelGGL((conv_mfma_f16x3_wx_kernel<SPLIT, 1>), grid, dim3(256), lds, s, p);                          \
+  }
+  if (a.in_split) SHF_WX_LAUNCH(true)
+  else SHF_WX_LAUNCH(false)
+#undef SHF_WX_LAUNCH
+  if (a.sub_hook) a.sub_hook(a.sub_ctx, 1, 8 + (a.in_split ? 1 : 0), 1.0);
+  SHF_HIP_OK(hipGetLastError());
+  return 0;
+}
+
+}  // namespace shf
