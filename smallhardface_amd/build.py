@@ -20,7 +20,6 @@ ARCH = "gfx950"
 SOURCES = [
     ("conv.hip", []),
     ("conv_f16x3.hip", []),
-    ("conv_f16x3_wx.hip", []),
     ("misc.hip", []),
     ("tail.hip", ["-ffp-contract=off"]),
     ("merge.hip", ["-ffp-contract=off"]),

@@ -1417,7 +1417,6 @@ static int launch_f16x3_t(const ConvArgs* as, int n, hipStream_t s) {
 
 int conv_f16x3_init_attributes() {
   (void)knobs();
-  if (conv_f16x3_wx_init_attributes()) return -1;
 #define SHF_LDS_ATTR(K) SHF_HIP_OK(hipFuncSetAttribute((const void*)(K), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   SHF_LDS_ATTR((conv_mfma_f16x3_kernel<128, false, 1, 3>))
   SHF_LDS_ATTR((conv_mfma_f16x3_kernel<128, false, 1, 1>))
@@ -1443,7 +1442,6 @@ int launch_conv_f16x3_group(const ConvArgs* as, int n, hipStream_t s) {
   for (int i = 0; i < n; ++i)
     if ((as[i].in.cstride % 4) || (as[i].in.coff % 4)) { set_error("conv: input view not 16-byte aligned"); return -1; }
   if (!as[0].wsplit16) { set_error("conv f16x3: split weights not packed"); return -1; }
-  if (conv_f16x3_group_is_wx(as, n)) return launch_conv_f16x3_wx_group(as, n, s);
   if (as[0].img) {
     if (as[0].in.C != 64 || !as[0].w1t) { set_error("conv f16x3: fused first layer needs 64 channels + transposed weights"); return -1; }
     return launch_f16x3_t<64, true>(as, n, s);  // conv1_1 computed in place (BN=64 tile: Cout 64 or any multiple of 64)

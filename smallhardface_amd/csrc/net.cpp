@@ -87,9 +87,8 @@ struct HostBuf {
 struct ParamBlob {
   std::vector<int> shape;
   std::vector<float> host;
-  DevBuf raw, packed, packed16, packed16h, packedwx, first_t, first_frag;
+  DevBuf raw, packed, packed16, packed16h, first_t, first_frag;
   float wscale_inv = 1.f;  // packed16h: the power of two its weights were scaled by, inverted
-  float wscale_inv_wx = 1.f;  // packedwx (Winograd-x pack, SHF_F16X3_WX=1)
   bool dirty = true;
   bool split_stale = false;  // committed while the net was in fp32 mode: packed16 / packed16h hold OLDER weights
   size_t count() const {
@@ -138,7 +137,7 @@ struct Layer {
 };
 
 // the first 8 classes are the instantiations of conv_mfma_f32_kernel, named like rocprofv3 prints them
-enum ProfClass { PC_CONV_MFMA, PC_CONV_MFMA_1 = 1, PC_CONV_MFMA_7 = 7, PC_CONV_F16X3_128, PC_CONV_F16X3_W4, PC_CONV_F16X3_W4_SPLIT, PC_CONV_F16X3_W4_MT2, PC_CONV_F16X3_W4_SPLIT_MT2, PC_CONV_F16X3_64, PC_CONV_F16X3_64_FUSE1, PC_CONV_F16X3_64_D2, PC_CONV_F16X3_64_D4, PC_CONV_F16X3_128_K1, PC_CONV_F16X3_64_K1, PC_CONV_F16X3_PC, PC_CONV_F16X3_W4D_0, PC_CONV_F16X3_W4D_7 = PC_CONV_F16X3_W4D_0 + 7, PC_CONV_F16X3_WX, PC_CONV_F16X3_WX_SPLIT, PC_CONV_FIRST, PC_CONV_DIRECT, PC_POOL, PC_DECONV, PC_TAIL, PC_MERGE, PC_LAYOUT, PC_COUNT };
+enum ProfClass { PC_CONV_MFMA, PC_CONV_MFMA_1 = 1, PC_CONV_MFMA_7 = 7, PC_CONV_F16X3_128, PC_CONV_F16X3_W4, PC_CONV_F16X3_W4_SPLIT, PC_CONV_F16X3_W4_MT2, PC_CONV_F16X3_W4_SPLIT_MT2, PC_CONV_F16X3_64, PC_CONV_F16X3_64_FUSE1, PC_CONV_F16X3_64_D2, PC_CONV_F16X3_64_D4, PC_CONV_F16X3_128_K1, PC_CONV_F16X3_64_K1, PC_CONV_F16X3_PC, PC_CONV_F16X3_W4D_0, PC_CONV_F16X3_W4D_7 = PC_CONV_F16X3_W4D_0 + 7, PC_CONV_FIRST, PC_CONV_DIRECT, PC_POOL, PC_DECONV, PC_TAIL, PC_MERGE, PC_LAYOUT, PC_COUNT };
 static const char* kProfNames[PC_COUNT] = {"conv_mfma_f32_kernel<3, 1, 128, 8, 16>", "conv_mfma_f32_kernel<3, 2, 128, 8, 16>",
                                            "conv_mfma_f32_kernel<3, 4, 128, 8, 16>", "conv_mfma_f32_kernel<3, 1, 64, 16, 16>",
                                            "conv_mfma_f32_kernel<3, 2, 64, 16, 16>", "conv_mfma_f32_kernel<3, 4, 64, 16, 16>",
@@ -155,8 +154,6 @@ static const char* kProfNames[PC_COUNT] = {"conv_mfma_f32_kernel<3, 1, 128, 8, 1
                                            "conv_mfma_f16x3_w4d_kernel<false, 2, 2, 3>", "conv_mfma_f16x3_w4d_kernel<false, 2, 1, 3>",
                                            "conv_mfma_f16x3_w4d_kernel<true, 4, 2, 3>", "conv_mfma_f16x3_w4d_kernel<true, 4, 1, 3>",
                                            "conv_mfma_f16x3_w4d_kernel<true, 2, 2, 3>", "conv_mfma_f16x3_w4d_kernel<true, 2, 1, 3>",
-                                           // Winograd-x kernel (sub_hook variants 8 / 9)
-                                           "conv_mfma_f16x3_wx_kernel<false, 3>", "conv_mfma_f16x3_wx_kernel<true, 3>",
                                            "conv_first_kernel", "conv_direct_kernel", "maxpool_kernel",
                                            "deconv_depthwise", "detect_tail", "box_merge", "layout"};
 
@@ -1103,12 +1100,6 @@ void shf_net::commit_params(int li) {
           p.packed16h.ensure(sh.size() * 2);
           HIP_THROW(hipMemcpy(p.packed16h.p, sh.data(), sh.size() * 2, hipMemcpyHostToDevice));
         }
-        if (conv_f16x3_wx_enabled() && conv_f16x3_wx_shape_ok(p.shape[1], p.shape[0], L.k, L.pad, L.dil)) {
-          std::vector<uint16_t> sw(wx_conv_weight_halfs(p.shape[0], p.shape[1]));
-          p.wscale_inv_wx = pack_conv_weights_wx16h(p.host.data(), p.shape[0], p.shape[1], sw.data());
-          p.packedwx.ensure(sw.size() * 2);
-          HIP_THROW(hipMemcpy(p.packedwx.p, sw.data(), sw.size() * 2, hipMemcpyHostToDevice));
-        }
       }
     }
     p.dirty = false;
@@ -1188,8 +1179,6 @@ void shf_net::forward_ops(bool fused_path, float im_h, float im_w, float im_scal
         a.wsplit16 = split16 ? L.params[0]->packed16.p : nullptr;
         a.wsplit16h = split16 ? L.params[0]->packed16h.p : nullptr;
         a.wscale_inv = L.params[0]->wscale_inv;
-        a.wsplitwx = split16 && conv_f16x3_wx_shape_ok(ib.shape[1], L.nout, L.k, L.pad, L.dil) ? L.params[0]->packedwx.p : nullptr;
-        a.wscale_inv_wx = L.params[0]->wscale_inv_wx;
         if (fused_path && L.fuse_pool >= 0) {
           a.pool = view_of(layers[L.fuse_pool].tops[0]);
           a.write_main = L.pool_only ? 0 : 1;
@@ -1231,7 +1220,7 @@ void shf_net::forward_ops(bool fused_path, float im_h, float im_w, float im_scal
           if (L.kclass == 0 && collect) {
             *collect = a;  // grouped launch: the caller batches this layer over several units
           } else if (L.kclass == 0 && split16) {
-            if (conv_f16x3_group_is_dual(&a, 1) || conv_f16x3_group_is_wx(&a, 1)) {
+            if (conv_f16x3_group_is_dual(&a, 1)) {
               SubProf sp{&pf, st, fl, by, {}};
               a.sub_hook = &SubProf::hook;
               a.sub_ctx = &sp;
@@ -1817,7 +1806,7 @@ int shf_detect_add_levels(shf_net* net, int n, shf_net** members, const float* c
           fl += conv_flops(F, mb->blobs[F.bottoms[0]].shape, mb->blobs[F.tops[0]].shape);
         }
       }
-      if (conv_f16x3_group_is_dual(group.data(), n) || conv_f16x3_group_is_wx(group.data(), n)) {
+      if (conv_f16x3_group_is_dual(group.data(), n)) {
         SubProf sp{&net->prof, st, fl, by, {}};
         group[0].sub_hook = &SubProf::hook;
         group[0].sub_ctx = &sp;

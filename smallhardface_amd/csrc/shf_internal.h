@@ -33,8 +33,6 @@ struct ConvArgs {
   const void* wsplit16 = nullptr;  // split-fp16 pack [Cin/32][tap][Cout][hi32|lo32] (conv_f16x3.hip)
   const void* wsplit16h = nullptr; // dual-tile 4-wave kernel: [Cin/16][tap][Cout][hi16|lo16], lo UNSCALED, weights x 1/wscale_inv
   float wscale_inv = 1.f;          // ... and the power of two the epilogue multiplies back
-  const void* wsplitwx = nullptr;  // Winograd-x kernel (conv_f16x3_wx.hip): [Cin/16][ky][position][Cout][hi16|lo16] of the
-  float wscale_inv_wx = 1.f;       // transformed weights, unscaled low parts, and its power of two; null = not this kernel
   const float* bias = nullptr;     // [Cout] or null
   int k = 3, dil = 1, pad = 1;
   int relu = 0;
@@ -82,14 +80,6 @@ size_t split16_conv_weight_halfs(int Cout, int Cin, int k);
 size_t split16h_conv_weight_halfs(int Cout, int Cin, int k);
 float pack_conv_weights_split16h(const float* w, int Cout, int Cin, int k, void* dst);  // returns 1 / scale
 bool conv_f16x3_group_is_dual(const ConvArgs* as, int n);
-// Winograd F(2,3) along x on the same arithmetic (conv_f16x3_wx.hip; SHF_F16X3_WX=1)
-bool conv_f16x3_wx_enabled();
-bool conv_f16x3_wx_shape_ok(int Cin, int Cout, int k, int pad, int dil);
-bool conv_f16x3_group_is_wx(const ConvArgs* as, int n);
-size_t wx_conv_weight_halfs(int Cout, int Cin);
-float pack_conv_weights_wx16h(const float* w, int Cout, int Cin, void* dst);   // returns 1 / scale
-int conv_f16x3_wx_init_attributes();
-int launch_conv_f16x3_wx_group(const ConvArgs* as, int n, hipStream_t s);
 void pack_conv_weights_split16(const float* w, int Cout, int Cin, int k, void* dst);
 // first layer (64, 27) as the B operand of v_mfma_f32_32x32x16_f16: [n 2][kk 2][hi/lo 2][lane 64][8 halfs], K padded 27 -> 32
 constexpr size_t kFirstConvFragHalfs = 2 * 2 * 2 * 64 * 8;
