@@ -91,7 +91,11 @@ int shf_net_get_conv_mode(shf_net* net);
  * fp16 products, at 2/3 and 1/3 of the matrix-core work; their score drift against the fp32 reference is measured,
  * not assumed (tools/precision_ladder.py -> profiles/).  shf_net_set_layer_products overrides the count for ONE
  * layer by name (1..3; 0 clears), so a mode can be relaxed only where the measured contribution to the score error is
- * negligible.  Shared by a net and its lanes.  Kernels without a reduced instantiation keep three products. */
+ * negligible.  Shared by a net and its lanes.  Every split-fp16 kernel (4-wave family, 8-wave, fused first pair) has
+ * the 2- and 1-product instantiations; the fused pair's conv1_1 (0.5 % of the FLOPs) always forms three.
+ * Mode 4 = bf16: ONE v_mfma_f32_32x32x16_bf16 product per fp32 product, operands rounded to bf16 (8 mantissa bits), fp32
+ * accumulate, fp32 activations in HBM.  bf16 has fp32's exponent range: no range guard, no weight refusal.  Like modes 2
+ * and 3 it is a drift-labelled throughput mode, not a parity mode (bench.py reports its drift beside the headline). */
 int shf_net_set_layer_products(shf_net* net, const char* layer, int nprod);
 /* fp16 range guard of mode 1 (the reference is fp32 everywhere, caffe/python/caffe/_caffe.cpp:46-48): hi = fp16(x)
  * overflows above 65504.  Weights are checked when they are packed (shf_net_param_commit / shf_net_set_conv_mode

@@ -39,7 +39,7 @@ def set_device(device_id):
 
 # arithmetic of the MFMA convolutions (C ABI shf_net_set_conv_mode): exact fp32; split-fp16 with three products
 # (fp32-class: the mode every parity test runs); the reduced ladder with two / one product (drift-labelled)
-CONV_MODES = {"fp32": 0, "f16x3": 1, "f16x2": 2, "f16": 3, 0: 0, 1: 1, 2: 2, 3: 3}
+CONV_MODES = {"fp32": 0, "f16x3": 1, "f16x2": 2, "f16": 3, "bf16": 4, 0: 0, 1: 1, 2: 2, 3: 3, 4: 4}
 
 
 class Layer(object):
@@ -174,14 +174,16 @@ class Net(object):
                                                       float(min_size)), "set_proposal_cfg")
 
     def set_conv_mode(self, mode):
-        """"fp32" (exact fp32 MFMA) or "f16x3" (split-fp16 MFMA, fp32-class accuracy) for the 3x3 convs."""
+        """Arithmetic of the MFMA convolutions: "fp32" (exact fp32 MFMA), "f16x3" (split-fp16, three fp16 products per
+        fp32 product: fp32-class accuracy, the parity mode), and the reduced, drift-labelled modes "f16x2", "f16" (two /
+        one fp16 product; fp16 range guard applies) and "bf16" (one bf16 product; fp32's exponent range, no guard)."""
         m = CONV_MODES[mode]
         self.commit_params()
         _lib.check(self._lib.shf_net_set_conv_mode(self._h, m), "set_conv_mode")
 
     @property
     def conv_mode(self):
-        return {0: "fp32", 1: "f16x3", 2: "f16x2", 3: "f16"}[int(self._lib.shf_net_get_conv_mode(self._h))]
+        return {0: "fp32", 1: "f16x3", 2: "f16x2", 3: "f16", 4: "bf16"}[int(self._lib.shf_net_get_conv_mode(self._h))]
 
     def set_layer_products(self, table):
         """{layer name: 1 | 2 | 3 (0 clears)}: fp16 products per fp32 product for single layers of a split-fp16 mode

@@ -56,6 +56,26 @@ constexpr int TH = 16, TW = 16, HTW = TW + 2, HTH = TH + 2, HP = HTH * HTW;
 constexpr float LO_SCALE = 2048.0f, LO_INV = 1.0f / 2048.0f;
 }  // namespace f16x3
 
+// bf16 mode (BF = true kernels; conv mode "bf16"): ONE product per fp32 product on v_mfma_f32_32x32x16_bf16, operands
+// rounded to bf16 (8 mantissa bits, fp32's exponent range: no fp16 range guard, no activation exponent).  The 16-bit
+// "hi" halves of the LDS rows / weight packs then hold bf16 bit patterns and the "lo" halves are never read.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+template <bool BF>
+__device__ __forceinline__ f32x16 mma16(const half8 a, const half8 b, const f32x16 c) {
+  if constexpr (BF)
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ _Float16 bf16_as_half(float x) { return __builtin_bit_cast(_Float16, (__bf16)x); }
+// four floats -> four bf16 bit patterns in a half4
+__device__ __forceinline__ void bf16x4_of(const float4 v, _Float16 (&h)[4]) {
+  const bf16x2v a = __builtin_convertvector((f32x2){v.x, v.y}, bf16x2v), b = __builtin_convertvector((f32x2){v.z, v.w}, bf16x2v);
+  h[0] = __builtin_bit_cast(_Float16, a[0]); h[1] = __builtin_bit_cast(_Float16, a[1]);
+  h[2] = __builtin_bit_cast(_Float16, b[0]); h[3] = __builtin_bit_cast(_Float16, b[1]);
+}
+
 // x -> (hi, lo) for four values, two per instruction: v_cvt_pk_f16_f32 for both halves, packed fp32
 // subtract / scale in between (3 VALU ops per value instead of 6; same results as the scalar form)
 typedef _Float16 half2v __attribute__((ext_vector_type(2)));
@@ -68,6 +88,17 @@ __device__ __forceinline__ void split4(const float4 v, half4& hi, half4& lo) {
   hi = half4{h01[0], h01[1], h23[0], h23[1]};
   lo = half4{l01[0], l01[1], l23[0], l23[1]};
 }
+template <bool BF>
+__device__ __forceinline__ void split4t(const float4 v, half4& hi, half4& lo) {
+  if constexpr (BF) {
+    _Float16 h[4];
+    bf16x4_of(v, h);
+    hi = half4{h[0], h[1], h[2], h[3]};
+    lo = half4{(_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0};
+  } else {
+    split4(v, hi, lo);
+  }
+}
 
 // BN = 128: waves 4(M) x 2(N), each 64 px x 64 couts (MT = 2 M-tiles); BN = 64: waves 8 x 1, each 32 px x 64 couts.
 // FUSE1: the input of this layer is the first conv of the net (3x3, pad 1, Cin <= 3, + ReLU) applied
@@ -75,8 +106,10 @@ __device__ __forceinline__ void split4(const float4 v, half4& hi, half4& lo) {
 // in place from a 20x20x3 image patch staged in LDS (one thread per halo pixel, 27 x 32 FMAs per
 // chunk, under the MFMAs of the previous chunk).  conv1_1 never touches HBM: -1.8 GB written and
 // read per image on the bench pyramid.
-template <int BN, bool FUSE1, int DIL, int KS>
+// NP: fp16 products per fp32 product -- 3 (fp32-class), 2 (a_lo * b_hi dropped: activations act as fp16) or 1 (hi * hi).
+template <int BN, bool FUSE1, int DIL, int KS, int NP = 3, bool BF = false>
 __global__ __launch_bounds__(512) void conv_mfma_f16x3_kernel(ConvK p) {
+  static_assert(!BF || NP == 1, "bf16 mode is a one-product mode");
   using namespace f16x3;
   // halo tile for dilation DIL (the dilated heads: 2 and 4, BN = 64 only -- a 24x24 tile plus 128-cout weight
   // buffers would not fit the 160 KiB of LDS)
@@ -212,7 +245,7 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_kernel(ConvK p) {
       float4 v4 = make_float4(fmaxf(acc[4 * q], 0.f), fmaxf(acc[4 * q + 1], 0.f), fmaxf(acc[4 * q + 2], 0.f),
                               fmaxf(acc[4 * q + 3], 0.f));
       if (!f_inside) v4 = make_float4(0.f, 0.f, 0.f, 0.f);
-      split4(v4, fhi[q], flo[q]);
+      split4t<BF>(v4, fhi[q], flo[q]);
     }
   };
   auto first_store = [&]() {
@@ -258,7 +291,7 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_kernel(ConvK p) {
     for (int j = 0; j < ALD; ++j)
       if (a_loff[j] >= 0) {
         half4 hi, lo;
-        split4(areg0[j], hi, lo);
+        split4t<BF>(areg0[j], hi, lo);
         *(half4*)(As + a_loff[j]) = hi;
         *(half4*)(As + a_loff[j] + 64) = lo;
       }
@@ -322,26 +355,26 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_kernel(ConvK p) {
           for (int tm = 0; tm < MT; ++tm)
   #pragma unroll
             for (int tn = 0; tn < 2; ++tn)
-              accm[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tm], bh[tn], accm[tm][tn], 0, 0, 0);
+              accm[tm][tn] = mma16<BF>(ah[tm], bh[tn], accm[tm][tn]);
   #pragma unroll
           for (int tm = 0; tm < MT; ++tm)
   #pragma unroll
             for (int tn = 0; tn < 2; ++tn)
-              accc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tm], bl[tn], accc[tm][tn], 0, 0, 0);
+              if constexpr (NP >= 2) accc[tm][tn] = mma16<BF>(ah[tm], bl[tn], accc[tm][tn]);
   #pragma unroll
           for (int tm = 0; tm < MT; ++tm)
   #pragma unroll
             for (int tn = 0; tn < 2; ++tn)
-              accc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[tm], bh[tn], accc[tm][tn], 0, 0, 0);
+              if constexpr (NP >= 3) accc[tm][tn] = mma16<BF>(al[tm], bh[tn], accc[tm][tn]);
         } else {
           // with 4 output tiles per wave hipcc's own interleave of the tile-major order measured faster
 #pragma unroll
           for (int tm = 0; tm < MT; ++tm)
 #pragma unroll
             for (int tn = 0; tn < 2; ++tn) {
-              accm[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tm], bh[tn], accm[tm][tn], 0, 0, 0);
-              accc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tm], bl[tn], accc[tm][tn], 0, 0, 0);
-              accc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[tm], bh[tn], accc[tm][tn], 0, 0, 0);
+              accm[tm][tn] = mma16<BF>(ah[tm], bh[tn], accm[tm][tn]);
+              if constexpr (NP >= 2) accc[tm][tn] = mma16<BF>(ah[tm], bl[tn], accc[tm][tn]);
+              if constexpr (NP >= 3) accc[tm][tn] = mma16<BF>(al[tm], bh[tn], accc[tm][tn]);
             }
         }
       }
@@ -351,7 +384,7 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_kernel(ConvK p) {
           if (f_own) first_conv(c + 1);
         } else {
 #pragma unroll
-          for (int j = 0; j < ALD; ++j) split4(areg[j], ahi[j], alo[j]);
+          for (int j = 0; j < ALD; ++j) split4t<BF>(areg[j], ahi[j], alo[j]);
         }
       }
     }
@@ -375,7 +408,7 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_kernel(ConvK p) {
 #pragma unroll
         for (int j = 0; j < ALD; ++j)
           if (a_loff[j] >= 0) {
-            if (!F16X3_CONV_MID) split4(areg[j], ahi[j], alo[j]);
+            if (!F16X3_CONV_MID) split4t<BF>(areg[j], ahi[j], alo[j]);
             *(half4*)(As + a_loff[j]) = ahi[j];
             *(half4*)(As + a_loff[j] + 64) = alo[j];
           }
@@ -455,8 +488,9 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_kernel(ConvK p) {
 // fragment on the other half of the banks).  The six half-steps of a stage (tap kx, tile t) are software-pipelined
 // like the six k-steps of the single-tile kernel: while (kx, t) runs, the A fragments of the next (kx, t) -- and, on
 // even half-steps, the B fragments of tap kx + 1 -- are read.
-template <bool IN_SPLIT, int MT_, int NTILE, int NP = 3>
+template <bool IN_SPLIT, int MT_, int NTILE, int NP = 3, bool BF = false>
 __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4d_kernel(ConvK p) {
+  static_assert(!BF || (NP == 1 && !IN_SPLIT), "bf16 mode: one product, fp32 activations in HBM");
   static_assert((MT_ == 4 || MT_ == 2) && (NTILE == 1 || NTILE == 2), "16- or 8-row tiles, one or two per block");
   constexpr int MT = MT_, TH = 4 * MT, TW = 16, HTW = 18, HTH = TH + 2, HP = HTH * HTW;
   constexpr int KC = 16, ROWB = 80, ROWPAD = 224, BN = 128, NT = 256;
@@ -566,6 +600,11 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4d_kernel(ConvK p) {
         x = (x * f1) * sc.f2;
         e[k] = __builtin_bit_cast(float, x);
       }
+    } else if constexpr (BF) {
+      _Float16 h[4];
+      bf16x4_of(v, h);   // (no activation exponent: bf16 has fp32's range; the weights' pack is unscaled)
+      const half2v h01 = {h[0], h[1]}, h23 = {h[2], h[3]};
+      v = make_float4(__builtin_bit_cast(float, h01), __builtin_bit_cast(float, h23), 0.f, 0.f);
     } else {
       const f32x2 x01 = {v.x, v.y}, x23 = {v.z, v.w};
       // (lo through the split activation format's 2^11, like a producer's epilogue + the staging above would: the two
@@ -713,20 +752,20 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4d_kernel(ConvK p) {
         for (int tm = 0; tm < MT; ++tm)
 #pragma unroll
           for (int tn = 0; tn < 2; ++tn)
-            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[2 * tn], a[2 * tm], acc[tm][tn], 0, 0, 0);
+            acc[tm][tn] = mma16<BF>(bf[2 * tn], a[2 * tm], acc[tm][tn]);
         if constexpr (NP >= 2) {
 #pragma unroll
           for (int tm = 0; tm < MT; ++tm)
 #pragma unroll
             for (int tn = 0; tn < 2; ++tn)
-              acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[2 * tn + 1], a[2 * tm], acc[tm][tn], 0, 0, 0);
+              acc[tm][tn] = mma16<BF>(bf[2 * tn + 1], a[2 * tm], acc[tm][tn]);
         }
         if constexpr (NP >= 3) {
 #pragma unroll
           for (int tm = 0; tm < MT; ++tm)
 #pragma unroll
             for (int tn = 0; tn < 2; ++tn)
-              acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[2 * tn], a[2 * tm + 1], acc[tm][tn], 0, 0, 0);
+              acc[tm][tn] = mma16<BF>(bf[2 * tn], a[2 * tm + 1], acc[tm][tn]);
         }
       };
       if (tl) mfmas(acc1);
@@ -831,8 +870,10 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4d_kernel(ConvK p) {
 //  * waves 0-3 are CONSUMERS (one per SIMD): 64 px x 64 couts = 4 accumulator tiles each, 8 fragment reads
 //    per 12 MFMAs, the six k-steps of a stage software-pipelined like the 4-wave kernel (~2.6 k cycles per
 //    stage against 2.3 k of pure MFMA issue).  Waves 4-7 are PRODUCERS: they issue every weight DMA.
+template <int NP, bool BF = false>
 __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
   using namespace f16x3;
+  static_assert(!BF || NP == 1, "bf16 mode is a one-product mode");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 #ifdef SHF_CONV_TIMING
   unsigned long long tt[14];
@@ -943,9 +984,9 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
           const int o1 = k1 < 27 ? ((k1 / 9) * PH + (k1 % 9) / 3) * PW + k1 % 3 : 0;
           float x = pb[kh1 ? o1 : o0];
           if (k1 >= 27 && kh1) x = 0.f;
-          const _Float16 h = (_Float16)x;
+          const _Float16 h = BF ? bf16_as_half(x) : (_Float16)x;
           ah[kk][j] = h;
-          al[kk][j] = (_Float16)((x - (float)h) * LO_SCALE);
+          al[kk][j] = BF ? (_Float16)0 : (_Float16)((x - (float)h) * LO_SCALE);
         }
 #pragma unroll
       for (int n = 0; n < 2; ++n) {
@@ -955,11 +996,13 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
         for (int r = 0; r < 16; ++r) { cm[r] = 0.f; cc[r] = 0.f; }
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-          cm = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[kk], bw[n][kk][0], cm, 0, 0, 0);
-          cc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[kk], bw[n][kk][1], cc, 0, 0, 0);
+          cm = mma16<BF>(ah[kk], bw[n][kk][0], cm);
+          if constexpr (!BF) cc = mma16<BF>(ah[kk], bw[n][kk][1], cc);
         }
+        if constexpr (!BF) {
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) cc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[kk], bw[n][kk][0], cc, 0, 0, 0);
+          for (int kk = 0; kk < 2; ++kk) cc = mma16<BF>(al[kk], bw[n][kk][0], cc);
+        }
         // C row (pixel) = (r & 3) + 8 (r >> 2) + 4 kh, C column (cout) = lane & 31
         const float bias = n ? bias1 : bias0;
         unsigned char* At = (n ? As1 : As0) + i1 * 2;
@@ -973,9 +1016,9 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
           const float pre = cm[r] + cc[r] * LO_INV + bias;
           const float v = ok[r] ? fmaxf(pre, 0.f) : 0.f;
           amax1 = fmaxf(amax1, pre != pre ? __builtin_inff() : v);  // (fmaxf would swallow a NaN)
-          const _Float16 h = (_Float16)v;
+          const _Float16 h = BF ? bf16_as_half(v) : (_Float16)v;
           *(_Float16*)(At + hq * ROWB) = h;
-          *(_Float16*)(At + hq * ROWB + 64) = (_Float16)((v - (float)h) * LO_SCALE);
+          if constexpr (!BF) *(_Float16*)(At + hq * ROWB + 64) = (_Float16)((v - (float)h) * LO_SCALE);
         }
       }
     };
@@ -1030,17 +1073,21 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
       for (int tm = 0; tm < MT; ++tm)
 #pragma unroll
         for (int tn = 0; tn < 2; ++tn)
-          accm[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[2 * tm], bf[2 * tn], accm[tm][tn], 0, 0, 0);
+          accm[tm][tn] = mma16<BF>(a[2 * tm], bf[2 * tn], accm[tm][tn]);
+      if constexpr (NP >= 2) {
 #pragma unroll
-      for (int tm = 0; tm < MT; ++tm)
+        for (int tm = 0; tm < MT; ++tm)
 #pragma unroll
-        for (int tn = 0; tn < 2; ++tn)
-          accc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[2 * tm], bf[2 * tn + 1], accc[tm][tn], 0, 0, 0);
+          for (int tn = 0; tn < 2; ++tn)
+            accc[tm][tn] = mma16<BF>(a[2 * tm], bf[2 * tn + 1], accc[tm][tn]);
+      }
+      if constexpr (NP >= 3) {
 #pragma unroll
-      for (int tm = 0; tm < MT; ++tm)
+        for (int tm = 0; tm < MT; ++tm)
 #pragma unroll
-        for (int tn = 0; tn < 2; ++tn)
-          accc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[2 * tm + 1], bf[2 * tn], accc[tm][tn], 0, 0, 0);
+          for (int tn = 0; tn < 2; ++tn)
+            accc[tm][tn] = mma16<BF>(a[2 * tm + 1], bf[2 * tn], accc[tm][tn]);
+      }
       if (s_ + 1 < 6) {
 #pragma unroll
         for (int g = 0; g < 8; ++g) {
@@ -1103,8 +1150,21 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
 // ---------------------------------------------------------------------------
 size_t split16_conv_weight_halfs(int Cout, int Cin, int k) { return (size_t)Cout * (Cin / 32) * k * k * 72; }
 
+// host-side round-to-nearest-even fp32 -> bf16, returned as the fp16-typed bit pattern the packs store
+static _Float16 host_bf16_as_half(float x) {
+  uint32_t u;
+  memcpy(&u, &x, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) u |= 0x00400000u;                 // NaN stays a NaN
+  else u += 0x7fffu + ((u >> 16) & 1u);
+  const uint16_t b = (uint16_t)(u >> 16);
+  _Float16 h;
+  memcpy(&h, &b, 2);
+  return h;
+}
+
 // (Cout,Cin,3,3) fp32 -> [Cin/32][ky][kx][Cout][hi 32 | lo 32 | 8 pad] fp16 (144-B rows = the LDS image)
-void pack_conv_weights_split16(const float* w, int Cout, int Cin, int k, void* dst_) {
+// bf: the bf16 mode's pack -- hi = bf16(w) bit patterns, lo = 0
+void pack_conv_weights_split16(const float* w, int Cout, int Cin, int k, void* dst_, bool bf) {
   _Float16* dst = (_Float16*)dst_;
   const int taps = k * k;
   memset(dst_, 0, split16_conv_weight_halfs(Cout, Cin, k) * 2);
@@ -1112,8 +1172,8 @@ void pack_conv_weights_split16(const float* w, int Cout, int Cin, int k, void* d
     for (int ci = 0; ci < Cin; ++ci)
       for (int t = 0; t < taps; ++t) {
         const float x = w[((size_t)co * Cin + ci) * taps + t];
-        const _Float16 h = (_Float16)x;
-        const _Float16 l = (_Float16)((x - (float)h) * f16x3::LO_SCALE);
+        const _Float16 h = bf ? host_bf16_as_half(x) : (_Float16)x;
+        const _Float16 l = bf ? (_Float16)0 : (_Float16)((x - (float)h) * f16x3::LO_SCALE);
         const size_t row = (((size_t)(ci / 32) * taps + t) * Cout + co) * 72;
         dst[row + (ci % 32)] = h;
         dst[row + 32 + (ci % 32)] = l;
@@ -1129,7 +1189,7 @@ size_t split16h_conv_weight_halfs(int Cout, int Cin, int k) { return (size_t)Cou
 // lo is NOT scaled here: lo = fp16(w s - hi) with one power of two s per layer that lifts the weights to [8, 16) at the top,
 // so that the low parts of all but the tiniest weights are normal fp16 numbers (the MFMA honours subnormals anyway:
 // tools/mfma_denorm.hip) and the three products share one accumulator.  Returns 1 / s for the epilogue.
-float pack_conv_weights_split16h(const float* w, int Cout, int Cin, int k, void* dst_) {
+float pack_conv_weights_split16h(const float* w, int Cout, int Cin, int k, void* dst_, bool bf) {
   _Float16* dst = (_Float16*)dst_;
   const int taps = k * k;
   float amax = 0.f;
@@ -1137,14 +1197,15 @@ float pack_conv_weights_split16h(const float* w, int Cout, int Cin, int k, void*
   int e = 0;
   if (amax > 0.f) e = (int)std::floor(std::log2(8.0 / (double)amax));
   e = std::max(-14, std::min(14, e));
+  if (bf) e = 0;   // bf16 has fp32's exponent range: nothing to lift
   const float s = std::ldexp(1.0f, e);
   memset(dst_, 0, split16h_conv_weight_halfs(Cout, Cin, k) * 2);
   for (int co = 0; co < Cout; ++co)
     for (int ci = 0; ci < Cin; ++ci)
       for (int t = 0; t < taps; ++t) {
         const float x = w[((size_t)co * Cin + ci) * taps + t] * s;
-        const _Float16 h = (_Float16)x;
-        const _Float16 l = (_Float16)(x - (float)h);
+        const _Float16 h = bf ? host_bf16_as_half(x) : (_Float16)x;
+        const _Float16 l = bf ? (_Float16)0 : (_Float16)(x - (float)h);
         const size_t row = (((size_t)(ci / 16) * taps + t) * Cout + co) * 32;
         const int kk = ci % 16, rot = ((co & 127) >> 2) & 3;
         dst[row + (((kk >> 3) + rot) & 3) * 8 + (kk & 7)] = h;
@@ -1206,7 +1267,7 @@ bool conv_f16x3_group_is_dual(const ConvArgs* as, int n) {
   return true;
 }
 
-void pack_first_conv_frags(const float* w, void* dst_) {
+void pack_first_conv_frags(const float* w, void* dst_, bool bf) {
   _Float16* dst = (_Float16*)dst_;
   for (int n = 0; n < 2; ++n)
     for (int kk = 0; kk < 2; ++kk)
@@ -1214,8 +1275,8 @@ void pack_first_conv_frags(const float* w, void* dst_) {
         for (int j = 0; j < 8; ++j) {
           const int i = lane & 31, kh = lane >> 5, k = kk * 16 + kh * 8 + j;
           const float x = k < 27 ? w[(size_t)(n * 32 + i) * 27 + k] : 0.f;
-          const _Float16 h = (_Float16)x;
-          const _Float16 l = (_Float16)((x - (float)h) * f16x3::LO_SCALE);
+          const _Float16 h = bf ? host_bf16_as_half(x) : (_Float16)x;
+          const _Float16 l = bf ? (_Float16)0 : (_Float16)((x - (float)h) * f16x3::LO_SCALE);
           dst[(((size_t)(n * 2 + kk) * 2 + 0) * 64 + lane) * 8 + j] = h;
           dst[(((size_t)(n * 2 + kk) * 2 + 1) * 64 + lane) * 8 + j] = l;
         }
@@ -1338,7 +1399,10 @@ static int launch_f16x3_t(const ConvArgs* as, int n, hipStream_t s) {
     // two halo tiles (both channel chunks of conv1_1's output) + the weight double buffer + the image patch
     constexpr size_t HPP = (HP + 31) / 32 * 32;
     const size_t lds_pc = 2 * HPP * ROWB + 2 * 3 * (size_t)BN * ROWB + 3 * (TH + 4) * (TW + 4) * sizeof(float) + HPP;
-    hipLaunchKernelGGL(conv_mfma_f16x3_pc_kernel, dim3((unsigned)tiles), dim3(512), lds_pc, s, p);
+    if (a.bf16) hipLaunchKernelGGL((conv_mfma_f16x3_pc_kernel<1, true>), dim3((unsigned)tiles), dim3(512), lds_pc, s, p);
+    else if (a.nprod >= 3) hipLaunchKernelGGL(conv_mfma_f16x3_pc_kernel<3>, dim3((unsigned)tiles), dim3(512), lds_pc, s, p);
+    else if (a.nprod == 2) hipLaunchKernelGGL(conv_mfma_f16x3_pc_kernel<2>, dim3((unsigned)tiles), dim3(512), lds_pc, s, p);
+    else hipLaunchKernelGGL(conv_mfma_f16x3_pc_kernel<1>, dim3((unsigned)tiles), dim3(512), lds_pc, s, p);
   } else if (dual) {
     // dual-tile family (conv_mfma_f16x3_w4d_kernel<.., MT, NTILE, ..>): every variant forms an output with the same
     // operations in the same order, so the choice below -- two tiles per block where that fills whole rounds of one
@@ -1363,7 +1427,8 @@ static int launch_f16x3_t(const ConvArgs* as, int n, hipStream_t s) {
     const size_t lds1 = as_b + 2 * 3 * (size_t)BN * 64 + BN * sizeof(float), lds2 = lds1 + as_b;
 #define SHF_W4D_LAUNCH(SPLIT, MTV, NTV, GRID, LDS)                                                                        \
     {                                                                                                                    \
-      if (a.nprod >= 3) hipLaunchKernelGGL((conv_mfma_f16x3_w4d_kernel<SPLIT, MTV, NTV, 3>), GRID, dim3(256), LDS, s, p);    \
+      if (a.bf16) hipLaunchKernelGGL((conv_mfma_f16x3_w4d_kernel<false, MTV, NTV, 1, true>), GRID, dim3(256), LDS, s, p);  \
+      else if (a.nprod >= 3) hipLaunchKernelGGL((conv_mfma_f16x3_w4d_kernel<SPLIT, MTV, NTV, 3>), GRID, dim3(256), LDS, s, p);    \
       else if (a.nprod == 2) hipLaunchKernelGGL((conv_mfma_f16x3_w4d_kernel<SPLIT, MTV, NTV, 2>), GRID, dim3(256), LDS, s, p); \
       else hipLaunchKernelGGL((conv_mfma_f16x3_w4d_kernel<SPLIT, MTV, NTV, 1>), GRID, dim3(256), LDS, s, p);                 \
     }
@@ -1397,7 +1462,12 @@ static int launch_f16x3_t(const ConvArgs* as, int n, hipStream_t s) {
     set_error("conv f16x3: split-format input reached a kernel other than the 4-wave family (unaligned views, or an input of 4 GiB or more)");
     return -1;
   } else {
-    hipLaunchKernelGGL((conv_mfma_f16x3_kernel<BN, FUSE1, DIL, KS>), dim3((unsigned)(tiles * p.nct)), dim3(512), lds, s, p);
+    const dim3 g8((unsigned)(tiles * p.nct));
+    if (a.bf16 && FUSE1) { set_error("conv f16x3: bf16 mode runs the first pair on the producer/consumer kernel only"); return -1; }
+    if (a.bf16) hipLaunchKernelGGL((conv_mfma_f16x3_kernel<BN, false, DIL, KS, 1, true>), g8, dim3(512), lds, s, p);
+    else if (FUSE1 || a.nprod >= 3) hipLaunchKernelGGL((conv_mfma_f16x3_kernel<BN, FUSE1, DIL, KS, 3>), g8, dim3(512), lds, s, p);
+    else if (a.nprod == 2) hipLaunchKernelGGL((conv_mfma_f16x3_kernel<BN, false, DIL, KS, 2>), g8, dim3(512), lds, s, p);
+    else hipLaunchKernelGGL((conv_mfma_f16x3_kernel<BN, false, DIL, KS, 1>), g8, dim3(512), lds, s, p);
   }
   SHF_HIP_OK(hipGetLastError());
 #ifdef SHF_CONV_TIMING
@@ -1418,14 +1488,18 @@ static int launch_f16x3_t(const ConvArgs* as, int n, hipStream_t s) {
 int conv_f16x3_init_attributes() {
   (void)knobs();
 #define SHF_LDS_ATTR(K) SHF_HIP_OK(hipFuncSetAttribute((const void*)(K), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  SHF_LDS_ATTR((conv_mfma_f16x3_kernel<128, false, 1, 3>))
-  SHF_LDS_ATTR((conv_mfma_f16x3_kernel<128, false, 1, 1>))
-  SHF_LDS_ATTR((conv_mfma_f16x3_kernel<64, false, 1, 1>))
-  SHF_LDS_ATTR((conv_mfma_f16x3_kernel<64, false, 2, 3>))
-  SHF_LDS_ATTR((conv_mfma_f16x3_kernel<64, false, 4, 3>))
-  SHF_LDS_ATTR((conv_mfma_f16x3_kernel<64, false, 1, 3>))
-  SHF_LDS_ATTR((conv_mfma_f16x3_kernel<64, true, 1, 3>))
-  SHF_LDS_ATTR(conv_mfma_f16x3_pc_kernel)
+#define SHF_8W_ATTR(BNV, DILV, KSV)                                       \
+  SHF_LDS_ATTR((conv_mfma_f16x3_kernel<BNV, false, DILV, KSV, 3>))         \
+  SHF_LDS_ATTR((conv_mfma_f16x3_kernel<BNV, false, DILV, KSV, 2>))         \
+  SHF_LDS_ATTR((conv_mfma_f16x3_kernel<BNV, false, DILV, KSV, 1>))         \
+  SHF_LDS_ATTR((conv_mfma_f16x3_kernel<BNV, false, DILV, KSV, 1, true>))
+  SHF_8W_ATTR(128, 1, 3) SHF_8W_ATTR(128, 1, 1) SHF_8W_ATTR(64, 1, 1) SHF_8W_ATTR(64, 2, 3) SHF_8W_ATTR(64, 4, 3) SHF_8W_ATTR(64, 1, 3)
+#undef SHF_8W_ATTR
+  SHF_LDS_ATTR((conv_mfma_f16x3_kernel<64, true, 1, 3, 3>))
+  SHF_LDS_ATTR(conv_mfma_f16x3_pc_kernel<3>)
+  SHF_LDS_ATTR(conv_mfma_f16x3_pc_kernel<2>)
+  SHF_LDS_ATTR(conv_mfma_f16x3_pc_kernel<1>)
+  SHF_LDS_ATTR((conv_mfma_f16x3_pc_kernel<1, true>))
 #define SHF_W4D_ATTR(SPLIT, MTV, NTV)                                      \
   SHF_LDS_ATTR((conv_mfma_f16x3_w4d_kernel<SPLIT, MTV, NTV, 3>))           \
   SHF_LDS_ATTR((conv_mfma_f16x3_w4d_kernel<SPLIT, MTV, NTV, 2>))           \
@@ -1433,6 +1507,8 @@ int conv_f16x3_init_attributes() {
   SHF_W4D_ATTR(false, 4, 2) SHF_W4D_ATTR(true, 4, 2) SHF_W4D_ATTR(false, 4, 1) SHF_W4D_ATTR(true, 4, 1)
   SHF_W4D_ATTR(false, 2, 2) SHF_W4D_ATTR(true, 2, 2) SHF_W4D_ATTR(false, 2, 1) SHF_W4D_ATTR(true, 2, 1)
 #undef SHF_W4D_ATTR
+  SHF_LDS_ATTR((conv_mfma_f16x3_w4d_kernel<false, 4, 2, 1, true>)) SHF_LDS_ATTR((conv_mfma_f16x3_w4d_kernel<false, 4, 1, 1, true>))
+  SHF_LDS_ATTR((conv_mfma_f16x3_w4d_kernel<false, 2, 2, 1, true>)) SHF_LDS_ATTR((conv_mfma_f16x3_w4d_kernel<false, 2, 1, 1, true>))
 #undef SHF_LDS_ATTR
   return 0;
 }

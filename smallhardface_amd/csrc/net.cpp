@@ -88,6 +88,8 @@ struct ParamBlob {
   std::vector<int> shape;
   std::vector<float> host;
   DevBuf raw, packed, packed16, packed16h, first_t, first_frag;
+  DevBuf packed16b, packed16hb, first_frag_b;   // the same three packs for conv mode "bf16" (built on first use of the mode)
+  bool bf_stale = true;                         // ... and whether they hold the current weights
   float wscale_inv = 1.f;  // packed16h: the power of two its weights were scaled by, inverted
   bool dirty = true;
   bool split_stale = false;  // committed while the net was in fp32 mode: packed16 / packed16h hold OLDER weights
@@ -476,12 +478,12 @@ struct shf_net {
   // single-accumulator split-fp16 kernels.  Concat members share their owner's slot.
   DevBuf amax_slots;
   unsigned* amax_slot(int bi) {
-    if (!amax_slots.p || conv_mode < 1) return nullptr;
+    if (!amax_slots.p || conv_mode < 1 || conv_mode == 4) return nullptr;
     const int o = blobs[bi].owner >= 0 ? blobs[bi].owner : bi;
     return (unsigned*)amax_slots.p + o;
   }
   void reset_amax(hipStream_t st) {
-    if (conv_mode >= 1 && amax_slots.p) HIP_THROW(hipMemsetAsync(amax_slots.p, 0, blobs.size() * 4, st));
+    if (conv_mode >= 1 && conv_mode != 4 && amax_slots.p) HIP_THROW(hipMemsetAsync(amax_slots.p, 0, blobs.size() * 4, st));
   }
   DevBuf range_flag;  // device int: raised by a split-fp16 conv epilogue that produced |x| > 65504 (fp16 hi overflows)
   TailWork tw;
@@ -1006,7 +1008,7 @@ void shf_net::ensure_tail_workspace(size_t total) {
   tw.rec = (float*)tw_rec.p;
   tw.keys = (unsigned long long*)tw_keys.p;
   tw.counters = (int*)tw_counters.p;
-  tw.amax = conv_mode >= 1 ? (unsigned*)amax_slots.p : nullptr;   // (the tail's reset kernel zeroes the slots for the next pass)
+  tw.amax = conv_mode >= 1 && conv_mode != 4 ? (unsigned*)amax_slots.p : nullptr;   // (the tail's reset kernel zeroes the slots for the next pass)
   tw.n_amax = (int)blobs.size();
   tw.cap_anchors = total;
   tw.cap_keys = npad;
@@ -1072,6 +1074,13 @@ void shf_net::commit_params(int li) {
         pack_first_conv_frags(p.host.data(), fr.data());
         p.first_frag.ensure(fr.size() * 2);
         HIP_THROW(hipMemcpy(p.first_frag.p, fr.data(), fr.size() * 2, hipMemcpyHostToDevice));
+        p.bf_stale = true;
+        if (conv_mode == 4) {
+          pack_first_conv_frags(p.host.data(), fr.data(), true);
+          p.first_frag_b.ensure(fr.size() * 2);
+          HIP_THROW(hipMemcpy(p.first_frag_b.p, fr.data(), fr.size() * 2, hipMemcpyHostToDevice));
+          p.bf_stale = false;
+        }
       }
     }
     if (pi == 0 && L.type == "Convolution" && L.kclass == 0 && !in_tail) {
@@ -1081,7 +1090,22 @@ void shf_net::commit_params(int li) {
       HIP_THROW(hipMemcpy(p.packed.p, packed.data(), packed.size() * 4, hipMemcpyHostToDevice));
       // a commit in fp32 mode leaves the split-fp16 packs behind: shf_net_set_conv_mode re-packs them on the way back
       p.split_stale = p.packed16.p != nullptr;
-      if (conv_mode >= 1 && conv_f16x3_eligible(p.shape[1], p.shape[0], L.k, L.pad, L.dil)) {
+      p.bf_stale = true;
+      if (conv_mode == 4 && conv_f16x3_eligible(p.shape[1], p.shape[0], L.k, L.pad, L.dil)) {
+        // bf16 mode: hi = bf16(w) bit patterns in the same layouts (no range check: bf16 has fp32's exponent range)
+        std::vector<uint16_t> sp(split16_conv_weight_halfs(p.shape[0], p.shape[1], p.shape[2]));
+        pack_conv_weights_split16(p.host.data(), p.shape[0], p.shape[1], p.shape[2], sp.data(), true);
+        p.packed16b.ensure(sp.size() * 2);
+        HIP_THROW(hipMemcpy(p.packed16b.p, sp.data(), sp.size() * 2, hipMemcpyHostToDevice));
+        if (L.k == 3 && L.dil == 1 && conv_f16x3_uses_w4(p.shape[1]) && p.shape[0] % 128 == 0 && p.shape[1] % 32 == 0) {
+          std::vector<uint16_t> sh(split16h_conv_weight_halfs(p.shape[0], p.shape[1], p.shape[2]));
+          pack_conv_weights_split16h(p.host.data(), p.shape[0], p.shape[1], p.shape[2], sh.data(), true);
+          p.packed16hb.ensure(sh.size() * 2);
+          HIP_THROW(hipMemcpy(p.packed16hb.p, sh.data(), sh.size() * 2, hipMemcpyHostToDevice));
+        }
+        p.bf_stale = false;
+      }
+      if (conv_mode >= 1 && conv_mode <= 3 && conv_f16x3_eligible(p.shape[1], p.shape[0], L.k, L.pad, L.dil)) {
         // split-fp16 keeps hi = fp16(w): a weight beyond the fp16 range would become inf (the reference is fp32
         // everywhere, caffe/python/caffe/_caffe.cpp:46-48) -- refuse the mode instead of computing garbage
         for (float w : p.host)
@@ -1174,27 +1198,30 @@ void shf_net::forward_ops(bool fused_path, float im_h, float im_w, float im_scal
         a.wraw = (const float*)L.params[0]->raw.p;
         a.wpacked = (const float*)L.params[0]->packed.p;
         a.wfirst = (const float*)L.params[0]->first_t.p;
-        const bool split16 = conv_mode >= 1 && L.kclass == 0 && L.params[0]->packed16.p &&
+        const bool bf = conv_mode == 4;
+        const bool split16 = conv_mode >= 1 && L.kclass == 0 && (bf ? L.params[0]->packed16b.p : L.params[0]->packed16.p) &&
                              conv_f16x3_eligible(ib.shape[1], L.nout, L.k, L.pad, L.dil);
-        a.wsplit16 = split16 ? L.params[0]->packed16.p : nullptr;
-        a.wsplit16h = split16 ? L.params[0]->packed16h.p : nullptr;
-        a.wscale_inv = L.params[0]->wscale_inv;
+        a.wsplit16 = split16 ? (bf ? L.params[0]->packed16b.p : L.params[0]->packed16.p) : nullptr;
+        a.wsplit16h = split16 ? (bf ? L.params[0]->packed16hb.p : L.params[0]->packed16h.p) : nullptr;
+        a.wscale_inv = bf ? 1.f : L.params[0]->wscale_inv;
+        a.bf16 = bf && split16 ? 1 : 0;
         if (fused_path && L.fuse_pool >= 0) {
           a.pool = view_of(layers[L.fuse_pool].tops[0]);
           a.write_main = L.pool_only ? 0 : 1;
-          a.pool_split = split16 && blobs[layers[L.fuse_pool].tops[0]].split_fused;
+          a.pool_split = split16 && !bf && blobs[layers[L.fuse_pool].tops[0]].split_fused;
         }
         // split-fp16 mode: every producer of a map that a split-fp16 conv may read guards the fp16 range
-        a.range_flag = conv_mode >= 1 ? (flag_ptr ? flag_ptr : (int*)range_flag.p) : nullptr;
+        // (bf16 has fp32's exponent range: no fp16 range guard; amax_slot() is null in that mode)
+        a.range_flag = conv_mode >= 1 && !bf ? (flag_ptr ? flag_ptr : (int*)range_flag.p) : nullptr;
         a.in_amax = amax_slot(L.bottoms[0]);
         a.out_amax = amax_slot(L.tops[0]);
         if (a.pool.p) a.pool_amax = amax_slot(layers[L.fuse_pool].tops[0]);
         if (split16) {  // how many of the three fp16 products this layer forms
-          a.nprod = conv_mode == 1 ? 3 : conv_mode == 2 ? 2 : 1;
+          a.nprod = conv_mode == 1 ? 3 : conv_mode == 2 ? 2 : 1;   // (modes 3 "f16" and 4 "bf16": one product)
           auto it = sh->layer_products.find(L.name);
           if (it != sh->layer_products.end()) a.nprod = it->second;
         }
-        if (fused_path && split16) {
+        if (fused_path && split16 && !bf) {   // (bf16 mode keeps fp32 activations in HBM)
           a.in_split = ib.split_fused;
           a.out_split = blobs[L.tops[0]].split_fused;
         }
@@ -1203,10 +1230,11 @@ void shf_net::forward_ops(bool fused_path, float im_h, float im_w, float im_scal
           Blob& db = blobs[F.bottoms[0]];
           a.img = db.ext_dev ? db.ext_dev : (const float*)db.dev.p;
           a.w1t = (const float*)F.params[0]->first_t.p;
-          a.w1f = F.params[0]->first_frag.p;
+          a.w1f = bf ? F.params[0]->first_frag_b.p : F.params[0]->first_frag.p;
           a.b1 = F.params.size() > 1 ? (const float*)F.params[1]->raw.p : nullptr;
         }
-        if (fused_path && conv_mode >= 1 && L.first_dst >= 0 && layers[L.first_dst].params[0]->packed16.p)
+        if (fused_path && conv_mode >= 1 && L.first_dst >= 0 &&
+            (bf ? layers[L.first_dst].params[0]->packed16b.p : layers[L.first_dst].params[0]->packed16.p))
           break;  // computed inside the next conv's halo staging
         const double fl = conv_flops(L, ib.shape, blobs[L.tops[0]].shape);
         const double by = 4.0 * (ib.count() + blobs[L.tops[0]].count() + L.params[0]->count());
@@ -1254,7 +1282,7 @@ void shf_net::forward_ops(bool fused_path, float im_h, float im_w, float im_scal
         CHECK_RC(launch_deconv_depthwise(view_of(L.bottoms[0]), view_of(L.tops[0]), (const float*)L.params[0]->raw.p,
                                          L.params.size() > 1 ? (const float*)L.params[1]->raw.p : nullptr, L.k,
                                          L.stride, L.pad, st,
-                                         conv_mode >= 1 ? (flag_ptr ? flag_ptr : (int*)range_flag.p) : nullptr,
+                                         conv_mode >= 1 && conv_mode != 4 ? (flag_ptr ? flag_ptr : (int*)range_flag.p) : nullptr,
                                          amax_slot(L.tops[0])));
         break;
       }
@@ -1518,8 +1546,8 @@ int shf_net_set_proposal_cfg(shf_net* net, int pre_nms_topN, float score_thresh,
 
 int shf_net_set_conv_mode(shf_net* net, int mode) {
   API_BEGIN
-  if (mode < 0 || mode > 3)
-    throw std::runtime_error("conv mode must be 0 (fp32), 1 (split-fp16 x3), 2 (x2) or 3 (plain fp16)");
+  if (mode < 0 || mode > 4)
+    throw std::runtime_error("conv mode must be 0 (fp32), 1 (split-fp16 x3), 2 (x2), 3 (plain fp16) or 4 (bf16)");
   if (net->conv_mode == mode) return 0;
   HIP_THROW(hipDeviceSynchronize());  // the mode is shared with every lane: nothing may be in flight while it flips
   net->conv_mode = mode;
@@ -1529,10 +1557,11 @@ int shf_net_set_conv_mode(shf_net* net, int mode) {
     try {
       for (size_t li = 0; li < net->layers.size(); ++li) {
         Layer& L = net->layers[li];
-        if (L.type == "Convolution" && L.kclass == 0 && !L.params.empty() &&
-            (!L.params[0]->packed16.p || L.params[0]->split_stale) &&
-            conv_f16x3_eligible(L.params[0]->shape[1], L.params[0]->shape[0], L.k, L.pad, L.dil))
-          net->commit_params((int)li);
+        if (L.type != "Convolution" || L.params.empty()) continue;
+        ParamBlob& w = *L.params[0];
+        if (L.kclass == 1 && mode == 4 && w.first_frag.p && (!w.first_frag_b.p || w.bf_stale)) net->commit_params((int)li);
+        if (L.kclass != 0 || !conv_f16x3_eligible(w.shape[1], w.shape[0], L.k, L.pad, L.dil)) continue;
+        if (mode == 4 ? (!w.packed16b.p || w.bf_stale) : (!w.packed16.p || w.split_stale)) net->commit_params((int)li);
       }
     } catch (...) {
       net->conv_mode = 0;  // e.g. a weight outside the fp16 range: stay on the exact kernels
@@ -1890,7 +1919,7 @@ int shf_detect_add_levels(shf_net* net, int n, shf_net** members, const float* c
         CHECK_RC(launch_deconv_depthwise_group(dins, douts, n, (const float*)L.params[0]->raw.p,
                                                L.params.size() > 1 ? (const float*)L.params[1]->raw.p : nullptr, L.k,
                                                L.stride, L.pad, cs,
-                                               net->conv_mode >= 1 ? (int*)net->range_flag.p : nullptr, dslots));
+                                               net->conv_mode >= 1 && net->conv_mode != 4 ? (int*)net->range_flag.p : nullptr, dslots));
       } else {
         for (int m = 0; m < n; ++m)
           members[m]->forward_ops(true, (float)im_h[m], (float)im_w[m], im_scale[m], cs, &net->prof, (int)li, nullptr);

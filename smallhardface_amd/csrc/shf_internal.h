@@ -46,6 +46,8 @@ struct ConvArgs {
   // convs is stored as [pixel][32-channel chunk][hi 32 halfs | lo 32 halfs] -- the same 4 B per element, already
   // split, so the consumer's halo staging is a plain copy
   int in_split = 0, out_split = 0, pool_split = 0;
+  int bf16 = 0;   // conv mode "bf16": one bf16 product per fp32 product (nprod = 1), the packs hold bf16 bit patterns, fp32
+                  // activations in HBM, no fp16 range guard and no activation exponent (bf16 has fp32's range)
   int nprod = 3;  // split-fp16 kernels: fp16 products formed per fp32 product -- 3 (hi*hi + hi*lo + lo*hi: fp32-class),
                   // 2 (drops a_lo*b_hi: activations effectively fp16) or 1 (hi*hi only: plain fp16 operands)
   int* range_flag = nullptr;  // split-fp16 kernels raise it when an output leaves the fp16 range (net.cpp: fp32 re-run)
@@ -78,12 +80,12 @@ int conv_f16x3_init_attributes();
 int launch_conv_f16x3_group(const ConvArgs* as, int n, hipStream_t s);
 size_t split16_conv_weight_halfs(int Cout, int Cin, int k);
 size_t split16h_conv_weight_halfs(int Cout, int Cin, int k);
-float pack_conv_weights_split16h(const float* w, int Cout, int Cin, int k, void* dst);  // returns 1 / scale
+float pack_conv_weights_split16h(const float* w, int Cout, int Cin, int k, void* dst, bool bf = false);  // returns 1 / scale
 bool conv_f16x3_group_is_dual(const ConvArgs* as, int n);
-void pack_conv_weights_split16(const float* w, int Cout, int Cin, int k, void* dst);
+void pack_conv_weights_split16(const float* w, int Cout, int Cin, int k, void* dst, bool bf = false);
 // first layer (64, 27) as the B operand of v_mfma_f32_32x32x16_f16: [n 2][kk 2][hi/lo 2][lane 64][8 halfs], K padded 27 -> 32
 constexpr size_t kFirstConvFragHalfs = 2 * 2 * 2 * 64 * 8;
-void pack_first_conv_frags(const float* w, void* dst);
+void pack_first_conv_frags(const float* w, void* dst, bool bf = false);
 // host-side weight re-pack for the mfma kernel
 void pack_conv_weights(const float* w, int Cout, int Cin, int k, float* dst);
 size_t packed_conv_weight_floats(int Cout, int Cin, int k);

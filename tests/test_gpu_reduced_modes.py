@@ -1,0 +1,84 @@
+"""The reduced-precision conv modes (BASELINE configs C3 / C5 name bf16): "f16x2", "f16" (two / one fp16 product per
+fp32 product) and "bf16" (one bf16 product).  They are drift-labelled THROUGHPUT modes, not parity modes -- the reference
+is fp32 everywhere (caffe/python/caffe/_caffe.cpp:46-48) and the headline stays f16x3 -- so what is pinned here is that
+every convolution of the net really runs reduced (fused first pair, 8-wave, 4-wave family), that the drift stays in its
+measured band, and bf16's range behaviour."""
+import numpy as np
+import pytest
+
+from smallhardface_amd import prototxt as P
+from smallhardface_amd.config import cfg
+from tests import helpers as H
+from tests.test_gpu_parity import conv_layer, unmatched_rows
+
+pytestmark = pytest.mark.gpu
+
+# max |dscore| vs the exact fp32 mode over all anchors of a 160x224 level (measured: f16x3 ~1e-5, f16x2 ~1e-3,
+# f16 ~2e-3, bf16 ~1.5e-2): lower bound = "really reduced", upper bound = "still a detector"
+BANDS = {"f16x2": (2e-5, 1e-2), "f16": (5e-5, 2e-2), "bf16": (5e-4, 1e-1)}
+
+
+@pytest.mark.parametrize("mode", ["f16x2", "f16", "bf16"])
+def test_reduced_mode_drift_and_coverage(mode):
+    from smallhardface_amd import test as T
+    cfg.MODEL.DIFFERENT_DILATION.ENABLE = True
+    gnet, _ = H.make_pair(H.detector_msg(True), cls_bias=1.0)
+    data = H.synth_image_blob(160, 224, seed=8)
+    info = np.array([[160, 224, 1.0]], np.float32)
+
+    def run(m):
+        gnet.set_conv_mode(m)
+        gnet.blobs['data'].reshape(*data.shape)
+        gnet.blobs['im_info'].reshape(1, 3)
+        gnet.forward(data=data, im_info=info)
+        layers = {n: gnet.blobs[n].data.copy() for n in ("conv1_2", "conv2_1", "conv3_3", "conv4_256", "conv4_fuse_final", "head_1", "head_4")}
+        scores = gnet.blobs["cls_prob_reshape_output"].data.copy()
+        dets = T.detect_fused(gnet, [(data, 160, 224, 160, 224, 1.0, False)], thresh=0.05)[0]
+        return layers, scores, dets
+
+    ref_l, ref_s, ref_d = run("fp32")
+    x3_l, x3_s, x3_d = run("f16x3")
+    red_l, red_s, red_d = run(mode)
+    assert gnet.conv_mode == mode
+    drift = float(np.abs(red_s - ref_s).max())
+    lo, hi = BANDS[mode]
+    assert lo < drift < hi, (mode, drift)
+    assert float(np.abs(x3_s - ref_s).max()) < 1e-4
+    # every kernel family runs reduced: each of these layers (fused first pair in the fused path / 8-wave conv1_2 here,
+    # 8-wave conv2_1, 4-wave conv3_3 / fuse_final / head_1, 1x1 conv4_256, dilated head_4) moves away from fp32 by more
+    # than the parity mode does, and not by much
+    for n in ref_l:
+        e3, er = H.rel_err(x3_l[n], ref_l[n]), H.rel_err(red_l[n], ref_l[n])
+        assert er > 4 * e3 and er < 5e-2, (mode, n, e3, er)
+    # the fused path (fused first pair, split activation format where the mode keeps it, grouped launches) agrees with
+    # the per-layer path of the same mode, and most boxes survive
+    slack = max(3, len(ref_d) // 10)
+    assert abs(len(red_d) - len(ref_d)) <= slack and unmatched_rows(ref_d, red_d, box_tol=2.0) <= slack, (mode, len(ref_d), len(red_d))
+    gnet.set_conv_mode("f16x3")
+
+
+def test_bf16_mode_has_no_fp16_range_guard():
+    """Activations of 3e5 (beyond fp16) and a weight of 1e5: bf16 mode neither refuses nor falls back, and stays within
+    bf16's accuracy of the oracle; the fp16-based modes refuse the weight."""
+    h, w = 40, 56
+    txt = H.single_layer_net(conv_layer("c0", "data", 64, 3, 1) + conv_layer("c1", "c0", 128, 3, 1) +
+                             conv_layer("c2", "c1", 128, 3, 1), 3, h, w)
+    gnet, onet = H.make_pair(P.parse(txt), seed=11)
+    data = np.random.default_rng(2).normal(0, 1, (1, 3, h, w)).astype(np.float32)
+    onet.blobs['data'].reshape(*data.shape)
+    onet.blobs['im_info'].reshape(1, 3)
+    onet.forward(data=data, im_info=np.array([[h, w, 1]], np.float32))
+    data = data * np.float32(3.0e5 / np.abs(onet.blobs["c0"].data).max())
+    gnet.set_conv_mode("bf16")
+    before = gnet.range_fallbacks
+    go, oo = H.run_both(gnet, onet, data, np.array([[h, w, 1]], np.float32))
+    assert np.abs(onet.blobs["c0"].data).max() > 65504 and gnet.range_fallbacks == before
+    assert np.isfinite(go["c2"]).all() and H.rel_err(go["c2"], oo["c2"]) < 3e-2
+    big = onet.params["c1"][0].copy()
+    big[0, 0, 0, 0] = 1.0e5
+    onet.params["c1"][0][...] = big
+    H.load_params(gnet, onet.params)                      # committed in bf16 mode: accepted
+    go, oo = H.run_both(gnet, onet, data * np.float32(1e-3), np.array([[h, w, 1]], np.float32))
+    assert np.isfinite(go["c2"]).all() and H.rel_err(go["c2"], oo["c2"]) < 3e-2
+    with pytest.raises(Exception, match="fp16 range"):
+        gnet.set_conv_mode("f16")
