@@ -69,11 +69,19 @@ __device__ __forceinline__ f32x16 mma16(const half8 a, const half8 b, const f32x
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
 __device__ __forceinline__ _Float16 bf16_as_half(float x) { return __builtin_bit_cast(_Float16, (__bf16)x); }
+// two floats -> their bf16 bit patterns in one register (low half = a).  (hipcc 7.2 lowers a VECTOR float2 -> bf16x2
+// conversion to v_cvt_pk_bf16_f32 with the first element in both source slots -- the odd element is lost: tools/diag_bf16.py
+// -- so the instruction is spelled out.)
+__device__ __forceinline__ unsigned pk_bf16(float a, float b) {
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
 // four floats -> four bf16 bit patterns in a half4
 __device__ __forceinline__ void bf16x4_of(const float4 v, _Float16 (&h)[4]) {
-  const bf16x2v a = __builtin_convertvector((f32x2){v.x, v.y}, bf16x2v), b = __builtin_convertvector((f32x2){v.z, v.w}, bf16x2v);
-  h[0] = __builtin_bit_cast(_Float16, a[0]); h[1] = __builtin_bit_cast(_Float16, a[1]);
-  h[2] = __builtin_bit_cast(_Float16, b[0]); h[3] = __builtin_bit_cast(_Float16, b[1]);
+  typedef _Float16 h2_ __attribute__((ext_vector_type(2)));
+  const h2_ a = __builtin_bit_cast(h2_, pk_bf16(v.x, v.y)), b = __builtin_bit_cast(h2_, pk_bf16(v.z, v.w));
+  h[0] = a[0]; h[1] = a[1]; h[2] = b[0]; h[3] = b[1];
 }
 
 // x -> (hi, lo) for four values, two per instruction: v_cvt_pk_f16_f32 for both halves, packed fp32

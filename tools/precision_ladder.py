@@ -3,7 +3,7 @@
     python tools/precision_ladder.py [--quick]
 
 For each conv mode -- f16x3 (three fp16 products: the parity mode), f16x2 (activations act as fp16), f16 (plain fp16
-operands) -- and for single layers switched to 2 / 1 products inside the f16x3 mode:
+operands), bf16 (plain bf16 operands) -- and for single layers switched to 2 / 1 products inside the f16x3 mode:
   * C1 (512x512 level): max |score - oracle| over the 12 288 anchors (the 1e-4 bar), max |delta - oracle|
   * 1008x1008 level: max |score - fp32 mode| over the 47 628 anchors
   * C5 image (10 units): voted detections against the fp32 mode: count, max |dscore|, rows whose written integer
@@ -95,7 +95,7 @@ def main():
         print(tag, r, flush=True)
         return r
 
-    for mode in ("f16x3", "f16x2", "f16"):
+    for mode in ("f16x3", "f16x2", "f16", "bf16"):
         net.set_conv_mode(mode)
         r = measure(mode)
         r.update(image_metrics())
