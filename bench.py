@@ -384,6 +384,7 @@ def main():
                     n += 1
             return n
 
+        headline_last = dict(last)   # (the leg's steps overwrite `last`: --dump-dets and the JSON line report the headline run)
         net.set_conv_mode("fp32")
         ref_scores = level_scores()
         ref_dets = np.asarray(fd.detect(unit_list, thresh, on_device=True)[0])
@@ -405,6 +406,8 @@ def main():
                           "max_abs_dscore_vs_fp32": drift, "boxes_fp32": int(len(ref_dets)), "boxes": int(len(dets)),
                           "boxes_matched": matched(dets, ref_dets, max(4 * drift, 1e-3))}
         net.set_conv_mode(args.conv_mode)
+        last.clear()
+        last.update(headline_last)
         reduced = dict(legs["bf16"])
         reduced["products"] = "one v_mfma_f32_32x32x16_bf16 per fp32 product in every conv kernel, fp32 accumulate, fp32 activations in HBM"
         reduced["drift_level"] = "%dx%d level of the workload, every anchor score against conv mode fp32; boxes matched within 2 px" % (
