@@ -454,6 +454,16 @@ __device__ __forceinline__ void conv_flush_quarter(const float* __restrict__ Cs,
 // accumulator tile, no LDS round trip and no barrier.  The fused 2x2 max-pool is a max over the four lanes of a quad
 // (row_to_pixel walks a 2x2 window with the two low lane bits): two DPP quad permutes; windows on a ragged edge are
 // clipped like Caffe's (pooling_layer.cu:24-27) by feeding -FLT_MAX for pixels outside the image.
+// the half-wave exchange on its own (used by the fused first pair for conv1_1's way into LDS): afterwards kh = 0 holds
+// rows 0..15 and kh = 1 rows 16..31 of the 32-row tile, in register order 0-3, 8-11, 4-7, 12-15
+__device__ __forceinline__ void conv_swap_halves(float (&v)[16]) {
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    const int x = (s & 3) + 4 * (s >> 2), y = x + 8;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(v[x]), "+v"(v[y]));
+  }
+}
+
 template <bool RELU>
 __device__ __forceinline__ void conv_epilogue_regs_tail(float (&v)[16], const float4* bias16, bool valid, bool interior,
                                                         float* __restrict__ pix_main, int cout16, bool main_split,

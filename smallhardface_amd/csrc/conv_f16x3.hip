@@ -971,7 +971,16 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
 #pragma unroll
         for (int hl = 0; hl < 2; ++hl)
           bw[n][kk][hl] = *(const half8*)((const _Float16*)p.w1f + ((size_t)((n * 2 + kk) * 2 + hl) * 64 + lane) * 8);
-    const float bias0 = p.b1 ? p.b1[i1] : 0.f, bias1 = p.b1 ? p.b1[32 + i1] : 0.f;
+    // conv1_1 runs as D[cout][pixel] (weights = A operand): a lane owns ONE halo pixel and the 16 couts
+    // (r & 3) + 8 (r >> 2) + 4 kh of each 32-channel chunk -- one validity flag per lane, and after the half-wave
+    // exchange 16 consecutive couts = two 16-byte LDS stores each for hi and lo (the D[pixel][cout] form wrote 32 two-byte
+    // values per lane and chunk and read 16 flags).  bias1v[n][q] = biases of couts 8 q + 4 kh .. + 3 of chunk n.
+    float4 bias1v[2][4];
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        bias1v[n][q] = p.b1 ? *(const float4*)(p.b1 + n * 32 + 8 * q + 4 * kh1) : make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
     PC_T();
     constexpr int NMT = (HP + 31) / 32;  // 11 row tiles
@@ -1004,29 +1013,49 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
         for (int r = 0; r < 16; ++r) { cm[r] = 0.f; cc[r] = 0.f; }
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-          cm = mma16<BF>(ah[kk], bw[n][kk][0], cm);
-          if constexpr (!BF) cc = mma16<BF>(ah[kk], bw[n][kk][1], cc);
+          cm = mma16<BF>(bw[n][kk][0], ah[kk], cm);
+          if constexpr (!BF) cc = mma16<BF>(bw[n][kk][1], ah[kk], cc);
         }
         if constexpr (!BF) {
 #pragma unroll
-          for (int kk = 0; kk < 2; ++kk) cc = mma16<BF>(al[kk], bw[n][kk][0], cc);
+          for (int kk = 0; kk < 2; ++kk) cc = mma16<BF>(bw[n][kk][0], al[kk], cc);
         }
-        // C row (pixel) = (r & 3) + 8 (r >> 2) + 4 kh, C column (cout) = lane & 31
-        const float bias = n ? bias1 : bias0;
-        unsigned char* At = (n ? As1 : As0) + i1 * 2;
-        unsigned char ok[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) ok[r] = valid[m * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh1];
+        // C row (cout) = (r & 3) + 8 (r >> 2) + 4 kh, C column (halo pixel) = lane & 31
+        const bool ok = valid[m * 32 + i1] != 0;   // 0 outside the image (conv1_2's zero padding, not conv1_1 evaluated out there)
+        float v[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int hq = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh1;
-          // valid[]: 0 outside the image (conv1_2's zero padding, not conv1_1 evaluated out there)
+          const float4 bq = bias1v[n][r >> 2];
+          const float bias = (r & 3) == 0 ? bq.x : (r & 3) == 1 ? bq.y : (r & 3) == 2 ? bq.z : bq.w;
           const float pre = cm[r] + cc[r] * LO_INV + bias;
-          const float v = ok[r] ? fmaxf(pre, 0.f) : 0.f;
-          amax1 = fmaxf(amax1, pre != pre ? __builtin_inff() : v);  // (fmaxf would swallow a NaN)
-          const _Float16 h = BF ? bf16_as_half(v) : (_Float16)v;
-          *(_Float16*)(At + hq * ROWB) = h;
-          if constexpr (!BF) *(_Float16*)(At + hq * ROWB + 64) = (_Float16)((v - (float)h) * LO_SCALE);
+          v[r] = ok ? fmaxf(pre, 0.f) : 0.f;
+          amax1 = fmaxf(amax1, pre != pre ? __builtin_inff() : v[r]);  // (fmaxf would swallow a NaN)
+        }
+        conv_swap_halves(v);   // kh = 0 now holds couts 0..15, kh = 1 couts 16..31, register order 0-3, 8-11, 4-7, 12-15
+        constexpr int ORD[4] = {0, 8, 4, 12};
+        float hi8[8], lo8[8];
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int t = 0; t < 4; t += 2) {
+            const float x0 = v[ORD[g] + t], x1 = v[ORD[g] + t + 1];
+            half2v h, l;
+            if constexpr (BF) {
+              h = __builtin_bit_cast(half2v, pk_bf16(x0, x1));
+              l = half2v{(_Float16)0, (_Float16)0};
+            } else {
+              h = __builtin_convertvector(f32x2{x0, x1}, half2v);
+              l = __builtin_convertvector((f32x2{x0, x1} - __builtin_convertvector(h, f32x2)) * LO_SCALE, half2v);
+            }
+            hi8[g * 2 + (t >> 1)] = __builtin_bit_cast(float, h);
+            lo8[g * 2 + (t >> 1)] = __builtin_bit_cast(float, l);
+          }
+        unsigned char* row = (n ? As1 : As0) + (m * 32 + i1) * ROWB + kh1 * 32;
+        *(float4*)row = make_float4(hi8[0], hi8[1], hi8[2], hi8[3]);
+        *(float4*)(row + 16) = make_float4(hi8[4], hi8[5], hi8[6], hi8[7]);
+        if constexpr (!BF) {
+          *(float4*)(row + 64) = make_float4(lo8[0], lo8[1], lo8[2], lo8[3]);
+          *(float4*)(row + 80) = make_float4(lo8[4], lo8[5], lo8[6], lo8[7]);
         }
       }
     };
@@ -1081,20 +1110,20 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
       for (int tm = 0; tm < MT; ++tm)
 #pragma unroll
         for (int tn = 0; tn < 2; ++tn)
-          accm[tm][tn] = mma16<BF>(a[2 * tm], bf[2 * tn], accm[tm][tn]);
+          accm[tm][tn] = mma16<BF>(bf[2 * tn], a[2 * tm], accm[tm][tn]);   // weights = A operand: D[cout][pixel]
       if constexpr (NP >= 2) {
 #pragma unroll
         for (int tm = 0; tm < MT; ++tm)
 #pragma unroll
           for (int tn = 0; tn < 2; ++tn)
-            accc[tm][tn] = mma16<BF>(a[2 * tm], bf[2 * tn + 1], accc[tm][tn]);
+            accc[tm][tn] = mma16<BF>(bf[2 * tn + 1], a[2 * tm], accc[tm][tn]);
       }
       if constexpr (NP >= 3) {
 #pragma unroll
         for (int tm = 0; tm < MT; ++tm)
 #pragma unroll
           for (int tn = 0; tn < 2; ++tn)
-            accc[tm][tn] = mma16<BF>(a[2 * tm + 1], bf[2 * tn], accc[tm][tn]);
+            accc[tm][tn] = mma16<BF>(bf[2 * tn], a[2 * tm + 1], accc[tm][tn]);
       }
       if (s_ + 1 < 6) {
 #pragma unroll
@@ -1120,27 +1149,38 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
   }
 
   PC_T();
-  // epilogue: transposed through LDS (conv_common.h), all 512 threads flush
-  __syncthreads();
-  float* Cs = (float*)smem;
+  // epilogue: the four consumer waves store from registers (conv_common.h conv_epilogue_regs: half-wave exchange, 16
+  // consecutive couts per lane, fused 2x2 max-pool as a DPP quad max) -- no LDS round trip, no barrier
   float amax = 0.f;  // this layer's stored outputs: fp16 range guard (with conv1_1's, amax1) + activation exponent
   if (consumer) {
+    const bool relu = (p.relu & 1) != 0, write_main = !(p.relu & 8), main_split = (p.relu & 32) != 0,
+               pool_split = (p.relu & 64) != 0;
+    int px_e = px, dy_e = dy, kh_e = kh, i_e = i;
+    asm volatile("" : "+v"(px_e), "+v"(dy_e), "+v"(kh_e), "+v"(i_e));
+    const int Hp = (H + 1) >> 1, Wp = (W + 1) >> 1;
+    const bool interior = ty0 + TH <= H && tx0 + TW <= W;
+    const int x = tx0 + px_e;
 #pragma unroll
     for (int tn = 0; tn < 2; ++tn) {
-      const int cl = tn * 32 + i;
-      const float bv = p.bias ? p.bias[cl] : 0.f;
+      const int cout16 = tn * 32 + kh_e * 16;
+      float4 bias16[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) bias16[g] = p.bias ? *(const float4*)(p.bias + cout16 + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
       for (int tm = 0; tm < MT; ++tm) {
-        if (p.relu & 1)
-          conv_stage_tile_pk<BN, true>(Cs, accm[tm][tn], accc[tm][tn], LO_INV, bv, wm * 2 * MT + tm * 2, kh, cl, amax, H - ty0, W - tx0);
+        const int y = ty0 + wm * 2 * MT + tm * 2 + dy_e;
+        const bool vld = y < H && x < W;
+        float* pm = write_main ? gout + ((size_t)(b * H + y) * W + x) * p.out_stride : nullptr;
+        float* pq = mem.pool ? mem.pool + ((size_t)(b * Hp + (y >> 1)) * Wp + (x >> 1)) * p.pool_stride : nullptr;
+        if (relu)
+          conv_epilogue_regs<true>(accm[tm][tn], accc[tm][tn], LO_INV, bias16, vld, interior, pm, cout16, main_split, pq,
+                                   vld && (i_e & 3) == 0, pool_split, amax);
         else
-          conv_stage_tile_pk<BN, false>(Cs, accm[tm][tn], accc[tm][tn], LO_INV, bv, wm * 2 * MT + tm * 2, kh, cl, amax, H - ty0, W - tx0);
+          conv_epilogue_regs<false>(accm[tm][tn], accc[tm][tn], LO_INV, bias16, vld, interior, pm, cout16, main_split, pq,
+                                    vld && (i_e & 3) == 0, pool_split, amax);
       }
     }
   }
-  __syncthreads();
-  conv_flush_tile<BN, 512>(Cs, tid, ty0, tx0, H, W, b, 0, gout, p.out_stride, mem.pool, p.pool_stride, !(p.relu & 8),
-                           (p.relu & 32) != 0, (p.relu & 64) != 0);
   conv_raise_range_flag(p.range_flag, fmaxf(amax, amax1));
   conv_publish_amax(mem.out_amax, mem.pool ? mem.pool_amax : nullptr, amax);
   PC_T();
@@ -1226,7 +1266,7 @@ float pack_conv_weights_split16h(const float* w, int Cout, int Cin, int k, void*
 // Environment knobs (experiments; the defaults are the measured best), read ONCE: none of them is consulted per launch.
 namespace {
 struct Knobs {
-  int w4_mode;         // SHF_F16X3_W4: -1 auto (Cin >= 128), 0 never, 1 always -- which layers take the 4-wave dual-tile family
+  int w4_mode;         // SHF_F16X3_W4: -1 auto (Cin >= 64), 0 never, 1 always -- which layers take the 4-wave dual-tile family
   int w4_mt;           // SHF_F16X3_W4_MT: 0 auto, 2 / 4 force 8- / 16-row tiles
   int w4d_ntile;       // SHF_F16X3_W4D_NTILE: 0 auto (hybrid launches), 1 / 2 force single- / two-tile blocks
   int xcd_remap;       // SHF_F16X3_XCD_REMAP: 1 = all cout tiles of a pixel tile on one XCD (experiment)
@@ -1292,7 +1332,8 @@ void pack_first_conv_frags(const float* w, void* dst_, bool bf) {
 
 bool conv_f16x3_uses_pc() { return knobs().pc; }
 
-bool conv_f16x3_uses_w4(int Cin) { return knobs().w4_mode < 0 ? Cin >= 128 : knobs().w4_mode != 0; }
+// (Cin 64 -- conv2_1 -- joined in round 3: as two single-tile 8-row blocks per CU it beats the 8-wave kernel, 0.67 vs 0.81 ms)
+bool conv_f16x3_uses_w4(int Cin) { return knobs().w4_mode < 0 ? Cin >= 64 : knobs().w4_mode != 0; }
 
 bool conv_f16x3_eligible(int Cin, int Cout, int k, int pad, int dil) {
   const bool dil_ok = dil == 1 || (knobs().dilated && (dil == 2 || dil == 4));
