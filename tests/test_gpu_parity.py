@@ -476,10 +476,12 @@ def test_device_preprocessing_feeds_the_detector():
 
 def test_kernel_selection_knobs_do_not_change_results(tmp_path, conv_mode):
     """Every kernel-selection / data-format knob of the split-fp16 path is a pure performance choice: the
-    detections of the fused path are bit-identical with the 4-wave kernel, the producer/consumer first pair,
-    the split activation format switched off, single / two-tile blocks and 8-row tiles forced in the dual-tile family
-    (its activation exponent is a function of the unit alone, so no grouping may change a bit); kernels with another
-    accumulation scheme (8-wave two-accumulator, conv1_1 on the vector ALUs) agree to fp32-class tolerance."""
+    detections of the fused path are bit-identical with the split activation format switched off and with single /
+    two-tile blocks and 8-row tiles forced in the dual-tile family (its activation exponent is a function of the unit
+    alone, so no grouping may change a bit); kernels with another accumulation scheme (8-wave two-accumulator, conv1_1
+    on the vector ALUs) agree to fp32-class tolerance on the PRE-MERGE rows (a borderline IoU >= 0.4 decision of the
+    greedy vote cascades through a whole pile of overlapping boxes, so voted rows are compared only between builds of
+    the same arithmetic)."""
     if conv_mode != "f16x3":
         pytest.skip("split-fp16 knobs")
     import os
@@ -488,44 +490,52 @@ def test_kernel_selection_knobs_do_not_change_results(tmp_path, conv_mode):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / "run.py"
     script.write_text('''
-import sys, numpy as np
+import sys, numpy as np, torch
 from smallhardface_amd.config import cfg
 from smallhardface_amd import test as T
 from tests import helpers as H
 cfg.MODEL.DIFFERENT_DILATION.ENABLE = True
 cfg.TEST.SCALES = [100, 300, 500]
-gnet, _ = H.make_pair(H.detector_msg(True), cls_bias=1.0)
+msg = H.detector_msg(True)
+gnet, onet = H.make_pair(msg, cls_bias=1.0)
+rng = np.random.default_rng(17)                      # biases with some life (the synthetic ones are zero)
+for name, blobs in onet.params.items():
+    if name.startswith("conv") and len(blobs) > 1:
+        blobs[1][...] = rng.normal(0, 0.05, blobs[1].shape).astype(np.float32)
+H.load_params(gnet, onet.params)
 gnet.set_conv_mode("f16x3")
 im = np.random.default_rng(5).integers(0, 256, (150, 200, 3)).astype(np.uint8)
+units = list(T.pyramid_units(im))
 fd = T.FusedDetector(gnet, n_lanes=6, mode="group")
-np.save(sys.argv[1], fd.detect(list(T.pyramid_units(im)), thresh=0.05)[0])
+voted = fd.detect(units, thresh=0.05)[0]
+gnet.detect_begin()                                  # the same units once more, one by one: the rows before the merge
+for u in units:
+    gnet.detect_add_level(*u, thresh=0.05)
+buf = torch.empty((400000, 5), dtype=torch.float32, device="cuda")
+n = gnet.detect_export(buf.data_ptr(), 400000)
+np.savez(sys.argv[1], voted=voted, raw=buf[:n].cpu().numpy())
 ''')
     outs = {}
     for name, env in (("default", {}), ("no_split_act", {"SHF_F16X3_SPLIT_ACT": "0"}), ("no_w4", {"SHF_F16X3_W4": "0"}),
                       ("scalar_epilogue", {"SHF_CONV_SCALAR_EPILOGUE": "1", "SHF_F16X3_SPLIT_ACT": "0"}),
                       ("single_tile", {"SHF_F16X3_W4D_NTILE": "1"}), ("dual_tile", {"SHF_F16X3_W4D_NTILE": "2"}),
-                      ("rows8", {"SHF_F16X3_W4_MT": "2"}), ("no_pc", {"SHF_F16X3_PC": "0"})):
-        out = str(tmp_path / (name + ".npy"))
+                      ("rows8", {"SHF_F16X3_W4_MT": "2"}), ("rows16", {"SHF_F16X3_W4_MT": "4"}), ("no_pc", {"SHF_F16X3_PC": "0"})):
+        out = str(tmp_path / (name + ".npz"))
         e = dict(os.environ, PYTHONPATH=root, **env)
         r = subprocess.run([sys.executable, str(script), out], env=e, cwd=root, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, (name, r.stderr[-1500:])
         outs[name] = np.load(out)
-    assert len(outs["default"]) > 0
-    # (the scalar epilogue also rules the producer/consumer first pair out: its twin is "no_pc")
-    # same arithmetic, different data path: bit-identical
-    bad = [(name, ref) for name, ref in (("no_split_act", "default"), ("single_tile", "default"), ("dual_tile", "default"),
-                                         ("rows8", "default"))
-           if outs[name].shape != outs[ref].shape or not np.array_equal(outs[name], outs[ref])]
-    assert not bad, bad
-    # other kernels for the same layers (8-wave two-accumulator arithmetic, the pre-dual 4-wave kernels, conv1_1 on the
-    # vector ALUs): fp32-class agreement
-    # (~1500 voted boxes of a noise image: a handful of clusters sit within the 1e-5 arithmetic difference of the
-    # IoU >= 0.4 / score > 0.05 cuts -- tools/diag_arith.py: the exact fp32 mode gives 1524 boxes, the dual-tile family
-    # 1524, the 8-wave kernels everywhere 1520 -- so rows are matched by score and coordinates, not by rank)
+    assert len(outs["default"]["voted"]) > 0 and len(outs["default"]["raw"]) > len(outs["default"]["voted"])
+    # same arithmetic, different data path: bit-identical, merged and un-merged
+    for name in ("no_split_act", "single_tile", "dual_tile", "rows8", "rows16"):
+        for key in ("voted", "raw"):
+            assert outs[name][key].shape == outs["default"][key].shape and np.array_equal(outs[name][key], outs["default"][key]), (name, key)
+    # other kernels for the same layers: fp32-class agreement of the rows that go into the merge (a row may cross the
+    # > 0.05 cut on one side only)
     for name in ("no_w4", "scalar_epilogue", "no_pc"):
-        a, b = outs["default"], outs[name]
-        slack = max(2, len(a) // 200)
-        assert abs(len(a) - len(b)) <= slack, name
+        a, b = outs["default"]["raw"], outs[name]["raw"]
+        slack = max(2, len(a) // 500)
+        assert abs(len(a) - len(b)) <= slack, (name, len(a), len(b))
         assert unmatched_rows(a, b) <= slack and unmatched_rows(b, a) <= slack, name
 
 
