@@ -949,16 +949,18 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
     // fragments (weights) come pre-packed from global memory.  N tile 0 / 1 = channel chunk 0 / 1 = halo tile
     // As0 / As1.  (On the vector ALUs this was 15-18 k cycles per tile, a third of the block.)
     const float* img = mem.img + (size_t)b * 3 * H * W;
+    static_assert(PH == 20 && PW == 20 && HTW == 18, "the multiply-shift divisions below are exact for these sizes");
     for (int idx = tid; idx < 3 * PH * PW; idx += 512) {
-      const int ci = idx / (PH * PW), r = idx - ci * (PH * PW);
-      const int py = r / PW, pxx = r - py * PW;
+      // (integer division is a ~40-instruction sequence: n / 400, n / 20 and n / 18 as multiply + shift, exact below 1300 / 420 / 400)
+      const int ci = (idx * 2622) >> 20, r = idx - ci * (PH * PW);
+      const int py = (r * 52429) >> 20, pxx = r - py * PW;
       const int gy = ty0 - 2 + py, gx = tx0 - 2 + pxx;
       const float pv = ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) ? img[((size_t)ci * H + gy) * W + gx] : 0.f;
       patch[idx] = pv;
       amax1 = fmaxf(amax1, fabsf(pv));  // the image itself is split to fp16 hi/lo for conv1_1's MFMAs
     }
     if (tid < HPP) {
-      const int qy = tid / HTW, qx = tid - qy * HTW;
+      const int qy = (tid * 58255) >> 20, qx = tid - qy * HTW;
       valid[tid] = (tid < HP && (unsigned)(ty0 - 1 + qy) < (unsigned)H && (unsigned)(tx0 - 1 + qx) < (unsigned)W) ? 1 : 0;
     }
     PC_T();
@@ -988,7 +990,7 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
     // wave does 1.5 tiles instead of 2
     auto conv1_tile = [&](int m, int n_lo, int n_hi) {
       const int hp = m * 32 + i1 < HP ? m * 32 + i1 : HP - 1;
-      const int hy = hp / HTW, hx = hp - hy * HTW;
+      const int hy = (hp * 58255) >> 20, hx = hp - hy * HTW;
       const float* pb = patch + hy * PW + hx;
       half8 ah[2], al[2];
 #pragma unroll
@@ -1029,7 +1031,7 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
           const float bias = (r & 3) == 0 ? bq.x : (r & 3) == 1 ? bq.y : (r & 3) == 2 ? bq.z : bq.w;
           const float pre = cm[r] + cc[r] * LO_INV + bias;
           v[r] = ok ? fmaxf(pre, 0.f) : 0.f;
-          amax1 = fmaxf(amax1, pre != pre ? __builtin_inff() : v[r]);  // (fmaxf would swallow a NaN)
+          amax1 = fmaxf(amax1, v[r]);   // (an inf here comes from an inf in the patch, which amax1 has seen already)
         }
         conv_swap_halves(v);   // kh = 0 now holds couts 0..15, kh = 1 couts 16..31, register order 0-3, 8-11, 4-7, 12-15
         constexpr int ORD[4] = {0, 8, 4, 12};
