@@ -144,18 +144,17 @@ static const char* kProfNames[PC_COUNT] = {"conv_mfma_f32_kernel<3, 1, 128, 8, 1
                                            "conv_mfma_f32_kernel<3, 4, 128, 8, 16>", "conv_mfma_f32_kernel<3, 1, 64, 16, 16>",
                                            "conv_mfma_f32_kernel<3, 2, 64, 16, 16>", "conv_mfma_f32_kernel<3, 4, 64, 16, 16>",
                                            "conv_mfma_f32_kernel<1, 0, 128, 8, 16>", "conv_mfma_f32_kernel<1, 0, 64, 16, 16>",
-                                           "conv_mfma_f16x3_kernel<128, false, 1, 3>", "conv_mfma_f16x3_w4_kernel<false, 4, 3>",
-                                           "conv_mfma_f16x3_w4_kernel<true, 4, 3>", "conv_mfma_f16x3_w4_kernel<false, 2, 3>",
-                                           "conv_mfma_f16x3_w4_kernel<true, 2, 3>",
-                                           "conv_mfma_f16x3_kernel<64, false, 1, 3>",
-                                           "conv_mfma_f16x3_kernel<64, true, 1, 3>", "conv_mfma_f16x3_kernel<64, false, 2, 3>",
-                                           "conv_mfma_f16x3_kernel<64, false, 4, 3>", "conv_mfma_f16x3_kernel<128, false, 1, 1>",
-                                           "conv_mfma_f16x3_kernel<64, false, 1, 1>", "conv_mfma_f16x3_pc_kernel",
+                                           "conv_mfma_f16x3_kernel<128, false, 1, 3, 3, false>", "(retired: single-tile 4-wave kernel)",
+                                           "(retired)", "(retired)", "(retired)",
+                                           "conv_mfma_f16x3_kernel<64, false, 1, 3, 3, false>",
+                                           "conv_mfma_f16x3_kernel<64, true, 1, 3, 3, false>", "conv_mfma_f16x3_kernel<64, false, 2, 3, 3, false>",
+                                           "conv_mfma_f16x3_kernel<64, false, 4, 3, 3, false>", "conv_mfma_f16x3_kernel<128, false, 1, 1, 3, false>",
+                                           "conv_mfma_f16x3_kernel<64, false, 1, 1, 3, false>", "conv_mfma_f16x3_pc_kernel<3, false>",
                                            // dual-tile family <IN_SPLIT, rows / 4, tiles per block, products>: index = in_split * 4 + (rows == 8) * 2 + (tiles == 1)
-                                           "conv_mfma_f16x3_w4d_kernel<false, 4, 2, 3>", "conv_mfma_f16x3_w4d_kernel<false, 4, 1, 3>",
-                                           "conv_mfma_f16x3_w4d_kernel<false, 2, 2, 3>", "conv_mfma_f16x3_w4d_kernel<false, 2, 1, 3>",
-                                           "conv_mfma_f16x3_w4d_kernel<true, 4, 2, 3>", "conv_mfma_f16x3_w4d_kernel<true, 4, 1, 3>",
-                                           "conv_mfma_f16x3_w4d_kernel<true, 2, 2, 3>", "conv_mfma_f16x3_w4d_kernel<true, 2, 1, 3>",
+                                           "conv_mfma_f16x3_w4d_kernel<false, 4, 2, 3, false>", "conv_mfma_f16x3_w4d_kernel<false, 4, 1, 3, false>",
+                                           "conv_mfma_f16x3_w4d_kernel<false, 2, 2, 3, false>", "conv_mfma_f16x3_w4d_kernel<false, 2, 1, 3, false>",
+                                           "conv_mfma_f16x3_w4d_kernel<true, 4, 2, 3, false>", "conv_mfma_f16x3_w4d_kernel<true, 4, 1, 3, false>",
+                                           "conv_mfma_f16x3_w4d_kernel<true, 2, 2, 3, false>", "conv_mfma_f16x3_w4d_kernel<true, 2, 1, 3, false>",
                                            "conv_first_kernel", "conv_direct_kernel", "maxpool_kernel",
                                            "deconv_depthwise", "detect_tail", "box_merge", "layout"};
 
@@ -202,9 +201,8 @@ static int f16x3_prof_class(const ConvArgs& a, int nout, const ConvArgs* group =
   if (a.dil == 2) return PC_CONV_F16X3_64_D2;
   if (a.dil == 4) return PC_CONV_F16X3_64_D4;
   if (nout % 128) return PC_CONV_F16X3_64;
-  if (!conv_f16x3_uses_w4(a.in.C)) return PC_CONV_F16X3_128;
-  const bool mt2 = conv_f16x3_w4_mt(group ? group : &a, group ? n : 1) == 2;
-  return a.in_split ? (mt2 ? PC_CONV_F16X3_W4_SPLIT_MT2 : PC_CONV_F16X3_W4_SPLIT) : (mt2 ? PC_CONV_F16X3_W4_MT2 : PC_CONV_F16X3_W4);
+  (void)group; (void)n;
+  return PC_CONV_F16X3_128;   // (the dual-tile family reports through SubProf, one record per kernel of the layer)
 }
 
 static int conv_prof_class(int k, int dil, int nout) {

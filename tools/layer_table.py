@@ -159,8 +159,15 @@ def main():
         if "SQ_VALU_MFMA_BUSY_CYCLES" in a and a.get("GRBM_GUI_ACTIVE#max"):
             cyc = a["GRBM_GUI_ACTIVE"] / N_XCD
             e["mfma_busy"] = a["SQ_VALU_MFMA_BUSY_CYCLES"] / (cyc * N_SIMD * N_CU)
-            e["effective_clock_ghz"] = cyc / (a["us"] * 1e3)
-            e["mfma_busy_x_clock_over_2p4"] = e["mfma_busy"] * e["effective_clock_ghz"] / 2.4
+            clk = cyc / (a["us"] * 1e3)
+            # GRBM_GUI_ACTIVE counts the chip's busy cycles while the dispatch is in flight: a small kernel that shares the
+            # chip with another stream's grid (tails / merge beside the next image's convolutions) reads as tens of GHz
+            if clk <= 2.6:
+                e["effective_clock_ghz"] = clk
+                e["mfma_busy_x_clock_over_2p4"] = e["mfma_busy"] * clk / 2.4
+            else:
+                e["effective_clock_ghz"] = None
+                e["overlapped_with_another_stream"] = True
         if "SQ_LDS_BANK_CONFLICT" in a and a.get("SQ_LDS_IDX_ACTIVE"):
             e["lds_bank_conflict_frac"] = a["SQ_LDS_BANK_CONFLICT"] / a["SQ_LDS_IDX_ACTIVE"]
         kernels[k] = e
@@ -177,7 +184,7 @@ def main():
     # single tiles for the rest (same <IN_SPLIT, rows>).  Merge such pairs while there are more dispatches than layers.
     import re
     def w4d(n):
-        m = re.search(r"w4d_kernel<(\w+), (\d), (\d), (\d)>", n)
+        m = re.search(r"w4d_kernel<(\w+), (\d), (\d), (\d)(?:, \w+)?>", n)
         return None if m is None else (m.group(1), m.group(2), int(m.group(3)))
     groups, j = [], 0
     while j < len(conv_idx) and len(groups) < len(layers):
