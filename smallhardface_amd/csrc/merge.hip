@@ -6,6 +6,8 @@
 // word per lane-row of a wave64); the serial host reduce of the reference becomes an
 // on-device wavefront scan that resolves 64 boxes at a time out of registers.
 // Compiled with -ffp-contract=off: IoU must round exactly like devIoU / numpy.
+#include <algorithm>
+
 #include "shf_internal.h"
 
 namespace shf {
@@ -100,78 +102,107 @@ int launch_iou_mask(const float* sorted5, int n, float thr, int ge_pred, u64* ma
 }
 
 // ---------------------------------------------------------------------------
-// Greedy scan, ONE wave64.  Boxes are resolved 64 at a time: the 64x64 diagonal tile of
-// the bit matrix sits in registers (lane j = row j) and the within-block dependency chain
-// runs on readlane, no memory; then the rows of the block's kept heads are OR-ed into the
-// removed bitmap of all later blocks, lanes striding over words.
-// cluster[k] = index (sorted order) of the head that absorbed box k.
+// Greedy scan, one block of 16 waves.  Boxes are resolved 64 at a time: the 64x64 diagonal tile of the bit matrix sits
+// in the registers of wave 0 (lane j = row j) and the within-block dependency chain runs on scalar registers
+// (readlane, find-first-set over the not-yet-removed candidates: one turn per KEPT box, not per box); then the rows of
+// the block's kept heads are OR-ed into the removed bitmap of all later 64-box words, one word per wave and turn, lane j
+// holding row j's word -- fetched for ALL 64 rows BEFORE the chain's result is known, so that the loads fly while wave 0
+// runs the chain.  cluster[k] = index (sorted order) of the head that absorbed box k = the first kept head, in
+// ascending order, whose row covers k (a ballot per newly removed box).
+// (Round 2: one wave did both jobs, 2.4 us per block of 64 boxes = 0.26 ms for the bench image's 6 800 boxes.)
 // ---------------------------------------------------------------------------
 constexpr int SCAN_MAX_WORDS = 4096;  // 262144 boxes
+constexpr int SCAN_WAVES = 16, SCAN_PRE = 4;   // words per wave whose rows are fetched ahead of the chain
 
-__global__ __launch_bounds__(64) void greedy_scan_kernel(const u64* __restrict__ mask, int n, int* __restrict__ cluster,
-                                                         int* __restrict__ heads, int* __restrict__ counters) {
+__device__ __forceinline__ u64 wave_or_u64(u64 v) {
+  unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    lo |= (unsigned)__shfl_xor((int)lo, o, 64);
+    hi |= (unsigned)__shfl_xor((int)hi, o, 64);
+  }
+  return ((u64)hi << 32) | lo;
+}
+
+__global__ __launch_bounds__(64 * SCAN_WAVES) void greedy_scan_kernel(const u64* __restrict__ mask, int n,
+                                                                      int* __restrict__ cluster, int* __restrict__ heads,
+                                                                      int* __restrict__ counters) {
   __shared__ u64 removed[SCAN_MAX_WORDS];
+  __shared__ u64 s_kept;
   const int nw = (n + 63) >> 6;
-  const int lane = threadIdx.x;
-  for (int w = lane; w < nw; w += 64) removed[w] = 0;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int w = threadIdx.x; w < nw; w += 64 * SCAN_WAVES) removed[w] = 0;
   __syncthreads();
-  int nheads = 0;
+  int nheads = 0;   // (wave 0)
   for (int blk = 0; blk < nw; ++blk) {
     const int base = blk << 6;
     const int cnt = min(n - base, 64);
-    u64 rem = removed[blk];
-    const u64 diag = (lane < cnt) ? mask[(size_t)(base + lane) * nw + blk] : 0ull;
-    const unsigned dlo = (unsigned)diag, dhi = (unsigned)(diag >> 32);
-    u64 kept = 0;
-    int cl = -1;
-    for (int j = 0; j < cnt; ++j) {
-      if ((rem >> j) & 1ull) continue;
-      kept |= 1ull << j;
-      // readlane returns a signed int: go through unsigned or bit 31 smears over the high word
-      const u64 row = ((u64)(unsigned)__builtin_amdgcn_readlane((int)dhi, j) << 32) |
-                      (u64)(unsigned)__builtin_amdgcn_readlane((int)dlo, j);
-      const u64 nb = row & ~rem;
-      if (((nb >> lane) & 1ull) || lane == j) cl = base + j;
-      rem |= nb | (1ull << j);
+    // rows of this block at the first SCAN_PRE words this wave owns (w = blk + 1 + wave + 16 q): in flight during the chain
+    u64 pre[SCAN_PRE];
+#pragma unroll
+    for (int q = 0; q < SCAN_PRE; ++q) {
+      const int w = blk + 1 + wave + SCAN_WAVES * q;
+      pre[q] = (w < nw && lane < cnt) ? mask[(size_t)(base + lane) * nw + w] : 0ull;
     }
-    if (cl >= 0) cluster[base + lane] = cl;
-    if ((kept >> lane) & 1ull) heads[nheads + __popcll(kept & ((1ull << lane) - 1ull))] = base + lane;
-    nheads += __popcll(kept);
-    // propagate the kept heads' rows to the later words
-    for (int w = blk + 1 + lane; w < nw; w += 64) {
-      u64 r = removed[w];
-      u64 kk = kept;
-      while (kk) {
-        // batches of up to 4 heads: the row loads are independent of r
-        int hj[4];
-        u64 m[4];
-        int c = 0;
-        while (kk && c < 4) {
-          hj[c] = __ffsll((long long)kk) - 1;
-          kk &= kk - 1;
-          ++c;
-        }
-        for (int q = 0; q < c; ++q) m[q] = mask[(size_t)(base + hj[q]) * nw + w];
-        for (int q = 0; q < c; ++q) {
-          u64 nb = m[q] & ~r;
-          r |= nb;
-          while (nb) {
-            const int b = __ffsll((long long)nb) - 1;
-            nb &= nb - 1;
-            cluster[(w << 6) + b] = base + hj[q];
-          }
-        }
+    if (wave == 0) {
+      const u64 diag = (lane < cnt) ? mask[(size_t)(base + lane) * nw + blk] : 0ull;
+      const unsigned dlo = (unsigned)diag, dhi = (unsigned)(diag >> 32);
+      const u64 r0 = removed[blk];
+      // wave-uniform state in scalar registers
+      u64 rem = ((u64)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(r0 >> 32)) << 32) |
+                (u64)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)r0);
+      const u64 all = cnt == 64 ? ~0ull : ((1ull << cnt) - 1ull);
+      u64 cand = ~rem & all, kept = 0;
+      int cl = -1;
+      while (cand) {
+        const int j = __ffsll((long long)cand) - 1;
+        kept |= 1ull << j;
+        // readlane returns a signed int: go through unsigned or bit 31 smears over the high word
+        const u64 row = ((u64)(unsigned)__builtin_amdgcn_readlane((int)dhi, j) << 32) |
+                        (u64)(unsigned)__builtin_amdgcn_readlane((int)dlo, j);
+        const u64 nb = row & ~rem;
+        if (((nb >> lane) & 1ull) || lane == j) cl = base + j;
+        rem |= nb | (1ull << j);
+        cand &= ~rem;
       }
-      removed[w] = r;
+      if (cl >= 0) cluster[base + lane] = cl;
+      if ((kept >> lane) & 1ull) heads[nheads + __popcll(kept & ((1ull << lane) - 1ull))] = base + lane;
+      nheads += __popcll(kept);
+      if (lane == 0) s_kept = kept;
     }
     __syncthreads();
+    const u64 kept = s_kept;
+    const bool mine = (kept >> lane) & 1ull;   // lane j speaks for row j of the block, if it was kept
+    auto propagate = [&](int w, u64 val) {
+      val = mine ? val : 0ull;
+      const u64 orv = wave_or_u64(val);
+      const u64 r = removed[w];
+      u64 nb = orv & ~r;
+      if (nb) {
+        if (lane == 0) removed[w] = r | orv;
+        while (nb) {   // (wave-uniform)
+          const int b = __ffsll((long long)nb) - 1;
+          nb &= nb - 1;
+          const u64 col = __ballot((val >> b) & 1ull);          // the kept heads of this block that cover box (w, b)
+          if (lane == 0) cluster[(w << 6) + b] = base + (__ffsll((long long)col) - 1);
+        }
+      }
+    };
+#pragma unroll
+    for (int q = 0; q < SCAN_PRE; ++q) {
+      const int w = blk + 1 + wave + SCAN_WAVES * q;
+      if (w < nw) propagate(w, pre[q]);
+    }
+    for (int w = blk + 1 + wave + SCAN_WAVES * SCAN_PRE; w < nw; w += SCAN_WAVES)
+      propagate(w, (lane < cnt) ? mask[(size_t)(base + lane) * nw + w] : 0ull);
+    __syncthreads();
   }
-  if (lane == 0) counters[0] = nheads;
+  if (threadIdx.x == 0) counters[0] = nheads;
 }
 
 int launch_greedy_scan(const u64* mask, int n, int* cluster, int* heads, int* counters, hipStream_t s) {
   if ((n + 63) / 64 > SCAN_MAX_WORDS) { set_error("merge: too many boxes for the scan bitmap"); return -1; }
-  hipLaunchKernelGGL(greedy_scan_kernel, dim3(1), dim3(64), 0, s, mask, n, cluster, heads, counters);
+  hipLaunchKernelGGL(greedy_scan_kernel, dim3(1), dim3(64 * SCAN_WAVES), 0, s, mask, n, cluster, heads, counters);
   SHF_HIP_OK(hipGetLastError());
   return 0;
 }
@@ -237,44 +268,147 @@ __device__ float pairwise_scores(MemberIter& it, int n) {
   return a + b;
 }
 
-__global__ void vote_accumulate_kernel(const float* __restrict__ dets, const u64* __restrict__ mask,
-                                       const int* __restrict__ cluster, int n, const int* __restrict__ heads,
-                                       const int* __restrict__ counters, double* __restrict__ rows,
-                                       int* __restrict__ emit) {
+// one cluster, one thread: the round-1/2 form, kept for clusters beyond the wave kernel's LDS list
+__device__ void vote_one_serial(const float* __restrict__ dets, const u64* __restrict__ mask, const int* __restrict__ cluster,
+                                int nw, int h, int t, int nheads, double* __restrict__ rows, int* __restrict__ emit) {
+  MemberIter it;
+  it.init(mask, cluster, dets, h, nw);
+  int m = 0;
+  while (it.next() >= 0) ++m;
+  double* o = rows + (size_t)t * 5;
+  if (m <= 1) {
+    // a lone box is dropped unless nothing is left after it (test.py:200-206)
+    if (t == nheads - 1) {
+      for (int j = 0; j < 5; ++j) o[j] = (double)dets[h * 5 + j];
+      emit[t] = 1;
+    } else {
+      emit[t] = 0;
+    }
+    return;
+  }
+  float sx1 = 0.f, sy1 = 0.f, sx2 = 0.f, sy2 = 0.f, mx = 0.f;
+  it.init(mask, cluster, dets, h, nw);
+  for (int i = 0; i < m; ++i) {
+    const float* d = dets + (size_t)it.next() * 5;
+    const float sc = d[4];
+    const float px1 = d[0] * sc, py1 = d[1] * sc, px2 = d[2] * sc, py2 = d[3] * sc;
+    if (i == 0) { sx1 = px1; sy1 = py1; sx2 = px2; sy2 = py2; mx = sc; }
+    else { sx1 += px1; sy1 += py1; sx2 += px2; sy2 += py2; mx = fmaxf(mx, sc); }
+  }
+  it.init(mask, cluster, dets, h, nw);
+  const float ssum = pairwise_scores(it, m);
+  o[0] = (double)(sx1 / ssum); o[1] = (double)(sy1 / ssum);
+  o[2] = (double)(sx2 / ssum); o[3] = (double)(sy2 / ssum);
+  o[4] = (double)mx;
+  emit[t] = 1;
+}
+
+// numpy pairwise_sum over a[0..n) (the same recursion as pairwise_scores, on an array)
+__device__ float pairwise_array(const float* a, int n) {
+  if (n < 8) {
+    float res = 0.f;
+    for (int i = 0; i < n; ++i) res += a[i];
+    return res;
+  }
+  if (n <= 128) {
+    float r[8];
+    for (int j = 0; j < 8; ++j) r[j] = a[j];
+    int i = 8;
+    for (; i < n - (n % 8); i += 8)
+      for (int j = 0; j < 8; ++j) r[j] += a[i + j];
+    float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; ++i) res += a[i];
+    return res;
+  }
+  int n2 = n / 2;
+  n2 -= n2 % 8;
+  return pairwise_array(a, n2) + pairwise_array(a + n2, n - n2);
+}
+
+// One WAVE per cluster head.  The members (the head, then the boxes of its mask row that the scan gave to it, ascending)
+// are listed in LDS by all 64 lanes -- a lane filters one 64-box word of the row, a wave prefix sum places its hits --,
+// the fp32 products are formed in parallel, and the order-sensitive parts run on the list: lane c < 4 adds coordinate c
+// in member order (np.sum(axis=0) of the (m, 4) products), every lane forms numpy's pairwise score sum.  Bit-for-bit
+// what the one-thread form computes (round 2: 0.21 ms for the bench image, latency-bound on dependent row loads).
+constexpr int VOTE_CAP = 1024;
+__global__ __launch_bounds__(64) void vote_accumulate_kernel(const float* __restrict__ dets, const u64* __restrict__ mask,
+                                                             const int* __restrict__ cluster, int n,
+                                                             const int* __restrict__ heads,
+                                                             const int* __restrict__ counters, double* __restrict__ rows,
+                                                             int* __restrict__ emit) {
+  __shared__ int idx[VOTE_CAP];
+  __shared__ float prod[VOTE_CAP * 4];
+  __shared__ float scs[VOTE_CAP];
   const int nheads = counters[0];
   const int nw = (n + 63) >> 6;
-  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < nheads; t += gridDim.x * blockDim.x) {
+  const int lane = threadIdx.x;
+  for (int t = blockIdx.x; t < nheads; t += gridDim.x) {
     const int h = heads[t];
-    MemberIter it;
-    it.init(mask, cluster, dets, h, nw);
-    int m = 0;
-    while (it.next() >= 0) ++m;
+    const u64* row = mask + (size_t)h * nw;
+    __syncthreads();   // (the previous cluster's list is dead)
+    if (lane == 0) idx[0] = h;
+    int m = 1;
+    for (int wb = h >> 6; wb < nw; wb += 64) {
+      const int w = wb + lane;
+      u64 cur = w < nw ? row[w] : 0ull, fm = 0;
+      while (cur) {
+        const int b = __ffsll((long long)cur) - 1;
+        cur &= cur - 1;
+        if (cluster[(w << 6) + b] == h) fm |= 1ull << b;
+      }
+      const int cntl = __popcll(fm);
+      int incl = cntl;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += v;
+      }
+      int pos = m + incl - cntl;
+      while (fm) {
+        const int b = __ffsll((long long)fm) - 1;
+        fm &= fm - 1;
+        if (pos < VOTE_CAP) idx[pos] = (w << 6) + b;
+        ++pos;
+      }
+      m += __shfl(incl, 63, 64);
+    }
+    if (m > VOTE_CAP) {   // (wave-uniform) a cluster beyond the list: the serial form
+      if (lane == 0) vote_one_serial(dets, mask, cluster, nw, h, t, nheads, rows, emit);
+      continue;
+    }
     double* o = rows + (size_t)t * 5;
     if (m <= 1) {
       // a lone box is dropped unless nothing is left after it (test.py:200-206)
       if (t == nheads - 1) {
-        for (int j = 0; j < 5; ++j) o[j] = (double)dets[h * 5 + j];
-        emit[t] = 1;
-      } else {
+        if (lane < 5) o[lane] = (double)dets[h * 5 + lane];
+        if (lane == 0) emit[t] = 1;
+      } else if (lane == 0) {
         emit[t] = 0;
       }
       continue;
     }
-    float sx1 = 0.f, sy1 = 0.f, sx2 = 0.f, sy2 = 0.f, mx = 0.f;
-    it.init(mask, cluster, dets, h, nw);
-    for (int i = 0; i < m; ++i) {
-      const float* d = dets + (size_t)it.next() * 5;
+    __syncthreads();
+    float mx = 0.f;
+    for (int i = lane; i < m; i += 64) {
+      const float* d = dets + (size_t)idx[i] * 5;
       const float sc = d[4];
-      const float px1 = d[0] * sc, py1 = d[1] * sc, px2 = d[2] * sc, py2 = d[3] * sc;
-      if (i == 0) { sx1 = px1; sy1 = py1; sx2 = px2; sy2 = py2; mx = sc; }
-      else { sx1 += px1; sy1 += py1; sx2 += px2; sy2 += py2; mx = fmaxf(mx, sc); }
+      prod[i * 4 + 0] = d[0] * sc; prod[i * 4 + 1] = d[1] * sc; prod[i * 4 + 2] = d[2] * sc; prod[i * 4 + 3] = d[3] * sc;
+      scs[i] = sc;
+      mx = fmaxf(mx, sc);
     }
-    it.init(mask, cluster, dets, h, nw);
-    const float ssum = pairwise_scores(it, m);
-    o[0] = (double)(sx1 / ssum); o[1] = (double)(sy1 / ssum);
-    o[2] = (double)(sx2 / ssum); o[3] = (double)(sy2 / ssum);
-    o[4] = (double)mx;
-    emit[t] = 1;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    __syncthreads();
+    const float ssum = pairwise_array(scs, m);
+    if (lane < 4) {
+      float sacc = prod[lane];
+      for (int i = 1; i < m; ++i) sacc += prod[i * 4 + lane];
+      o[lane] = (double)(sacc / ssum);
+    }
+    if (lane == 0) {
+      o[4] = (double)mx;
+      emit[t] = 1;
+    }
   }
 }
 
@@ -319,8 +453,9 @@ int launch_vote_accumulate(const float* sorted5, const u64* mask, const int* clu
   // rows/emit scratch live behind the compacted output: out5 has room for 2n rows (see net.cpp)
   double* rows = out5 + (size_t)n * 5;
   int* emit = (int*)(rows + (size_t)n * 5);
-  hipLaunchKernelGGL(vote_accumulate_kernel, dim3(grid_for(n, 64)), dim3(64), 0, s, sorted5, mask, cluster, n, heads,
-                     counters, rows, emit);
+  // (one wave per cluster head, grid-stride: the head count is only known on the device)
+  hipLaunchKernelGGL(vote_accumulate_kernel, dim3((unsigned)std::min<long long>(std::max(n, 1), 4096)), dim3(64), 0, s, sorted5, mask,
+                     cluster, n, heads, counters, rows, emit);
   hipLaunchKernelGGL(compact_rows_kernel, dim3(1), dim3(1024), 0, s, rows, emit, counters, out5, n_out);
   SHF_HIP_OK(hipGetLastError());
   return 0;
