@@ -1,4 +1,4 @@
-"""The committed bench line (profiles/r02_bench.json, written by bench.py on an MI355X) carries every field
+"""The committed bench line (profiles/r03_bench.json, written by bench.py on an MI355X) carries every field
 the bench contract names, and the committed rocprofv3 summary names the same dominant kernel."""
 import csv
 import json
@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_bench_json_contract():
-    d = json.load(open(os.path.join(ROOT, "profiles", "r02_bench.json")))
+    d = json.load(open(os.path.join(ROOT, "profiles", "r03_bench.json")))
     base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
@@ -26,15 +26,22 @@ def test_bench_json_contract():
     assert r["traffic_measured_in_this_run"] is False            # PMC passes are separate runs (tools/make_profiles.sh)
     assert abs(r["frac_issued"] - 3.0 * r["frac"]) < 1e-9 and "mfma_busy" in r
     c = d["cpu_baseline"]
-    for k in ("value", "unit", "cores", "kind", "sample"):
+    for k in ("value", "unit", "cores", "kind", "sample", "cpu_model"):
         assert k in c, k
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1
+    assert "all five pyramid levels" in c["sample"]               # the whole image's work, not a FLOP-scaled slice
+    # the reduced-precision leg (BASELINE configs C3 / C5 name bf16): outside the timed region, drift-labelled
+    rp = d["reduced_precision"]
+    for k in ("mode", "value", "max_abs_dscore_vs_fp32", "boxes_matched"):
+        assert k in rp and k in rp["also"], k
+    assert rp["mode"] == "bf16" and rp["also"]["mode"] == "f16" and rp["value"] > d["value"]
+    assert 1e-4 < rp["max_abs_dscore_vs_fp32"] < 0.1 and 1e-5 < rp["also"]["max_abs_dscore_vs_fp32"] < 0.02
 
 
 def test_rocprof_summary_names_the_dominant_kernel():
-    d = json.load(open(os.path.join(ROOT, "profiles", "r02_bench_under_rocprof.json")))
+    d = json.load(open(os.path.join(ROOT, "profiles", "r03_bench_under_rocprof.json")))
     name = d["roofline"]["kernel"]
-    rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "r02_bench_kernel_stats.csv"))))
+    rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "r03_bench_kernel_stats.csv"))))
     hit = [r for r in rows if name in r["Name"]]
     assert hit, name
     avg_ms = float(hit[0]["AverageNs"]) / 1e6
@@ -43,16 +50,16 @@ def test_rocprof_summary_names_the_dominant_kernel():
 
 
 def test_committed_pmc_summary_and_layer_table():
-    """profiles/r02_pmc.json (counter passes) and r02_layers.csv (one row per conv launch of an image) are what the
+    """profiles/r03_pmc.json (counter passes) and r03_layers.csv (one row per conv launch of an image) are what the
     roofline numbers can be recomputed from; the layer table covers the whole image's algorithmic work."""
-    d = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc.json")))
-    dom = json.load(open(os.path.join(ROOT, "profiles", "r02_bench.json")))["roofline"]["kernel"]
-    assert dom.startswith("conv_mfma_f16x3_w4")     # a 4-wave split-fp16 kernel (the dual-tile family since round 2)
+    d = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc.json")))
+    dom = json.load(open(os.path.join(ROOT, "profiles", "r03_bench.json")))["roofline"]["kernel"]
+    assert dom.startswith("conv_mfma_f16x3_w4d")    # the dual-tile 4-wave family
     k = d["kernels"][dom]
     for key in ("hbm_bytes_per_launch", "mfma_busy", "effective_clock_ghz", "lds_bank_conflict_frac", "avg_us"):
         assert key in k, key
     assert 0.0 < k["mfma_busy"] <= 1.0
-    rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "r02_layers.csv"))))
+    rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "r03_layers.csv"))))
     assert len(rows) == 19 and rows[0]["layer"] == "conv1_1+conv1_2"
     gf = sum(float(r["algorithmic_gflop"]) for r in rows)
     assert abs(gf - 5021.6) < 2.0          # SURVEY.md 8d: 5021.62 GFLOP per image (the deconv's 0.1 GFLOP aside)
