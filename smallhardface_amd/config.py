@@ -124,6 +124,44 @@ def cfg_reset():
     cfg.update(_fresh())
 
 
+def _toml_value(v):
+    if isinstance(v, bool):
+        return "true" if v else "false"
+    if isinstance(v, (int, float)):
+        return repr(v)
+    if isinstance(v, str):
+        return '"' + v.replace("\\", "\\\\").replace('"', '\\"') + '"'
+    if isinstance(v, (list, tuple)):
+        return "[" + ", ".join(_toml_value(x) for x in v) + "]"
+    return '"' + str(v) + '"'
+
+
+def cfg_dumps(c):
+    """The configuration as TOML text: get_config.py:76-77 (`toml.dump(_sort_dict(cfg), file)`).  The `toml` package is
+    not in this image, so the writer is ours: sorted keys, a table's scalars before its sub-tables, `[A.B]` headers --
+    what `toml` 0.10 emits for nested dicts of scalars and lists; `tomli` reads it back to the same dictionary."""
+    out = []
+
+    def emit(d, prefix):
+        d = _sort_dict(d)
+        for k, v in d.items():
+            if not isinstance(v, dict):
+                out.append("%s = %s" % (k, _toml_value(v)))
+        for k, v in d.items():
+            if isinstance(v, dict):
+                out.append("")
+                out.append("[%s]" % (prefix + k))
+                emit(v, prefix + k + ".")
+
+    emit(dict(c), "")
+    return "\n".join(out).lstrip("\n") + "\n"
+
+
+def cfg_dump(c, file):
+    """get_config.py:76-77."""
+    file.write(cfg_dumps(c))
+
+
 def get_output_dir(imdb_name, net_name=None, output_dir='output', idx=-1):
     """get_config.py:47-66."""
     outdir = osp.abspath(osp.join(cfg.ROOT_DIR, output_dir, cfg.EXP_DIR, imdb_name))

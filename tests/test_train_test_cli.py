@@ -10,6 +10,25 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _stderr_of(r, exp):
+    """What the run wrote to stderr: its own pipe until train_test.py redirects fd 2 into <output_dir>/stderr.log
+    (reference train_test.py:122-124), that file from then on."""
+    text = r.stderr[-1500:]
+    for root, _, files in os.walk(str(exp)):
+        if "stderr.log" in files:
+            text += "\n--- stderr.log ---\n" + open(os.path.join(root, "stderr.log")).read()[-3000:]
+    return text
+
+
+def _run_outputs(exp):
+    """(stderr.log paths, cfgs.txt paths) under an experiment directory."""
+    logs, cfgs = [], []
+    for root, _, files in os.walk(str(exp)):
+        logs += [os.path.join(root, f) for f in files if f == "stderr.log"]
+        cfgs += [os.path.join(root, f) for f in files if f == "cfgs.txt"]
+    return logs, cfgs
+
+
 @pytest.mark.gpu
 def test_cli_writes_wider_detections(tmp_path):
     from PIL import Image
@@ -34,11 +53,18 @@ def test_cli_writes_wider_detections(tmp_path):
                             os.path.join(ROOT, "configs", "smallhardface.toml"), "--amend", "TEST.MODEL", model,
                             "DATA_DIR", str(data), "TEST.GPU_ID", "[0]", "TEST.SCALES", "[100, 300]", "EXP_DIR",
                             str(exp)], cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=600)
-        assert r.returncode == 0, r.stderr[-2000:]
+        assert r.returncode == 0, _stderr_of(r, exp)
         found = []
         for root, _, files in os.walk(str(exp)):
             found += [os.path.join(root, f) for f in files if f.endswith(".txt") and "img" in f]
-        assert len(found) == 2, (found, r.stderr[-1500:])
+        assert len(found) == 2, (found, _stderr_of(r, exp))
+        # train_test.py:122-132: stderr captured beside the results, the non-TRAIN configuration dumped as TOML
+        import tomli
+        logs, cfgs = _run_outputs(exp)
+        assert len(logs) == 1 and len(cfgs) == 1
+        dumped = tomli.loads(open(cfgs[0]).read())
+        assert "TRAIN" not in dumped and dumped["TEST"]["SCALES"] == [100, 300] and dumped["TEST"]["MODEL"] == model
+        assert dumped["EXP_DIR"] == str(exp) and dumped["TEST"]["NO_CACHE"] is True
         runs[fused] = [open(f).read().splitlines() for f in sorted(found)]
     lines = runs["1"][0]
     assert lines[0] == names[0] and int(lines[1]) == len(lines) - 2 and int(lines[1]) >= 1
@@ -59,7 +85,7 @@ def _run_cli(tmp_path, data, model, gpu_id, exp_name, scales="[100, 300]"):
                         os.path.join(ROOT, "configs", "smallhardface.toml"), "--amend", "TEST.MODEL", model,
                         "DATA_DIR", str(data), "TEST.GPU_ID", gpu_id, "TEST.SCALES", scales, "EXP_DIR", str(exp)],
                        cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.returncode == 0, _stderr_of(r, exp)
     found = {}
     for root, _, files in os.walk(str(exp)):
         for f in files:
@@ -92,7 +118,7 @@ def test_cli_one_process_per_gpu_id(tmp_path, n_images, gpu_id):
     caffemodel.write_caffemodel(model, weights.synth_params(H.detector_msg(True), cls_bias=1.0))
     one, _ = _run_cli(tmp_path, data, model, "[0]", "exp_one")
     many, r = _run_cli(tmp_path, data, model, gpu_id, "exp_many")
-    assert len(one) == n_images and sorted(one) == sorted(many), (sorted(one), sorted(many), r.stderr[-1500:])
+    assert len(one) == n_images and sorted(one) == sorted(many), (sorted(one), sorted(many), _stderr_of(r, tmp_path / "exp_many"))
     for f in one:
         assert one[f] == many[f], f           # same process-independent arithmetic: byte-identical files
         assert int(one[f].splitlines()[1]) >= 1

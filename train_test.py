@@ -19,7 +19,7 @@ import sys
 
 import numpy as np
 
-from smallhardface_amd.config import cfg, cfg_from_file, cfg_from_list, get_output_dir
+from smallhardface_amd.config import cfg, cfg_dump, cfg_from_file, cfg_from_list, get_output_dir
 from smallhardface_amd.datasets import ImageList
 from smallhardface_amd.prototxt import manipulate_test
 from smallhardface_amd.test import test_net
@@ -65,6 +65,13 @@ if __name__ == '__main__':
         cfg.NAME_TIME = datetime.datetime.now().strftime('%Y%m%d_%H%M%S')
         imdb = get_imdb(cfg.TEST.DB)
         output_dir = get_output_dir(cfg.TEST.DB, cfg.NAME_TIME)
+        # train_test.py:122-124: from here on the run's stderr goes to <output_dir>/stderr.log (warnings, tracebacks)
+        f = open(osp.join(output_dir, 'stderr.log'), 'w', 1)
+        sys.stderr.flush()
+        os.dup2(f.fileno(), sys.stderr.fileno())
         target_test = osp.join(output_dir, 'test.prototxt')
         manipulate_test(cfg.TEST.PROTOTXT, target_test)
+        with open(osp.join(output_dir, 'cfgs.txt'), 'w') as cf:   # train_test.py:131-132
+            cfg_dump({i: cfg[i] for i in cfg if i != 'TRAIN'}, cf)
         test_net(imdb, output_dir, target_test, no_cache=cfg.TEST.NO_CACHE)
+        f.close()
