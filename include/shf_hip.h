@@ -228,6 +228,15 @@ int shf_prof_num_classes(shf_net* net);
 const char* shf_prof_class_name(shf_net* net, int cls);
 int shf_prof_read(shf_net* net, int cls, int64_t* launches, double* total_ms, double* flops, double* bytes);
 int shf_prof_reset(shf_net* net);
+/* Calibration of the roofline's MFMA bound on the box at hand: the issued TFLOP/s a pure stream of
+ * v_mfma_f32_32x32x16_f16 (bf16 != 0: _bf16) sustains with the convolution kernels' register diet (one wave per SIMD,
+ * 8 accumulator tiles, 3 products per fragment pair) and NO memory traffic, for operands with random signs and
+ * mantissas of which zero_eighths/8 of the activation fragments are zero (constant_operands != 0: every element 1.0 --
+ * the nominal-peak case).  The chip is power-limited under matrix load and the limit depends on the operands' bit
+ * toggling, so this -- not the 2.5 PFLOP/s of non-toggling operands -- is what a kernel that moved its bytes for free
+ * could reach.  Runs (reps + 1) / 2 settling launches, then times `reps` launches of `iters` x 24 MFMAs per wave on a
+ * private stream; synchronises.  No counterpart in the reference (measurement only). */
+int shf_calib_matrix_pipe(int bf16, int zero_eighths, int constant_operands, int iters, int reps, double* tflops);
 /* stream synchronise (end of a timed region) */
 int shf_net_sync(shf_net* net);
 

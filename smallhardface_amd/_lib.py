@@ -115,6 +115,7 @@ def _declare(lib):
         "shf_prof_class_name": (C.c_char_p, [vp, ci]),
         "shf_prof_read": (ci, [vp, ci, C.POINTER(C.c_int64), dp, dp, dp]),
         "shf_prof_reset": (ci, [vp]),
+        "shf_calib_matrix_pipe": (ci, [ci, ci, ci, ci, ci, dp]),
         "shf_net_sync": (ci, [vp]),
     }
     for name, (res, args) in sig.items():

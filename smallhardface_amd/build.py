@@ -24,6 +24,7 @@ SOURCES = [
     ("tail.hip", ["-ffp-contract=off"]),
     ("merge.hip", ["-ffp-contract=off"]),
     ("pre.hip", ["-ffp-contract=off"]),
+    ("calib.hip", []),
     ("net.cpp", []),
 ]
 HEADERS = ["shf_internal.h", "conv_common.h", "proto_text.h", os.path.join("..", "..", "include", "shf_hip.h")]

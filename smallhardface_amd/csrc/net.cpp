@@ -400,6 +400,9 @@ static int conv_out(int n, int k, int pad, int stride, int dil) {
 
 }  // namespace shf
 
+namespace shf {
+int calib_matrix_pipe(int bf16, int zero_eighths, int constant, int iters, int reps, double* tflops);   // calib.hip
+}
 using namespace shf;
 
 // configuration shared by a net and every lane cloned from it: the arithmetic mode and what the reference's Python
@@ -2294,6 +2297,15 @@ int shf_prof_reset(shf_net* net) {
     net->prof.launches[i] = 0;
     net->prof.ms[i] = net->prof.flops[i] = net->prof.bytes[i] = 0;
   }
+  return 0;
+  API_END(-1)
+}
+int shf_calib_matrix_pipe(int bf16, int zero_eighths, int constant_operands, int iters, int reps, double* tflops) {
+  API_BEGIN
+  if (!tflops || iters < 1 || reps < 1 || zero_eighths < 0 || zero_eighths > 8)
+    throw std::runtime_error("calib_matrix_pipe: bad arguments");
+  const int rc = calib_matrix_pipe(bf16, zero_eighths, constant_operands, iters, reps, tflops);
+  if (rc != 0) throw std::runtime_error(std::string("calib_matrix_pipe: ") + hipGetErrorString((hipError_t)rc));
   return 0;
   API_END(-1)
 }

@@ -25,6 +25,10 @@ def test_bench_json_contract():
     assert r["traffic"] is None or r["traffic"] > 0
     assert r["traffic_measured_in_this_run"] is False            # PMC passes are separate runs (tools/make_profiles.sh)
     assert abs(r["frac_issued"] - 3.0 * r["frac"]) < 1e-9 and "mfma_busy" in r
+    if "matrix_pipe_sustained" in r:     # (lines written before the calibration leg existed do not carry it)
+        m = r["matrix_pipe_sustained"]
+        assert m["operands_random"] < m["operands_random_half_of_activations_zero"] < m["operands_constant"] <= 1.02 * r["peak"]
+        assert abs(m["frac_issued_of_sustained"] - r["issued_mfma_achieved"] / m["operands_random_half_of_activations_zero"]) < 1e-3
     c = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample", "cpu_model"):
         assert k in c, k

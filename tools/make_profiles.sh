@@ -18,7 +18,7 @@ out=$root/gpurun_out/prof_$tag
 dst=$root/gpurun_out/profiles_$tag
 mkdir -p $out $dst
 cd /tmp && export TMPDIR=/tmp && cd $root
-BENCH_PMC="bench.py --steps 2 --warmup 1 --no-events --no-cpu-baseline --no-latency --no-reduced"
+BENCH_PMC="bench.py --steps 2 --warmup 1 --no-events --no-cpu-baseline --no-latency --no-reduced --no-calib"
 rocprofv3 --kernel-trace --output-format csv -d $out/trace -- python3 $BENCH_PMC > $out/trace.log 2>&1
 i=0
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES"; do
@@ -27,7 +27,7 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GR
 done
 python3 tools/layer_table.py $out $dst $tag > $out/layer_table.log 2>&1
 tail -40 $out/layer_table.log
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --steps 10 --warmup 2 --no-reduced > $out/bench_under_rocprof.out 2> $out/bench_under_rocprof.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --steps 10 --warmup 2 --no-reduced --no-calib > $out/bench_under_rocprof.out 2> $out/bench_under_rocprof.log
 grep '^{"metric"' $out/bench_under_rocprof.out | tail -1 > $dst/${tag}_bench_under_rocprof.json
 cp $(ls $out/stats/*/*kernel_stats.csv | head -1) $dst/${tag}_bench_kernel_stats.csv
 # the bench line quotes traffic / MFMA-busy from the committed counter file: make this run's the committed one
