@@ -491,26 +491,37 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_kernel(ConvK p) {
 // end-to-end error of the scheme: tools/single_acc_study.py).  What makes room for the second halo tile's hand-over
 // registers is a CHUNK of 16 input channels instead of 32: a stage is still one kernel row of a chunk = 144 MFMAs per
 // wave (3 taps x 1 k-step x 2 tiles x 24), its three weight slabs are 30 KB instead of 55, a halo tile 30 KB instead
-// of 48, and a hand-over moves 2 x 6 pieces per thread.  LDS rows are [hi 16 halfs | lo 16 halfs | 16 B pad] = 80 B
-// (conflict-free ds_read_b128 over 16 consecutive rows; +224 B per halo-tile row puts the second pixel row of an A
-// fragment on the other half of the banks).  The six half-steps of a stage (tap kx, tile t) are software-pipelined
-// like the six k-steps of the single-tile kernel: while (kx, t) runs, the A fragments of the next (kx, t) -- and, on
-// even half-steps, the B fragments of tap kx + 1 -- are read.
+// of 48, and a hand-over moves 2 x 6 pieces per thread.  The six half-steps of a stage (tap kx, tile t) are
+// software-pipelined like the six k-steps of the single-tile kernel: while (kx, t) runs, the A fragments of the next
+// (kx, t) -- and, on even half-steps, the B fragments of tap kx + 1 -- are read.
+//
+// HALO TILES ARE DOUBLE-BUFFERED (round 3): with one buffer per tile the hand-over was a serial section -- barrier,
+// convert + park 12 pieces, barrier, first fragment reads -- that cost the dominant launch 7.6 % with the matrix pipe
+// idle (tools/experiments/w4d_power_ablation.sh: no_halo).  Chunk c + 1's pieces are now requested during kernel row
+// 1 of chunk c and converted + parked into the OTHER buffer pair under the MFMAs of kernel row 2, two pieces per
+// half-step; the next stage's barrier -- which the weights need anyway -- publishes them.  Four halo tiles fit in
+// 160 KB because the layout is PLANAR, without per-row padding: plane q (hi k 0-7 | hi k 8-15 | lo k 0-7 | lo k 8-15)
+// holds one 16-byte piece per halo pixel, rows of 24 pixels (384 B = 8 sixteen-byte slots mod 16, so the two pixel
+// rows a ds_read_b128 lane group touches land on complementary halves of the 256-B bank row), planes 32 B apart
+// mod 128 (the 8-lane groups of the parking ds_write_b128 -- 2 pixels x 4 planes -- cover all 32 banks).  Every
+// fragment address is lane offset + immediate: tap kx = +16 B, kernel row = +384 B, lo = +2 planes.
 template <bool IN_SPLIT, int MT_, int NTILE, int NP = 3, bool BF = false>
 __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4d_kernel(ConvK p) {
   static_assert(!BF || (NP == 1 && !IN_SPLIT), "bf16 mode: one product, fp32 activations in HBM");
   static_assert((MT_ == 4 || MT_ == 2) && (NTILE == 1 || NTILE == 2), "16- or 8-row tiles, one or two per block");
   constexpr int MT = MT_, TH = 4 * MT, TW = 16, HTW = 18, HTH = TH + 2, HP = HTH * HTW;
-  constexpr int KC = 16, ROWB = 80, ROWPAD = 224, BN = 128, NT = 256;
-  constexpr int HPITCH = HTW * ROWB + ROWPAD;        // 1664 B per halo-tile row
-  constexpr int AS_B = HTH * HPITCH;                  // 29 952 B per halo tile
+  constexpr int KC = 16, BN = 128, NT = 256;
+  constexpr int PROW = 24 * 16;                       // 384 B per halo-tile row of a plane (18 pixels used)
+  constexpr int PLANE = HTH * PROW + 32;              // 6 944 B (16-row tiles) / 3 872 B (8-row tiles)
+  constexpr int AS_B = 4 * PLANE;                     // 27 776 B / 15 488 B per halo tile
+  constexpr int NB_B = NTILE * AS_B;                  // one buffer set (the tiles of one chunk)
   constexpr int WROWB = 64;                           // weight rows: no padding, the 16-byte pieces rotated by row / 4
   constexpr int SLAB_B = BN * WROWB;                  // 8 192 B per tap slab
   constexpr int ALD = (HP * 4 + NT - 1) / NT;         // 16-byte halo pieces per thread and tile: 6 (16 rows) or 3
   constexpr float LO_SCALE = 2048.0f;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* As = smem;                           // [NTILE][HTH][HPITCH]
-  unsigned char* Bs = smem + NTILE * AS_B;            // [2 buffers][3 taps][BN][ROWB]
+  unsigned char* As = smem;                           // [2 buffer sets][NTILE][4 planes][HTH][24 px][16 B]
+  unsigned char* Bs = smem + 2 * NB_B;                // [2 buffers][3 taps][BN][64 B]
   float* biasL = (float*)(Bs + 2 * 3 * SLAB_B);       // [BN]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -570,7 +581,6 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4d_kernel(ConvK p) {
   };
   halo_offsets(g0, 0, true);
   if constexpr (NTILE == 2) halo_offsets(g1, 1, has1);
-  const bool a_last = tid + NT * (ALD - 1) < HP * 4;  // the ragged last piece exists for this thread
   // chunk c16 -> byte offset inside a pixel
   auto chunk_off = [&](int c16) -> unsigned {
     return IN_SPLIT ? (unsigned)((c16 >> 1) * 128 + (c16 & 1) * 32) : (unsigned)(c16 * 64);
@@ -595,12 +605,16 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4d_kernel(ConvK p) {
     return ActScale{conv_pk_pow2_f16(e1 - lo_shift), conv_pk_pow2_f16(e1), conv_pk_pow2_f16(e1 - 11), conv_pk_pow2_f16(e - e1)};
   };
   const ActScale as0 = act_scale(e_t0), as1 = act_scale(e_t1);
-  // piece as fetched -> the 16 bytes (split input) / the hi half4 | lo half4 pair (fp32 input) that go to LDS
-  auto convert = [&](float4& v, bool valid, const ActScale& sc_) {
-    if (!valid) v = make_float4(0.f, 0.f, 0.f, 0.f);
-    struct { h2 hi1, lo1, f2; } sc = {__builtin_bit_cast(h2, sc_.hi1), __builtin_bit_cast(h2, sc_.lo1), __builtin_bit_cast(h2, sc_.f2)};
+  // piece as fetched -> the 16 bytes (split input) / the hi half4 | lo half4 pair (fp32 input) that go to LDS.  A piece
+  // outside the image (bit `vbit` of a_valid clear; it fetched the member's first bytes) becomes zeros by way of its
+  // FACTOR -- no select on the data and, above all, no branch: the parking runs inside the MFMA stages, and control flow
+  // there would split the region the sched_group_barriers order
+  auto convert = [&](float4& v, int vbit, const ActScale& sc_) {
+    const unsigned keep = (unsigned)((int)(a_valid << (31 - vbit)) >> 31);   // all ones / zero
+    struct { h2 hi1, lo1, f2; } sc = {__builtin_bit_cast(h2, sc_.hi1 & keep), __builtin_bit_cast(h2, sc_.lo1 & keep),
+                                      __builtin_bit_cast(h2, sc_.f2)};
     if constexpr (IN_SPLIT) {
-      const h2 f1 = __builtin_bit_cast(h2, sc_.pk_f1);
+      const h2 f1 = __builtin_bit_cast(h2, sc_.pk_f1 & keep);
       float* e = &v.x;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
@@ -612,7 +626,8 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4d_kernel(ConvK p) {
       _Float16 h[4];
       bf16x4_of(v, h);   // (no activation exponent: bf16 has fp32's range; the weights' pack is unscaled)
       const half2v h01 = {h[0], h[1]}, h23 = {h[2], h[3]};
-      v = make_float4(__builtin_bit_cast(float, h01), __builtin_bit_cast(float, h23), 0.f, 0.f);
+      v = make_float4(__builtin_bit_cast(float, __builtin_bit_cast(unsigned, h01) & keep),
+                      __builtin_bit_cast(float, __builtin_bit_cast(unsigned, h23) & keep), 0.f, 0.f);
     } else {
       const f32x2 x01 = {v.x, v.y}, x23 = {v.z, v.w};
       // (lo through the split activation format's 2^11, like a producer's epilogue + the staging above would: the two
@@ -624,15 +639,25 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4d_kernel(ConvK p) {
                       __builtin_bit_cast(float, (l01 * sc.lo1) * sc.f2), __builtin_bit_cast(float, (l23 * sc.lo1) * sc.f2));
     }
   };
-  auto store_piece = [&](const float4& v, int t, int j) {
+  // (set_off: byte offset of the buffer set the pieces go to)
+  auto store_piece = [&](const float4& v, int t, int j, unsigned set_off) {
     const int idx = tid + NT * j;
     const int hp = idx >> 2, q = idx & 3;
-    unsigned char* row = As + t * AS_B + hp * ROWB + (hp / HTW) * ROWPAD;
+    int hy = hp / HTW, hx = hp - hy * HTW;
+    if (NT * (j + 1) > HP * 4) {
+      // the ragged last piece: threads past the tile's end store theirs in the unused columns 18..23 of the first rows
+      // (no branch inside the stage -- it would split the scheduling region)
+      const int hpd = hp - HP, ry = hpd / 6;
+      const bool past = idx >= HP * 4;
+      hy = past ? ry : hy;
+      hx = past ? HTW + hpd - ry * 6 : hx;
+    }
+    unsigned char* pix = As + set_off + t * AS_B + hy * PROW + hx * 16;
     if constexpr (IN_SPLIT) {
-      *(float4*)(row + q * 16) = v;
+      *(float4*)(pix + q * PLANE) = v;
     } else {
-      *(float2*)(row + q * 8) = make_float2(v.x, v.y);
-      *(float2*)(row + 32 + q * 8) = make_float2(v.z, v.w);
+      *(float2*)(pix + (q >> 1) * PLANE + (q & 1) * 8) = make_float2(v.x, v.y);
+      *(float2*)(pix + (2 + (q >> 1)) * PLANE + (q & 1) * 8) = make_float2(v.z, v.w);
     }
   };
 
@@ -649,9 +674,12 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4d_kernel(ConvK p) {
     unsigned char* bd_ = Bs + buf * (3 * SLAB_B);
 #pragma unroll
     for (int r = r0; r < r0 + n; ++r) {
+      // (inline asm, not __builtin_amdgcn_global_load_lds: the compiler cannot tell the DMA's LDS destination (weights)
+      // from the halo buffers, and would drain vmcnt -- i.e. wait out the weight fetch it has just issued -- before
+      // every ds_write that parks a halo piece inside the stage.  Completion is waited for by hand at the stage start.)
       const unsigned char* ub = ws_ + w_goff(r);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ub + lane16),
-                                       (__attribute__((address_space(3))) void*)(bd_ + w_loff(r)), 16, 0, 0);
+      const unsigned lds = (unsigned)(__SIZE_TYPE__)(__attribute__((address_space(3))) unsigned char*)(bd_ + w_loff(r));
+      asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds), "v"(lane16), "s"(ub) : "m0");
     }
   };
 
@@ -671,7 +699,9 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4d_kernel(ConvK p) {
   row_to_pixel(i, dy, px);
   int a_off[MT], b_off[2];
 #pragma unroll
-  for (int t = 0; t < MT; ++t) a_off[t] = (wm * 2 * MT + t * 2 + dy) * HPITCH + px * ROWB + kh * 16;
+  for (int t = 0; t < MT; ++t) a_off[t] = kh * PLANE + (wm * 2 * MT + t * 2 + dy) * PROW + px * 16;
+  int a_delta = NB_B;              // the chunk's buffer set lives in a_off: += a_delta after every chunk but the last
+  unsigned park_off = NB_B;        // the buffer set the NEXT chunk is parked in
 #pragma unroll
   for (int t = 0; t < 2; ++t)   // the lane's hi piece (the lo piece sits two rotated positions further: b_off ^ ... below)
     b_off[t] = (wn * 64 + t * 32 + i) * WROWB + ((kh + ((wn * 64 + t * 32 + i) >> 2)) & 3) * 16;
@@ -685,24 +715,26 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4d_kernel(ConvK p) {
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int j = 0; j < ALD; ++j) {
-    convert(areg0[j], (a_valid >> j) & 1, as0);
-    if (j + 1 < ALD || a_last) store_piece(areg0[j], 0, j);
+    convert(areg0[j], j, as0);
+    store_piece(areg0[j], 0, j, 0u);
   }
   if constexpr (NTILE == 2) {
 #pragma unroll
     for (int j = 0; j < ALD; ++j) {
-      convert(areg1[j], (a_valid >> (8 + j)) & 1, as1);
-      if (j + 1 < ALD || a_last) store_piece(areg1[j], 1, j);
+      convert(areg1[j], 8 + j, as1);
+      store_piece(areg1[j], 1, j, 0u);
     }
   }
 
-  // one stage = kernel row KY of the 16-channel chunk c; HANDOVER (last kernel row of a chunk but the last): fetch,
-  // convert and park both halo tiles of chunk c + 1
-  auto stage = [&](int c, auto KY_, auto HAND_) {
+  // one stage = kernel row KY of the 16-channel chunk c.  MODE 1 (kernel row 1 of a chunk that has a successor):
+  // request the pieces of chunk c + 1's halo tiles; MODE 2 (kernel row 2): convert them and park them in the other
+  // buffer set, spread over the half-steps
+  auto stage = [&](int c, auto KY_, auto MODE_) {
     constexpr int ky = decltype(KY_)::value;
-    constexpr bool HANDOVER = decltype(HAND_)::value != 0;
+    constexpr int MODE = decltype(MODE_)::value;
     const int st = c * 3 + ky;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of W(st) has landed
+    // this wave's share of W(st) (and, MODE 2, its halo pieces) has landed; its parked pieces are in LDS
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();
     const int st_next = st + 1 < NST ? st + 1 : st;   // the last stage re-fetches itself (unused) instead of branching
     const int buf_next = (st + 1) & 1;
@@ -710,11 +742,11 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4d_kernel(ConvK p) {
     const unsigned char* Bst = Bs + (st & 1) * (3 * SLAB_B);
     half8 fa[2][2 * MT], fb[2][4];
     auto load_a = [&](int h, half8* a) {              // half-step h = NTILE kx + tile
-      const unsigned char* Ap = As + (h % NTILE) * AS_B + ky * HPITCH + (h / NTILE) * ROWB;
+      const unsigned char* Ap = As + (h % NTILE) * AS_B + ky * PROW + (h / NTILE) * 16;
 #pragma unroll
       for (int t = 0; t < MT; ++t) {
         a[2 * t] = *(const half8*)(Ap + a_off[t]);
-        a[2 * t + 1] = *(const half8*)(Ap + a_off[t] + 32);
+        a[2 * t + 1] = *(const half8*)(Ap + a_off[t] + 2 * PLANE);
       }
     };
     auto load_b = [&](int kx, half8* bf) {
@@ -729,6 +761,9 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4d_kernel(ConvK p) {
     load_b(0, fb[0]);
     __builtin_amdgcn_sched_barrier(0);
     constexpr int NH = 3 * NTILE;                     // half-steps per stage
+    constexpr int NPC = NTILE * ALD;                  // pieces per thread and chunk
+    constexpr int PP = (NPC + NH - 1) / NH;           // pieces parked per half-step (MODE 2): 2 or 1
+    constexpr int PARK_VALU = IN_SPLIT ? 4 : 7;       // vector instructions the scheduler may put beside one MFMA
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
       constexpr int DMA_N2[6] = {1, 1, 1, 1, 1, 1}, DMA_J2[6] = {0, 1, 2, 3, 4, 5};
@@ -742,9 +777,8 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4d_kernel(ConvK p) {
       if (tl == 0 && kx + 1 < 3) { load_b(kx + 1, fb[(kx + 1) & 1]); n_ds += 4; }
       if (dma_n) dma_w(st_next, buf_next, dma_j, dma_n);
       int n_vmem = dma_n;
-      if constexpr (HANDOVER) {
-        // tile 0's / tile 1's pieces of the next chunk are requested in the first half-steps (converted and parked
-        // after the stage)
+      if constexpr (MODE == 1) {
+        // tile 0's / tile 1's pieces of the next chunk are requested in the first half-steps
         if (h == 0) {
 #pragma unroll
           for (int j = 0; j < ALD; ++j) areg0[j] = *(const float4*)((const char*)g0.in + (a_goff[0][j] + coff));
@@ -753,6 +787,21 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4d_kernel(ConvK p) {
 #pragma unroll
           for (int j = 0; j < ALD; ++j) areg1[j] = *(const float4*)((const char*)g1.in + (a_goff[NTILE - 1][j] + coff));
           n_vmem += ALD;
+        }
+      }
+      int n_park = 0;
+      if constexpr (MODE == 2) {
+#pragma unroll
+        for (int k = h * PP; k < (h + 1) * PP && k < NPC; ++k) {
+          const int t = k / ALD, j = k % ALD;
+          if (t == 0) {
+            convert(areg0[j], j, as0);
+            store_piece(areg0[j], 0, j, park_off);
+          } else {
+            convert(areg1[j], 8 + j, as1);
+            store_piece(areg1[j], 1, j, park_off);
+          }
+          ++n_park;
         }
       }
       auto mfmas = [&](f32x16 (&acc)[MT][2]) {
@@ -778,43 +827,42 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4d_kernel(ConvK p) {
       };
       if (tl) mfmas(acc1);
       else mfmas(acc0);
-      if (h + 1 < NH) {
-        // next half-step's fragment reads go out under the first MFMAs, the VMEM issues over the rest
+      constexpr int NM = 2 * NP * MT;                 // MFMAs of the half-step
+      if (h + 1 < NH || n_park > 0) {
+        // next half-step's fragment reads go out under the first MFMAs, the VMEM issues and the parking (vector
+        // instructions of a piece, then its LDS store) over the rest
+        const int n_first = n_ds < NM ? n_ds : NM;
 #pragma unroll
-        for (int g = 0; g < (n_ds < 2 * NP * MT ? n_ds : 2 * NP * MT); ++g) {
+        for (int g = 0; g < n_first; ++g) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
           __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
+        const int n_rest = NM > n_first + 2 ? NM - n_first - 2 : 0;
+        const int per_piece = n_park > 0 ? (n_rest / n_park > 0 ? n_rest / n_park : 1) : 0;   // MFMA slots per parked piece
 #pragma unroll
-        for (int g = 0; g < (2 * NP * MT > n_ds + 2 ? 2 * NP * MT - n_ds - 2 : 0); ++g) {
+        for (int g = 0; g < n_rest; ++g) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
           if (g < n_vmem) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+          if (n_park > 0) {
+            __builtin_amdgcn_sched_group_barrier(0x002, PARK_VALU, 0);
+            if (g % per_piece == per_piece - 1 && g / per_piece < n_park)
+              __builtin_amdgcn_sched_group_barrier(0x200, IN_SPLIT ? 1 : 2, 0);
+          }
         }
       }
       __builtin_amdgcn_sched_barrier(0);
-    }
-    if constexpr (HANDOVER) {
-      __syncthreads();  // every wave is done reading the halo tiles of chunk c
-#pragma unroll
-      for (int j = 0; j < ALD; ++j) {
-        convert(areg0[j], (a_valid >> j) & 1, as0);
-        if (j + 1 < ALD || a_last) store_piece(areg0[j], 0, j);
-      }
-      if constexpr (NTILE == 2) {
-#pragma unroll
-        for (int j = 0; j < ALD; ++j) {
-          convert(areg1[j], (a_valid >> (8 + j)) & 1, as1);
-          if (j + 1 < ALD || a_last) store_piece(areg1[j], 1, j);
-        }
-      }
     }
   };
   using std::integral_constant;
 #pragma unroll 1
   for (int c = 0; c + 1 < nchunks; ++c) {
     stage(c, integral_constant<int, 0>{}, integral_constant<int, 0>{});
-    stage(c, integral_constant<int, 1>{}, integral_constant<int, 0>{});
-    stage(c, integral_constant<int, 2>{}, integral_constant<int, 1>{});
+    stage(c, integral_constant<int, 1>{}, integral_constant<int, 1>{});
+    stage(c, integral_constant<int, 2>{}, integral_constant<int, 2>{});
+#pragma unroll
+    for (int t = 0; t < MT; ++t) a_off[t] += a_delta;
+    a_delta = -a_delta;
+    park_off = NB_B - park_off;
   }
   stage(nchunks - 1, integral_constant<int, 0>{}, integral_constant<int, 0>{});
   stage(nchunks - 1, integral_constant<int, 1>{}, integral_constant<int, 0>{});
@@ -1474,8 +1522,9 @@ static int launch_f16x3_t(const ConvArgs* as, int n, hipStream_t s) {
     if (w4_short_k(as) && knobs().w4_mt == 0) n2 = 0;          // two single-tile blocks per CU (w4_pick_mt)
     if (knobs().w4d_ntile == 1) n2 = 0;
     if (knobs().w4d_ntile == 2) n2 = tiles;
-    const size_t as_b = (size_t)(th + 2) * (18 * 80 + 224);
-    const size_t lds1 = as_b + 2 * 3 * (size_t)BN * 64 + BN * sizeof(float), lds2 = lds1 + as_b;
+    // two buffer sets of halo tiles (4 planes of (th + 2) rows x 24 pixels x 16 B, + 32 B), the weight double buffer, biases
+    const size_t as_b = 4 * ((size_t)(th + 2) * 24 * 16 + 32);
+    const size_t lds1 = 2 * as_b + 2 * 3 * (size_t)BN * 64 + BN * sizeof(float), lds2 = lds1 + 2 * as_b;
 #define SHF_W4D_LAUNCH(SPLIT, MTV, NTV, GRID, LDS)                                                                        \
     {                                                                                                                    \
       if (a.bf16) hipLaunchKernelGGL((conv_mfma_f16x3_w4d_kernel<false, MTV, NTV, 1, true>), GRID, dim3(256), LDS, s, p);  \

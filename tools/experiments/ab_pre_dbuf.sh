@@ -1,0 +1,13 @@
+set -u
+cd $GRAFT_REPO_ROOT
+python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "conv or knob or four_wave or mfma" 2>&1 | tail -5
+for i in 1 2; do
+python bench.py --steps 30 --warmup 3 --no-cpu-baseline --no-reduced --no-latency --no-calib 2>/dev/null | tail -1 > gpurun_out/ab_new$i.json
+SHF_LIB=$GRAFT_REPO_ROOT/variants/pre_dbuf.so python bench.py --steps 30 --warmup 3 --no-cpu-baseline --no-reduced --no-latency --no-calib 2>/dev/null | tail -1 > gpurun_out/ab_old$i.json
+done
+python - <<'PY'
+import json
+for n in ("new1","old1","new2","old2"):
+    d=json.load(open("gpurun_out/ab_%s.json"%n)); r=d["roofline"]
+    print(n, "%.2f img/s"%d["value"], {k.replace("conv_mfma_f16x3_",""):v for k,v in r["kernel_ms_per_image"].items() if "w4d" in k})
+PY

@@ -6,7 +6,8 @@
 //   TYPE    0: v_mfma_f32_32x32x16_f16   1: v_mfma_f32_32x32x16_bf16   2: v_mfma_f32_16x16x32_f16
 //   RANDOM  0: every fragment register holds 1.0   1: random sign + mantissa, exponents spread over 8 binades
 //   REFRESH 1: every fragment gets new mantissa / sign bits every 24 MFMAs (a half-step of the conv)
-//   ZERO8   eighths of the ACTIVATION dwords that are zero (post-ReLU maps)
+//   ZERO8   eighths of the ACTIVATION dwords (second MFMA source) that are zero (post-ReLU maps); 16 + n: n eighths of the
+//           WEIGHT dwords (first MFMA source) instead
 //   ORDER   0: the conv kernel's order (tm outer, tn inner)   1: snake (one operand changes per MFMA)
 //   TRUNC   low mantissa bits forced to zero in the lo fragments (a[odd], b[odd])
 // hipcc --offload-arch=gfx950 -O3 tools/mfma_power.hip -o tools/bin/mfma_power && ./tools/bin/mfma_power
@@ -45,7 +46,7 @@ __global__ __launch_bounds__(256) void k(float* out, int iters) {
   for (int i = 0; i < 8; ++i) for (int j = 0; j < 4; ++j) {
     seed = mix(seed + 0x9e3779b9u);
     A[i][j] = RANDOM == 0 ? ONE : rnd_pair<TYPE>(seed);
-    K[i][j] = (int)((seed >> 16) & 7) < ZERO8 ? 0u : 0xFFFFFFFFu;
+    K[i][j] = (ZERO8 < 16 && (int)((seed >> 16) & 7) < ZERO8) ? 0u : 0xFFFFFFFFu;
     if (i & 1) K[i][j] &= TMASK;
     A[i][j] &= K[i][j];
   }
@@ -53,6 +54,7 @@ __global__ __launch_bounds__(256) void k(float* out, int iters) {
     seed = mix(seed + 0x9e3779b9u);
     B[i][j] = RANDOM == 0 ? ONE : rnd_pair<TYPE>(seed);
     if (i & 1) B[i][j] &= TMASK;
+    if (ZERO8 >= 16 && (int)((seed >> 16) & 7) < ZERO8 - 16) B[i][j] = 0u;
   }
   for (int it = 0; it < iters; ++it) {
     if (REFRESH) {
@@ -134,6 +136,7 @@ int main() {
   run<0, 1, 0, 4, 0, 0>("f16 random, act half zero");
   run<0, 1, 0, 5, 0, 0>("f16 random, act 5/8 zero");
   run<0, 1, 0, 8, 0, 0>("f16 random, act all zero");
+  run<0, 1, 0, 20, 0, 0>("f16 random, WEIGHTS half zero");
   run<0, 1, 0, 0, 1, 0>("f16 random, snake order");
   run<0, 1, 0, 4, 1, 0>("f16 random, half zero, snake");
   run<0, 1, 0, 4, 0, 3>("f16 random, half zero, lo 8 bits");
