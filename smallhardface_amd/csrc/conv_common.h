@@ -478,6 +478,14 @@ __device__ __forceinline__ void conv_epilogue_regs_tail(float (&v)[16], const fl
   }
   constexpr int ORD[4] = {0, 8, 4, 12};
   float4 o[4];
+  // max |output| of the tile on the BIT PATTERNS (sign cleared, they order like the magnitudes): one and / max3 per two
+  // values instead of fmaxf's NaN-quieting float sequence -- and a NaN, which fmaxf would drop, reaches the range flag
+  unsigned tmax = 0u;
+  auto umax3 = [](unsigned t, float x, float y) {
+    const unsigned p = __builtin_bit_cast(unsigned, x) & 0x7fffffffu, q = __builtin_bit_cast(unsigned, y) & 0x7fffffffu;
+    const unsigned m = p > q ? p : q;
+    return t > m ? t : m;           // v_max3_u32
+  };
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     cs_f32x2 a = cs_f32x2{v[ORD[g]], v[ORD[g] + 1]} + cs_f32x2{bias16[g].x, bias16[g].y};
@@ -488,9 +496,12 @@ __device__ __forceinline__ void conv_epilogue_regs_tail(float (&v)[16], const fl
       auto relu1 = [](float x) { const int q = __builtin_bit_cast(int, x); return __builtin_bit_cast(float, q > 0 ? q : 0); };
       o[g] = make_float4(relu1(o[g].x), relu1(o[g].y), relu1(o[g].z), relu1(o[g].w));
     }
+    tmax = umax3(umax3(tmax, o[g].x, o[g].y), o[g].z, o[g].w);
+  }
+  {
     // (only pixels inside the image count: the unit's max must not depend on how the launch tiles the map)
-    const float m4 = fmaxf(fmaxf(fabsf(o[g].x), fabsf(o[g].y)), fmaxf(fabsf(o[g].z), fabsf(o[g].w)));
-    amax = valid ? fmaxf(amax, m4) : amax;
+    const unsigned am = __builtin_bit_cast(unsigned, amax);
+    amax = __builtin_bit_cast(float, valid && tmax > am ? tmax : am);
   }
   if (pix_main && valid) {
     if (main_split) {

@@ -1,9 +1,9 @@
 set -u
 cd $GRAFT_REPO_ROOT
-python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "conv or knob or four_wave or mfma" 2>&1 | tail -5
+[ "${2:-}" = "test" ] && python -m pytest tests/test_gpu_parity.py tests/test_gpu_magnitudes.py -x -q -m gpu 2>&1 | tail -3
 for i in 1 2; do
 python bench.py --steps 30 --warmup 3 --no-cpu-baseline --no-reduced --no-latency --no-calib 2>/dev/null | tail -1 > gpurun_out/ab_new$i.json
-SHF_LIB=$GRAFT_REPO_ROOT/variants/pre_dbuf.so python bench.py --steps 30 --warmup 3 --no-cpu-baseline --no-reduced --no-latency --no-calib 2>/dev/null | tail -1 > gpurun_out/ab_old$i.json
+SHF_LIB=$GRAFT_REPO_ROOT/variants/${1:-pre_dbuf}.so python bench.py --steps 30 --warmup 3 --no-cpu-baseline --no-reduced --no-latency --no-calib 2>/dev/null | tail -1 > gpurun_out/ab_old$i.json
 done
 python - <<'PY'
 import json

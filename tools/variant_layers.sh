@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp && cd $root
 run() {
   name=$1; shift
   rm -rf $out/tr_$name
-  rocprofv3 --kernel-trace --output-format csv -d $out/tr_$name -- python3 bench.py --steps 3 --warmup 1 --no-events --no-cpu-baseline --no-latency > $out/$name.json 2> $out/$name.err
+  rocprofv3 --kernel-trace --output-format csv -d $out/tr_$name -- python3 bench.py --steps 3 --warmup 1 --no-events --no-cpu-baseline --no-latency --no-reduced --no-calib > $out/$name.json 2> $out/$name.err
   python3 tools/trace_layers.py $out/tr_$name > $out/$name.txt 2>&1
   find $out/tr_$name -name "*.db" -delete
 }
