@@ -180,13 +180,38 @@ __device__ __forceinline__ void conv_raise_range_flag(int* flag, float amax) {
 // atomic per wave and slot (none once the slot has caught up: the max converges within the first blocks).  amax >= 0, so
 // the float bit patterns order like unsigned integers; a pooled output is bounded by the un-pooled one (slot2).
 __device__ __forceinline__ unsigned conv_wave_umax(unsigned v) {
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) {
-    const unsigned w = (unsigned)__shfl_xor((int)v, o, 64);
-    v = v > w ? v : w;
-  }
-  return v;
+  // four DPP steps make every 16-lane row uniform (quad xor 1, quad xor 2, half-row mirror, row mirror), four readlanes
+  // and scalar maxes finish -- no lane id, no LDS crossbar (__shfl_xor needs the lane id in a vector register, and one
+  // kept alive to the end of an epilogue is spilled and reloaded behind a wait for all the epilogue's stores)
+  auto step = [](unsigned x, unsigned w) { return x > w ? x : w; };
+  v = step(v, (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xf, 0xf, true));    // quad_perm [1,0,3,2]
+  v = step(v, (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xf, 0xf, true));    // quad_perm [2,3,0,1]
+  v = step(v, (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x141, 0xf, 0xf, true));   // row_half_mirror
+  v = step(v, (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x140, 0xf, 0xf, true));   // row_mirror
+  const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)v, 0), b = (unsigned)__builtin_amdgcn_readlane((int)v, 16),
+                 c = (unsigned)__builtin_amdgcn_readlane((int)v, 32), d = (unsigned)__builtin_amdgcn_readlane((int)v, 48);
+  return step(step(a, b), step(c, d));
 }
+// The same in two halves for kernels whose epilogue ends in a burst of stores: PEEK the slots early (the load completes
+// under the last MFMAs; pin the value with an empty asm before the first store so that no later `vmcnt` wait -- which on
+// gfx9 also waits for every store issued since -- is generated for it), COMMIT after the epilogue: a stale peek only
+// costs one atomic that changes nothing.
+__device__ __forceinline__ unsigned conv_amax_peek(const unsigned* slot) {
+  return slot ? __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;
+}
+__device__ __forceinline__ void conv_amax_commit(unsigned* slot, unsigned seen, unsigned* slot2, unsigned seen2, float amax) {
+  if (!slot && !slot2) return;
+  const unsigned m = conv_wave_umax(__builtin_bit_cast(unsigned, amax));
+  // (lane 0 by the hardware's lane id, formed here: threadIdx.x -- or a lane id -- kept alive to the end of an epilogue
+  // is spilled, and reloaded behind a wait for every store of the epilogue)
+  unsigned zero = 0u;
+  asm volatile("" : "+v"(zero));   // (opaque, so that the lane id is formed HERE and not shared with an earlier one)
+  if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, zero)) == 0) {
+    if (slot && m > seen) atomicMax(slot, m);
+    if (slot2 && m > seen2) atomicMax(slot2, m);
+  }
+}
+
 __device__ __forceinline__ void conv_publish_amax(unsigned* slot, unsigned* slot2, float amax) {
   if (!slot && !slot2) return;
   const unsigned m = conv_wave_umax(__builtin_bit_cast(unsigned, amax));

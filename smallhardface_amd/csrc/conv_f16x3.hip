@@ -679,7 +679,11 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4d_kernel(ConvK p) {
       // every ds_write that parks a halo piece inside the stage.  Completion is waited for by hand at the stage start.)
       const unsigned char* ub = ws_ + w_goff(r);
       const unsigned lds = (unsigned)(__SIZE_TYPE__)(__attribute__((address_space(3))) unsigned char*)(bd_ + w_loff(r));
-      asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds), "v"(lane16), "s"(ub) : "m0");
+      // (M0 is compiler-reserved and not preserved around a statement: it is written in the statement that reads it,
+      // with the one wait state an SALU write of M0 needs before the LDS-DMA that uses it -- nothing inside an asm string
+      // is padded by the compiler.  The "s" operands are SALU results; a value fresh from v_readfirstlane would need five
+      // wait states before the load.)
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds), "v"(lane16), "s"(ub));
     }
   };
 
@@ -726,6 +730,7 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4d_kernel(ConvK p) {
     }
   }
 
+  unsigned seen0 = 0xffffffffu, seen0p = 0xffffffffu, seen1 = 0xffffffffu, seen1p = 0xffffffffu;
   // one stage = kernel row KY of the 16-channel chunk c.  MODE 1 (kernel row 1 of a chunk that has a successor):
   // request the pieces of chunk c + 1's halo tiles; MODE 2 (kernel row 2): convert them and park them in the other
   // buffer set, spread over the half-steps
@@ -787,6 +792,18 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4d_kernel(ConvK p) {
 #pragma unroll
           for (int j = 0; j < ALD; ++j) areg1[j] = *(const float4*)((const char*)g1.in + (a_goff[NTILE - 1][j] + coff));
           n_vmem += ALD;
+        }
+      }
+      if constexpr (MODE == 3) {
+        // the very last stage: read the units' max |output| slots now (conv_amax_peek), under the MFMAs
+        if (h == 0) {
+          seen0 = conv_amax_peek(g0.out_amax);
+          seen0p = conv_amax_peek(g0.pool ? g0.pool_amax : nullptr);
+          if constexpr (NTILE == 2) {
+            seen1 = conv_amax_peek(g1.out_amax);
+            seen1p = conv_amax_peek(g1.pool ? g1.pool_amax : nullptr);
+          }
+          n_vmem += 2 * NTILE;
         }
       }
       int n_park = 0;
@@ -866,22 +883,40 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4d_kernel(ConvK p) {
   }
   stage(nchunks - 1, integral_constant<int, 0>{}, integral_constant<int, 0>{});
   stage(nchunks - 1, integral_constant<int, 1>{}, integral_constant<int, 0>{});
-  stage(nchunks - 1, integral_constant<int, 2>{}, integral_constant<int, 0>{});
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last stage's (unused) self re-fetch
+  stage(nchunks - 1, integral_constant<int, 2>{}, integral_constant<int, 3>{});
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last stage's (unused) self re-fetch, the slot peeks
+  asm volatile("" : "+v"(seen0), "+v"(seen0p), "+v"(seen1), "+v"(seen1p));   // (the compiler's own wait for them goes HERE)
+  // (wave-uniform: parked in scalar registers until the end of the epilogue -- a vector register would be spilled)
+  seen0 = __builtin_amdgcn_readfirstlane(seen0);
+  seen0p = __builtin_amdgcn_readfirstlane(seen0p);
+  seen1 = __builtin_amdgcn_readfirstlane(seen1);
+  seen1p = __builtin_amdgcn_readfirstlane(seen1p);
 
   // register epilogue, one tile after the other (each with its unit's scale and its unit's max |output| slot)
   float amax0 = 0.f, amax1 = 0.f;
   {
     const bool relu = (p.relu & 1) != 0, write_main = !(p.relu & 8), main_split = (p.relu & 32) != 0,
                pool_split = (p.relu & 64) != 0;
-    int px_e = px, dy_e = dy, kh_e = kh, i_e = i;
-    asm volatile("" : "+v"(px_e), "+v"(dy_e), "+v"(kh_e), "+v"(i_e));
+    // the lane's coordinates are formed AGAIN here, from the lane id the hardware hands out (mbcnt) and the wave number
+    // in its scalar register: kept alive across the K loop they were spilled, and every scratch reload in an epilogue
+    // is followed by a vmcnt(0) that waits for all the stores issued so far
+    int lane_e = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    asm volatile("" : "+v"(lane_e));
+    const int i_e = lane_e & 31, kh_e = lane_e >> 5;
+    int px_e, dy_e;
+    row_to_pixel(i_e, dy_e, px_e);
+    const int wn = wave_u & 1, wm = wave_u >> 1;
+    // (kernel arguments the 16 accumulator tiles all use: in vector registers, or the compiler -- out of scalar
+    // registers here -- re-reads each of them from the argument segment for every tile, an s_load + wait apiece)
+    int out_stride_e = p.out_stride, pool_stride_e = p.pool_stride;
+    float wscale_inv_e = p.wscale_inv;
+    asm volatile("" : "+v"(out_stride_e), "+v"(pool_stride_e), "+v"(wscale_inv_e));
     float4 bias16[2][4];
 #pragma unroll
     for (int g = 0; g < 8; ++g)
       bias16[g >> 2][g & 3] = *(const float4*)(biasL + wn * 64 + (g >> 2) * 32 + kh_e * 16 + 4 * (g & 3));
     auto tile_out = [&](f32x16 (&acc)[MT][2], const Geo& g, bool exists, int e_act, float& amax) {
-      const float out_scale = p.wscale_inv * __builtin_bit_cast(float, (unsigned)(127 - e_act) << 23);   // 2^-e, exact
+      const float out_scale = wscale_inv_e * __builtin_bit_cast(float, (unsigned)(127 - e_act) << 23);   // 2^-e, exact
       const int Hp = (g.H + 1) >> 1, Wp = (g.W + 1) >> 1;
       const bool interior = exists && g.ty0 + TH <= g.H && g.tx0 + TW <= g.W;
       const int x = g.tx0 + px_e;
@@ -890,10 +925,14 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4d_kernel(ConvK p) {
         const int cout16 = ct * BN + wn * 64 + tn * 32 + kh_e * 16;
 #pragma unroll
         for (int tm = 0; tm < MT; ++tm) {
-          const int y = g.ty0 + wm * 2 * MT + tm * 2 + dy_e;
+          int y = g.ty0 + wm * 2 * MT + tm * 2 + dy_e;
+          // (opaque: this tile's address arithmetic starts HERE -- hoisted to the top for all 16 tiles it was spilled, and
+          // a scratch reload between the stores waits for every store issued so far)
+          asm volatile("" : "+v"(y));
           const bool valid = exists && y < g.H && x < g.W;
-          float* pm = write_main ? g.out + ((size_t)(g.b * g.H + y) * g.W + x) * p.out_stride : nullptr;
-          float* pq = g.pool ? g.pool + ((size_t)(g.b * Hp + (y >> 1)) * Wp + (x >> 1)) * p.pool_stride : nullptr;
+          const unsigned pix_m = (unsigned)((g.b * g.H + y) * g.W + x), pix_q = (unsigned)((g.b * Hp + (y >> 1)) * Wp + (x >> 1));
+          float* pm = write_main ? g.out + (size_t)pix_m * (unsigned)out_stride_e : nullptr;
+          float* pq = g.pool ? g.pool + (size_t)pix_q * (unsigned)pool_stride_e : nullptr;
           if (relu)
             conv_epilogue_regs1<true>(acc[tm][tn], out_scale, bias16[tn], valid, interior, pm, cout16, main_split, pq,
                                       valid && (i_e & 3) == 0, pool_split, amax);
@@ -907,9 +946,9 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4d_kernel(ConvK p) {
     if constexpr (NTILE == 2) tile_out(acc1, g1, has1, e_t1, amax1);
   }
   conv_raise_range_flag(p.range_flag, fmaxf(amax0, amax1));
-  conv_publish_amax(g0.out_amax, g0.pool ? g0.pool_amax : nullptr, amax0);
+  conv_amax_commit(g0.out_amax, seen0, g0.pool ? g0.pool_amax : nullptr, seen0p, amax0);
   if constexpr (NTILE == 2) {
-    if (has1) conv_publish_amax(g1.out_amax, g1.pool ? g1.pool_amax : nullptr, amax1);   // (wave-uniform)
+    if (has1) conv_amax_commit(g1.out_amax, seen1, g1.pool ? g1.pool_amax : nullptr, seen1p, amax1);   // (wave-uniform)
   }
 }
 
@@ -948,6 +987,7 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
   unsigned char* Bs = smem + 2 * HPP * ROWB;        // [2][3][BN][ROWB]
   float* patch = (float*)(Bs + 2 * 3 * BN * ROWB);  // [3][PH][PW] raw image patch
   unsigned char* valid = (unsigned char*)(patch + 3 * PH * PW);  // [HPP] halo pixel inside the image? (0 in the padding)
+  float* bias2L = (float*)(valid + HPP);                          // [BN] conv1_2's biases (read by the register epilogue)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
@@ -1007,6 +1047,7 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
       patch[idx] = pv;
       amax1 = fmaxf(amax1, fabsf(pv));  // the image itself is split to fp16 hi/lo for conv1_1's MFMAs
     }
+    if (tid >= 512 - BN) bias2L[tid - (512 - BN)] = p.bias ? p.bias[tid - (512 - BN)] : 0.f;
     if (tid < HPP) {
       const int qy = (tid * 58255) >> 20, qx = tid - qy * HTW;
       valid[tid] = (tid < HP && (unsigned)(ty0 - 1 + qy) < (unsigned)H && (unsigned)(tx0 - 1 + qx) < (unsigned)W) ? 1 : 0;
@@ -1186,12 +1227,17 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
     }
   };
 
+  unsigned seen = 0xffffffffu, seenp = 0xffffffffu;
 #pragma unroll
   for (int st = 0; st < 6; ++st) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // producers: their share of W(st) has landed
     __syncthreads();
     PC_T();
     if (consumer) {
+      if (st == 5) {   // the unit's max |output| slots, read under the last stage (conv_amax_peek)
+        seen = conv_amax_peek(mem.out_amax);
+        seenp = conv_amax_peek(mem.pool ? mem.pool_amax : nullptr);
+      }
       mma_stage(st < 3 ? As0 : As1, st % 3, st & 1);
     } else if (st + 1 < 6) {
       dma_w(st + 1, (st + 1) & 1);
@@ -1207,6 +1253,12 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
                pool_split = (p.relu & 64) != 0;
     int px_e = px, dy_e = dy, kh_e = kh, i_e = i;
     asm volatile("" : "+v"(px_e), "+v"(dy_e), "+v"(kh_e), "+v"(i_e));
+    asm volatile("" : "+v"(seen), "+v"(seenp));   // (the compiler's wait for the peeks goes here, before the first store)
+    seen = __builtin_amdgcn_readfirstlane(seen);
+    seenp = __builtin_amdgcn_readfirstlane(seenp);
+    // (kernel arguments every accumulator tile uses: kept in vector registers, not re-read from the argument segment)
+    int out_stride_e = p.out_stride, pool_stride_e = p.pool_stride;
+    asm volatile("" : "+v"(out_stride_e), "+v"(pool_stride_e));
     const int Hp = (H + 1) >> 1, Wp = (W + 1) >> 1;
     const bool interior = ty0 + TH <= H && tx0 + TW <= W;
     const int x = tx0 + px_e;
@@ -1215,13 +1267,15 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
       const int cout16 = tn * 32 + kh_e * 16;
       float4 bias16[4];
 #pragma unroll
-      for (int g = 0; g < 4; ++g) bias16[g] = p.bias ? *(const float4*)(p.bias + cout16 + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int g = 0; g < 4; ++g) bias16[g] = *(const float4*)(bias2L + cout16 + 4 * g);   // (LDS: no vmcnt wait between the tiles' stores)
 #pragma unroll
       for (int tm = 0; tm < MT; ++tm) {
-        const int y = ty0 + wm * 2 * MT + tm * 2 + dy_e;
+        int y = ty0 + wm * 2 * MT + tm * 2 + dy_e;
+        asm volatile("" : "+v"(y));   // (this tile's address arithmetic starts here: see the dual-tile kernel's epilogue)
         const bool vld = y < H && x < W;
-        float* pm = write_main ? gout + ((size_t)(b * H + y) * W + x) * p.out_stride : nullptr;
-        float* pq = mem.pool ? mem.pool + ((size_t)(b * Hp + (y >> 1)) * Wp + (x >> 1)) * p.pool_stride : nullptr;
+        const unsigned pix_m = (unsigned)((b * H + y) * W + x), pix_q = (unsigned)((b * Hp + (y >> 1)) * Wp + (x >> 1));
+        float* pm = write_main ? gout + (size_t)pix_m * (unsigned)out_stride_e : nullptr;
+        float* pq = mem.pool ? mem.pool + (size_t)pix_q * (unsigned)pool_stride_e : nullptr;
         if (relu)
           conv_epilogue_regs<true>(accm[tm][tn], accc[tm][tn], LO_INV, bias16, vld, interior, pm, cout16, main_split, pq,
                                    vld && (i_e & 3) == 0, pool_split, amax);
@@ -1229,16 +1283,19 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
           conv_epilogue_regs<false>(accm[tm][tn], accc[tm][tn], LO_INV, bias16, vld, interior, pm, cout16, main_split, pq,
                                     vld && (i_e & 3) == 0, pool_split, amax);
       }
+      PC_T();
     }
+    conv_amax_commit(mem.out_amax, seen, mem.pool ? mem.pool_amax : nullptr, seenp, amax);   // (producers hold no outputs)
   }
   conv_raise_range_flag(p.range_flag, fmaxf(amax, amax1));
-  conv_publish_amax(mem.out_amax, mem.pool ? mem.pool_amax : nullptr, amax);
   PC_T();
 #ifdef SHF_CONV_TIMING
-  if (bid == 100 && lane == 0 && (wave == 0 || wave == 4 || wave == 7))
-    printf("[pc] wave%d decode %llu dma-issue %llu | setup %llu patch+barrier %llu conv1_1 %llu | to-stage0 %llu stages %llu %llu %llu %llu %llu last %llu | epilogue %llu\n", wave,
-           t_dec - tt[0], t_dma - t_dec, tt[1] - tt[0], tt[2] - tt[1], tt[3] - tt[2], tt[4] - tt[3], tt[5] - tt[4], tt[6] - tt[5], tt[7] - tt[6], tt[8] - tt[7],
-           tt[9] - tt[8], tt[10] - tt[9], tt[11] - tt[10]);
+  // tt: 0 entry, 1 patch requested + parked, 2 barrier, 3..8 the six stages' starts, 9 K loop done, (consumers: 10, 11 the
+  // two cout halves stored,) last: flags published.  A first-round block (100) and two steady-state ones.
+  if ((bid == 100 || bid == 9000 || bid == 20000) && lane == 0 && (wave == 0 || wave == 4))
+    printf("[pc] blk%d wave%d decode %llu dma-issue %llu | patch %llu barrier %llu conv1_1 %llu | stages %llu %llu %llu %llu %llu %llu | epilogue %llu %llu %llu\n",
+           bid, wave, t_dec - tt[0], t_dma - t_dec, tt[1] - tt[0], tt[2] - tt[1], tt[3] - tt[2], tt[4] - tt[3], tt[5] - tt[4], tt[6] - tt[5],
+           tt[7] - tt[6], tt[8] - tt[7], tt[9] - tt[8], tt[10] - tt[9], nt > 11 ? tt[11] - tt[10] : 0ull, nt > 12 ? tt[12] - tt[11] : 0ull);
 #endif
 #undef PC_T
 }
@@ -1497,7 +1554,7 @@ static int launch_f16x3_t(const ConvArgs* as, int n, hipStream_t s) {
   if (FUSE1 && BN == 64 && conv_f16x3_uses_pc() && vec_ok && p.Cin == 64 && p.Cout == 64 && p.w1f) {
     // two halo tiles (both channel chunks of conv1_1's output) + the weight double buffer + the image patch
     constexpr size_t HPP = (HP + 31) / 32 * 32;
-    const size_t lds_pc = 2 * HPP * ROWB + 2 * 3 * (size_t)BN * ROWB + 3 * (TH + 4) * (TW + 4) * sizeof(float) + HPP;
+    const size_t lds_pc = 2 * HPP * ROWB + 2 * 3 * (size_t)BN * ROWB + 3 * (TH + 4) * (TW + 4) * sizeof(float) + HPP + BN * sizeof(float);
     if (a.bf16) hipLaunchKernelGGL((conv_mfma_f16x3_pc_kernel<1, true>), dim3((unsigned)tiles), dim3(512), lds_pc, s, p);
     else if (a.nprod >= 3) hipLaunchKernelGGL(conv_mfma_f16x3_pc_kernel<3>, dim3((unsigned)tiles), dim3(512), lds_pc, s, p);
     else if (a.nprod == 2) hipLaunchKernelGGL(conv_mfma_f16x3_pc_kernel<2>, dim3((unsigned)tiles), dim3(512), lds_pc, s, p);
