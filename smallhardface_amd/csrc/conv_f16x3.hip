@@ -992,6 +992,28 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const bool consumer = wave_u < 4;
+  // what does not depend on the tile is requested FIRST -- conv1_1's weight fragments and biases (64 registers), conv1_2's
+  // biases for LDS -- so that their round trip runs under the tile decode and the image patch's (they used to be
+  // requested after the patch was parked: 2 k cycles of a second, serial round trip per tile)
+  const int i1 = lane & 31, kh1 = lane >> 5;
+  half8 bw[2][2][2];  // [n][kk][hi/lo]
+#pragma unroll
+  for (int n = 0; n < 2; ++n)
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int hl = 0; hl < 2; ++hl)
+        bw[n][kk][hl] = *(const half8*)((const _Float16*)p.w1f + ((size_t)((n * 2 + kk) * 2 + hl) * 64 + lane) * 8);
+  // (unconditional loads -- a missing bias vector reads the weight pack instead and is zeroed where it is first used: a
+  // branch around a load up here makes the compiler wait for everything requested so far)
+  const float* b1p = p.b1 ? p.b1 : (const float*)p.w1f;
+  const float* b2p = p.bias ? p.bias : (const float*)p.w1f;
+  float4 bias1v[2][4];
+#pragma unroll
+  for (int n = 0; n < 2; ++n)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bias1v[n][q] = *(const float4*)(b1p + n * 32 + 8 * q + 4 * kh1);
+  const float bias2v = b2p[tid & (BN - 1)];
   const int bid = blockIdx.x;
   int pt = bid;  // nct == 1
   const int mi = conv_find_member(p, pt);
@@ -1038,40 +1060,40 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
     // As0 / As1.  (On the vector ALUs this was 15-18 k cycles per tile, a third of the block.)
     const float* img = mem.img + (size_t)b * 3 * H * W;
     static_assert(PH == 20 && PW == 20 && HTW == 18, "the multiply-shift divisions below are exact for these sizes");
-    for (int idx = tid; idx < 3 * PH * PW; idx += 512) {
+    constexpr int NPATCH = (3 * PH * PW + 511) / 512;   // 3 values per thread (the last round ragged): all requested, then parked
+    float pv[NPATCH];
+#pragma unroll
+    for (int k = 0; k < NPATCH; ++k) {
       // (integer division is a ~40-instruction sequence: n / 400, n / 20 and n / 18 as multiply + shift, exact below 1300 / 420 / 400)
+      const int idx = tid + 512 * k;
       const int ci = (idx * 2622) >> 20, r = idx - ci * (PH * PW);
       const int py = (r * 52429) >> 20, pxx = r - py * PW;
       const int gy = ty0 - 2 + py, gx = tx0 - 2 + pxx;
-      const float pv = ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) ? img[((size_t)ci * H + gy) * W + gx] : 0.f;
-      patch[idx] = pv;
-      amax1 = fmaxf(amax1, fabsf(pv));  // the image itself is split to fp16 hi/lo for conv1_1's MFMAs
+      const bool in = idx < 3 * PH * PW && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+      pv[k] = in ? img[((size_t)ci * H + gy) * W + gx] : 0.f;
     }
-    if (tid >= 512 - BN) bias2L[tid - (512 - BN)] = p.bias ? p.bias[tid - (512 - BN)] : 0.f;
+#pragma unroll
+    for (int k = 0; k < NPATCH; ++k) {
+      const int idx = tid + 512 * k;
+      if (idx < 3 * PH * PW) patch[idx] = pv[k];
+      amax1 = fmaxf(amax1, fabsf(pv[k]));  // the image itself is split to fp16 hi/lo for conv1_1's MFMAs
+    }
+    if (tid < BN) bias2L[tid] = p.bias ? bias2v : 0.f;
+    if (!p.b1) {   // (wave-uniform, rare)
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bias1v[n][q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     if (tid < HPP) {
       const int qy = (tid * 58255) >> 20, qx = tid - qy * HTW;
       valid[tid] = (tid < HP && (unsigned)(ty0 - 1 + qy) < (unsigned)H && (unsigned)(tx0 - 1 + qx) < (unsigned)W) ? 1 : 0;
     }
     PC_T();
-    const int i1 = lane & 31, kh1 = lane >> 5;
-    half8 bw[2][2][2];  // [n][kk][hi/lo]
-#pragma unroll
-    for (int n = 0; n < 2; ++n)
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-        for (int hl = 0; hl < 2; ++hl)
-          bw[n][kk][hl] = *(const half8*)((const _Float16*)p.w1f + ((size_t)((n * 2 + kk) * 2 + hl) * 64 + lane) * 8);
     // conv1_1 runs as D[cout][pixel] (weights = A operand): a lane owns ONE halo pixel and the 16 couts
     // (r & 3) + 8 (r >> 2) + 4 kh of each 32-channel chunk -- one validity flag per lane, and after the half-wave
     // exchange 16 consecutive couts = two 16-byte LDS stores each for hi and lo (the D[pixel][cout] form wrote 32 two-byte
     // values per lane and chunk and read 16 flags).  bias1v[n][q] = biases of couts 8 q + 4 kh .. + 3 of chunk n.
-    float4 bias1v[2][4];
-#pragma unroll
-    for (int n = 0; n < 2; ++n)
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        bias1v[n][q] = p.b1 ? *(const float4*)(p.b1 + n * 32 + 8 * q + 4 * kh1) : make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
     PC_T();
     constexpr int NMT = (HP + 31) / 32;  // 11 row tiles
