@@ -965,7 +965,10 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4d_kernel(ConvK p) {
 //  * waves 0-3 are CONSUMERS (one per SIMD): 64 px x 64 couts = 4 accumulator tiles each, 8 fragment reads
 //    per 12 MFMAs, the six k-steps of a stage software-pipelined like the 4-wave kernel (~2.6 k cycles per
 //    stage against 2.3 k of pure MFMA issue).  Waves 4-7 are PRODUCERS: they issue every weight DMA.
-template <int NP, bool BF = false>
+//  * PERSIST (round 3): one block per CU WALKS the tiles (tile = block, block + grid, ...).  The producers fetch the
+//    next tile's image patch, its validity flags and its first weight stage under the current K loop, so a tile no
+//    longer pays the block turnaround, the tile decode and the patch's round trip (≈6 k of ≈37 k cycles).
+template <int NP, bool BF = false, bool PERSIST = false>
 __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
   using namespace f16x3;
   static_assert(!BF || NP == 1, "bf16 mode is a one-product mode");
@@ -989,41 +992,51 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
   unsigned char* valid = (unsigned char*)(patch + 3 * PH * PW);  // [HPP] halo pixel inside the image? (0 in the padding)
   float* bias2L = (float*)(valid + HPP);                          // [BN] conv1_2's biases (read by the register epilogue)
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int tid = threadIdx.x, lane = tid & 63;
+  const int wave = tid >> 6;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const bool consumer = wave_u < 4;
   // what does not depend on the tile is requested FIRST -- conv1_1's weight fragments and biases (64 registers), conv1_2's
   // biases for LDS -- so that their round trip runs under the tile decode and the image patch's (they used to be
   // requested after the patch was parked: 2 k cycles of a second, serial round trip per tile)
-  const int i1 = lane & 31, kh1 = lane >> 5;
+  int i1 = lane & 31, kh1 = lane >> 5;
   half8 bw[2][2][2];  // [n][kk][hi/lo]
-#pragma unroll
-  for (int n = 0; n < 2; ++n)
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-      for (int hl = 0; hl < 2; ++hl)
-        bw[n][kk][hl] = *(const half8*)((const _Float16*)p.w1f + ((size_t)((n * 2 + kk) * 2 + hl) * 64 + lane) * 8);
   // (unconditional loads -- a missing bias vector reads the weight pack instead and is zeroed where it is first used: a
   // branch around a load up here makes the compiler wait for everything requested so far)
   const float* b1p = p.b1 ? p.b1 : (const float*)p.w1f;
   const float* b2p = p.bias ? p.bias : (const float*)p.w1f;
   float4 bias1v[2][4];
+  auto load_conv1_operands = [&]() {   // (PERSIST: once per tile -- 64 registers that cannot stay alive across the K loop)
 #pragma unroll
-  for (int n = 0; n < 2; ++n)
+    for (int n = 0; n < 2; ++n)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) bias1v[n][q] = *(const float4*)(b1p + n * 32 + 8 * q + 4 * kh1);
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int hl = 0; hl < 2; ++hl)
+          bw[n][kk][hl] = *(const half8*)((const _Float16*)p.w1f + ((size_t)((n * 2 + kk) * 2 + hl) * 64 + (i1 + 32 * kh1)) * 8);
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) bias1v[n][q] = *(const float4*)(b1p + n * 32 + 8 * q + 4 * kh1);
+  };
+  load_conv1_operands();
   const float bias2v = b2p[tid & (BN - 1)];
   const int bid = blockIdx.x;
-  int pt = bid;  // nct == 1
-  const int mi = conv_find_member(p, pt);
-  const ConvMember& mem = p.m[mi];
-  pt -= mem.tile_start;
-  int b, ty_, tx_;
-  conv_split_tile(mem, pt, b, ty_, tx_);
-  const int ty0 = ty_ * TH, tx0 = tx_ * TW;
-  const int H = mem.H, W = mem.W;
-  float* __restrict__ gout = mem.out;
+  // the tile's geometry (wave-uniform; PERSIST: re-formed for every tile of the walk).  nct == 1: tile = pixel tile
+  struct TileGeo { int b, ty0, tx0, H, W; const float* img; float* out; float* pool; unsigned* out_amax; unsigned* pool_amax; };
+  auto decode = [&](int tile) {
+    int pt = tile;
+    const ConvMember& m = p.m[conv_find_member(p, pt)];
+    pt -= m.tile_start;
+    int b_, ty_, tx_;
+    conv_split_tile(m, pt, b_, ty_, tx_);
+    return TileGeo{b_, ty_ * TH, tx_ * TW, m.H, m.W, m.img + (size_t)b_ * 3 * m.H * m.W, m.out, m.pool, m.out_amax, m.pool_amax};
+  };
+  int tile = bid;
+  const int ntiles = PERSIST ? p.ntile_blocks : 0, gstride = (int)gridDim.x;
+  TileGeo mem = decode(tile);
+  int b = mem.b, ty0 = mem.ty0, tx0 = mem.tx0, H = mem.H, W = mem.W;
+  float* gout = mem.out;
 #ifdef SHF_CONV_TIMING
   asm volatile("" :: "s"(H), "s"(W), "s"(ty0), "s"(tx0));
   const unsigned long long t_dec = __builtin_amdgcn_s_memtime();
@@ -1053,13 +1066,16 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
 #endif
 
   float amax1 = 0.f;  // fp16 range guard for conv1_1's outputs (split right here, never seen by another epilogue)
+  bool first_tile = true;
+  for (;;) {   // (PERSIST: the walk over this block's tiles; otherwise one turn)
   {  // prologue, all eight waves: conv1_1 + ReLU of the whole halo tile ON THE MATRIX CORES
     // [324 halo px x 27 taps (padded to 32)] x [32 x 64 couts] as split-fp16 MFMAs: 11 row tiles of 32 pixels,
     // 12 MFMAs each; a lane builds its A fragments (pixel lane&31, 8 taps) from the LDS image patch, the B
     // fragments (weights) come pre-packed from global memory.  N tile 0 / 1 = channel chunk 0 / 1 = halo tile
     // As0 / As1.  (On the vector ALUs this was 15-18 k cycles per tile, a third of the block.)
-    const float* img = mem.img + (size_t)b * 3 * H * W;
     static_assert(PH == 20 && PW == 20 && HTW == 18, "the multiply-shift divisions below are exact for these sizes");
+    if (first_tile) {   // (a later tile's patch, flags and first weights were fetched by the producers under the previous K loop)
+    const float* img = mem.img;
     constexpr int NPATCH = (3 * PH * PW + 511) / 512;   // 3 values per thread (the last round ragged): all requested, then parked
     float pv[NPATCH];
 #pragma unroll
@@ -1079,22 +1095,23 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
       amax1 = fmaxf(amax1, fabsf(pv[k]));  // the image itself is split to fp16 hi/lo for conv1_1's MFMAs
     }
     if (tid < BN) bias2L[tid] = p.bias ? bias2v : 0.f;
-    if (!p.b1) {   // (wave-uniform, rare)
-#pragma unroll
-      for (int n = 0; n < 2; ++n)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) bias1v[n][q] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
     if (tid < HPP) {
       const int qy = (tid * 58255) >> 20, qx = tid - qy * HTW;
       valid[tid] = (tid < HP && (unsigned)(ty0 - 1 + qy) < (unsigned)H && (unsigned)(tx0 - 1 + qx) < (unsigned)W) ? 1 : 0;
+    }
     }
     PC_T();
     // conv1_1 runs as D[cout][pixel] (weights = A operand): a lane owns ONE halo pixel and the 16 couts
     // (r & 3) + 8 (r >> 2) + 4 kh of each 32-channel chunk -- one validity flag per lane, and after the half-wave
     // exchange 16 consecutive couts = two 16-byte LDS stores each for hi and lo (the D[pixel][cout] form wrote 32 two-byte
     // values per lane and chunk and read 16 flags).  bias1v[n][q] = biases of couts 8 q + 4 kh .. + 3 of chunk n.
-    __syncthreads();
+    if (first_tile) __syncthreads();   // (wave-uniform; a later tile starts behind the walk's barrier)
+    if (!p.b1) {   // (wave-uniform, rare)
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bias1v[n][q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     PC_T();
     constexpr int NMT = (HP + 31) / 32;  // 11 row tiles
     // work items: tiles 0..7 whole (one per wave), tiles 8..10 split by N tile over waves 0..5: the longest
@@ -1250,6 +1267,12 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
   };
 
   unsigned seen = 0xffffffffu, seenp = 0xffffffffu;
+  // PERSIST, producers: the next tile of the walk -- its patch is requested in stage 0 and parked (with the validity flags)
+  // in stage 2: the patch and the flags are only read by conv1_1, which is behind stage 0's barrier
+  constexpr int NPF = (3 * PH * PW + 255) / 256;   // 5 patch values per producer thread
+  const bool has_next = PERSIST && tile + gstride < ntiles;
+  TileGeo nxt = mem;
+  float pvn[NPF];
 #pragma unroll
   for (int st = 0; st < 6; ++st) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // producers: their share of W(st) has landed
@@ -1261,8 +1284,40 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
         seenp = conv_amax_peek(mem.pool ? mem.pool_amax : nullptr);
       }
       mma_stage(st < 3 ? As0 : As1, st % 3, st & 1);
-    } else if (st + 1 < 6) {
-      dma_w(st + 1, (st + 1) & 1);
+    } else {
+      if (st + 1 < 6) dma_w(st + 1, (st + 1) & 1);
+      if constexpr (PERSIST) {
+        const int ptid = tid - 256;
+        if (st == 0 && has_next) {
+          nxt = decode(tile + gstride);
+#pragma unroll
+          for (int k = 0; k < NPF; ++k) {
+            const int idx = ptid + 256 * k;
+            const int ci = (idx * 2622) >> 20, r = idx - ci * (PH * PW);
+            const int py = (r * 52429) >> 20, pxx = r - py * PW;
+            const int gy = nxt.ty0 - 2 + py, gx = nxt.tx0 - 2 + pxx;
+            const bool in = idx < 3 * PH * PW && (unsigned)gy < (unsigned)nxt.H && (unsigned)gx < (unsigned)nxt.W;
+            pvn[k] = in ? nxt.img[((size_t)ci * nxt.H + gy) * nxt.W + gx] : 0.f;
+          }
+        }
+        if (st == 2 && has_next) {
+#pragma unroll
+          for (int k = 0; k < NPF; ++k) {
+            const int idx = ptid + 256 * k;
+            if (idx < 3 * PH * PW) patch[idx] = pvn[k];
+            amax1 = fmaxf(amax1, fabsf(pvn[k]));
+          }
+#pragma unroll
+          for (int k = 0; k < (HPP + 255) / 256; ++k) {
+            const int hp = ptid + 256 * k;
+            const int qy = (hp * 58255) >> 20, qx = hp - qy * HTW;
+            if (hp < HPP)
+              valid[hp] = (hp < HP && (unsigned)(nxt.ty0 - 1 + qy) < (unsigned)nxt.H && (unsigned)(nxt.tx0 - 1 + qx) < (unsigned)nxt.W) ? 1 : 0;
+          }
+        }
+        // (buffer 0 held stage 4's weights; every consumer is past them behind this stage's barrier)
+        if (st == 5 && has_next) dma_w(0, 0);
+      }
     }
   }
 
@@ -1310,6 +1365,20 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
     conv_amax_commit(mem.out_amax, seen, mem.pool ? mem.pool_amax : nullptr, seenp, amax);   // (producers hold no outputs)
   }
   conv_raise_range_flag(p.range_flag, fmaxf(amax, amax1));
+  if (!PERSIST || !has_next) break;
+  // the walk's next tile: its patch, flags and first weight stage are in flight or parked; conv1_1 may overwrite the halo
+  // tiles once every consumer is out of the K loop (they are: the epilogue is behind it)
+  tile += gstride;
+  mem = decode(tile);
+  b = mem.b; ty0 = mem.ty0; tx0 = mem.tx0; H = mem.H; W = mem.W; gout = mem.out;
+  amax1 = 0.f;
+  first_tile = false;
+  // (opaque per tile: what conv1_1 derives from the lane's coordinates -- 16 patch offsets, row addresses -- is formed again
+  // for every tile instead of living in registers across the K loop)
+  asm volatile("" : "+v"(i1), "+v"(kh1), "+v"(lane), "+v"(tid));
+  load_conv1_operands();
+  __syncthreads();
+  }
   PC_T();
 #ifdef SHF_CONV_TIMING
   // tt: 0 entry, 1 patch requested + parked, 2 barrier, 3..8 the six stages' starts, 9 K loop done, (consumers: 10, 11 the
@@ -1400,6 +1469,7 @@ struct Knobs {
   int w4d_ntile;       // SHF_F16X3_W4D_NTILE: 0 auto (hybrid launches), 1 / 2 force single- / two-tile blocks
   int xcd_remap;       // SHF_F16X3_XCD_REMAP: 1 = all cout tiles of a pixel tile on one XCD (experiment)
   bool pc, dilated, k1, scalar_epilogue;   // SHF_F16X3_PC, SHF_F16X3_DILATED, SHF_F16X3_1X1 (default on), SHF_CONV_SCALAR_EPILOGUE (off)
+  bool pc_persist;     // SHF_F16X3_PC_PERSIST: the fused first pair as one block per CU walking the tiles
   int cus;
 };
 int env_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
@@ -1411,6 +1481,7 @@ const Knobs& knobs() {
     q.w4d_ntile = env_int("SHF_F16X3_W4D_NTILE", 0);
     q.xcd_remap = env_int("SHF_F16X3_XCD_REMAP", 0);
     q.pc = env_int("SHF_F16X3_PC", 1) != 0;
+    q.pc_persist = env_int("SHF_F16X3_PC_PERSIST", 0) != 0;
     q.dilated = env_int("SHF_F16X3_DILATED", 1) != 0;
     q.k1 = env_int("SHF_F16X3_1X1", 1) != 0;
     q.scalar_epilogue = env_int("SHF_CONV_SCALAR_EPILOGUE", 0) != 0;
@@ -1460,6 +1531,7 @@ void pack_first_conv_frags(const float* w, void* dst_, bool bf) {
 }
 
 bool conv_f16x3_uses_pc() { return knobs().pc; }
+bool conv_f16x3_pc_persistent() { return knobs().pc_persist; }
 
 // (Cin 64 -- conv2_1 -- joined in round 3: as two single-tile 8-row blocks per CU it beats the 8-wave kernel, 0.67 vs 0.81 ms)
 bool conv_f16x3_uses_w4(int Cin) { return knobs().w4_mode < 0 ? Cin >= 64 : knobs().w4_mode != 0; }
@@ -1577,7 +1649,15 @@ static int launch_f16x3_t(const ConvArgs* as, int n, hipStream_t s) {
     // two halo tiles (both channel chunks of conv1_1's output) + the weight double buffer + the image patch
     constexpr size_t HPP = (HP + 31) / 32 * 32;
     const size_t lds_pc = 2 * HPP * ROWB + 2 * 3 * (size_t)BN * ROWB + 3 * (TH + 4) * (TW + 4) * sizeof(float) + HPP + BN * sizeof(float);
-    if (a.bf16) hipLaunchKernelGGL((conv_mfma_f16x3_pc_kernel<1, true>), dim3((unsigned)tiles), dim3(512), lds_pc, s, p);
+    if (knobs().pc_persist) {
+      // one block per CU walks the tiles (tile = block, block + grid, ...)
+      p.ntile_blocks = (int)tiles;
+      const dim3 gp((unsigned)std::min<long long>(tiles, knobs().cus));
+      if (a.bf16) hipLaunchKernelGGL((conv_mfma_f16x3_pc_kernel<1, true, true>), gp, dim3(512), lds_pc, s, p);
+      else if (a.nprod >= 3) hipLaunchKernelGGL((conv_mfma_f16x3_pc_kernel<3, false, true>), gp, dim3(512), lds_pc, s, p);
+      else if (a.nprod == 2) hipLaunchKernelGGL((conv_mfma_f16x3_pc_kernel<2, false, true>), gp, dim3(512), lds_pc, s, p);
+      else hipLaunchKernelGGL((conv_mfma_f16x3_pc_kernel<1, false, true>), gp, dim3(512), lds_pc, s, p);
+    } else if (a.bf16) hipLaunchKernelGGL((conv_mfma_f16x3_pc_kernel<1, true>), dim3((unsigned)tiles), dim3(512), lds_pc, s, p);
     else if (a.nprod >= 3) hipLaunchKernelGGL(conv_mfma_f16x3_pc_kernel<3>, dim3((unsigned)tiles), dim3(512), lds_pc, s, p);
     else if (a.nprod == 2) hipLaunchKernelGGL(conv_mfma_f16x3_pc_kernel<2>, dim3((unsigned)tiles), dim3(512), lds_pc, s, p);
     else hipLaunchKernelGGL(conv_mfma_f16x3_pc_kernel<1>, dim3((unsigned)tiles), dim3(512), lds_pc, s, p);
@@ -1679,6 +1759,10 @@ int conv_f16x3_init_attributes() {
   SHF_LDS_ATTR(conv_mfma_f16x3_pc_kernel<2>)
   SHF_LDS_ATTR(conv_mfma_f16x3_pc_kernel<1>)
   SHF_LDS_ATTR((conv_mfma_f16x3_pc_kernel<1, true>))
+  SHF_LDS_ATTR((conv_mfma_f16x3_pc_kernel<3, false, true>))
+  SHF_LDS_ATTR((conv_mfma_f16x3_pc_kernel<2, false, true>))
+  SHF_LDS_ATTR((conv_mfma_f16x3_pc_kernel<1, false, true>))
+  SHF_LDS_ATTR((conv_mfma_f16x3_pc_kernel<1, true, true>))
 #define SHF_W4D_ATTR(SPLIT, MTV, NTV)                                      \
   SHF_LDS_ATTR((conv_mfma_f16x3_w4d_kernel<SPLIT, MTV, NTV, 3>))           \
   SHF_LDS_ATTR((conv_mfma_f16x3_w4d_kernel<SPLIT, MTV, NTV, 2>))           \

@@ -149,7 +149,7 @@ static const char* kProfNames[PC_COUNT] = {"conv_mfma_f32_kernel<3, 1, 128, 8, 1
                                            "conv_mfma_f16x3_kernel<64, false, 1, 3, 3, false>",
                                            "conv_mfma_f16x3_kernel<64, true, 1, 3, 3, false>", "conv_mfma_f16x3_kernel<64, false, 2, 3, 3, false>",
                                            "conv_mfma_f16x3_kernel<64, false, 4, 3, 3, false>", "conv_mfma_f16x3_kernel<128, false, 1, 1, 3, false>",
-                                           "conv_mfma_f16x3_kernel<64, false, 1, 1, 3, false>", "conv_mfma_f16x3_pc_kernel<3, false>",
+                                           "conv_mfma_f16x3_kernel<64, false, 1, 1, 3, false>", "conv_mfma_f16x3_pc_kernel<3, false, false>",
                                            // dual-tile family <IN_SPLIT, rows / 4, tiles per block, products>: index = in_split * 4 + (rows == 8) * 2 + (tiles == 1)
                                            "conv_mfma_f16x3_w4d_kernel<false, 4, 2, 3, false>", "conv_mfma_f16x3_w4d_kernel<false, 4, 1, 3, false>",
                                            "conv_mfma_f16x3_w4d_kernel<false, 2, 2, 3, false>", "conv_mfma_f16x3_w4d_kernel<false, 2, 1, 3, false>",
@@ -402,6 +402,9 @@ static int conv_out(int n, int k, int pad, int stride, int dil) {
 
 namespace shf {
 int calib_matrix_pipe(int bf16, int zero_eighths, int constant, int iters, int reps, double* tflops);   // calib.hip
+}
+namespace shf {
+bool conv_f16x3_pc_persistent();   // conv_f16x3.hip (SHF_F16X3_PC_PERSIST)
 }
 using namespace shf;
 
@@ -2278,7 +2281,10 @@ int shf_prof_enable(shf_net* net, int enable) {
   return 0;
 }
 int shf_prof_num_classes(shf_net*) { return PC_COUNT; }
-const char* shf_prof_class_name(shf_net*, int cls) { return (cls >= 0 && cls < PC_COUNT) ? kProfNames[cls] : nullptr; }
+const char* shf_prof_class_name(shf_net*, int cls) {
+  if (cls == PC_CONV_F16X3_PC && shf::conv_f16x3_pc_persistent()) return "conv_mfma_f16x3_pc_kernel<3, false, true>";
+  return (cls >= 0 && cls < PC_COUNT) ? kProfNames[cls] : nullptr;
+}
 int shf_prof_read(shf_net* net, int cls, int64_t* launches, double* total_ms, double* flops, double* bytes) {
   API_BEGIN
   if (cls < 0 || cls >= PC_COUNT) throw std::runtime_error("bad profile class");
