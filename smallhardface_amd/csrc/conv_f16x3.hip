@@ -1048,7 +1048,11 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
   const size_t slab = (size_t)p.Cout * 72;
   const _Float16* wbase = (const _Float16*)p.wp;
   auto dma_w = [&](int stage, int buf) {     // producer waves only: 7 rounds of 4 pieces (the last one ragged)
-    const unsigned char* ws_ = (const unsigned char*)(wbase + (size_t)stage * 3 * slab);
+    // (opaque base: the 42 source addresses of a tile are formed where they are used, on the scalar unit -- as loop
+    // invariants of the persistent walk they would occupy 84 scalar registers, i.e. be spilled)
+    const _Float16* wb = wbase;
+    asm volatile("" : "+s"(wb));
+    const unsigned char* ws_ = (const unsigned char*)(wb + (size_t)stage * 3 * slab);
     unsigned char* bd_ = Bs + buf * (3 * SLAB_B);
 #pragma unroll
     for (int j = 0; j < (PCS + 3) / 4; ++j) {
@@ -1469,7 +1473,7 @@ struct Knobs {
   int w4d_ntile;       // SHF_F16X3_W4D_NTILE: 0 auto (hybrid launches), 1 / 2 force single- / two-tile blocks
   int xcd_remap;       // SHF_F16X3_XCD_REMAP: 1 = all cout tiles of a pixel tile on one XCD (experiment)
   bool pc, dilated, k1, scalar_epilogue;   // SHF_F16X3_PC, SHF_F16X3_DILATED, SHF_F16X3_1X1 (default on), SHF_CONV_SCALAR_EPILOGUE (off)
-  bool pc_persist;     // SHF_F16X3_PC_PERSIST: the fused first pair as one block per CU walking the tiles
+  bool pc_persist;     // SHF_F16X3_PC_PERSIST (default on): the fused first pair as one block per CU walking the tiles
   int cus;
 };
 int env_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
@@ -1481,7 +1485,7 @@ const Knobs& knobs() {
     q.w4d_ntile = env_int("SHF_F16X3_W4D_NTILE", 0);
     q.xcd_remap = env_int("SHF_F16X3_XCD_REMAP", 0);
     q.pc = env_int("SHF_F16X3_PC", 1) != 0;
-    q.pc_persist = env_int("SHF_F16X3_PC_PERSIST", 0) != 0;
+    q.pc_persist = env_int("SHF_F16X3_PC_PERSIST", 1) != 0;
     q.dilated = env_int("SHF_F16X3_DILATED", 1) != 0;
     q.k1 = env_int("SHF_F16X3_1X1", 1) != 0;
     q.scalar_epilogue = env_int("SHF_CONV_SCALAR_EPILOGUE", 0) != 0;
