@@ -14,5 +14,5 @@ python - <<'PY'
 import json
 for n in ("off1", "on1", "off2", "on2"):
     d = json.load(open("gpurun_out/ab_%s.json" % n)); r = d["roofline"]
-    print(n, "%.2f img/s" % d["value"], {k.replace("conv_mfma_f16x3_", ""): v for k, v in r["kernel_ms_per_image"].items() if "pc_" in k or "w4d_kernel<true, 4, 2" in k})
+    print(n, "%.2f img/s" % d["value"], {k.replace("conv_mfma_f16x3_", ""): v for k, v in r["kernel_ms_per_image"].items() if "pc_" in k or "w4d_kernel<true, 4, 2" in k or ", 1, 1, 3, false>" in k})
 PY
