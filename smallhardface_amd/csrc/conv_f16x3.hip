@@ -535,6 +535,41 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4d_kernel(ConvK p) {
   const int pp = bid / p.nct;
   const int ntiles = p.ntile_blocks / p.nct;          // the launch covers pixel tiles [tile_base, ntiles) of the group
 
+  const int nchunks = p.Cin / KC;
+  const int NST = nchunks * 3;
+  const size_t slab = (size_t)p.Cout * 32;            // halfs per tap slab of the whole layer
+  const _Float16* wbase = (const _Float16*)p.wph + (size_t)ct * BN * 32;
+
+  // weight DMA: round r (0..5) of a wave moves 1-KiB piece q = wave + 4 r of the stage's 24 (8 per tap slab: rounds
+  // 0-1 / 2-3 / 4-5 are slabs 0 / 1 / 2 for every wave).  LDS offset = q KiB; global offset = slab (q / 8) + (q % 8) KiB.
+  constexpr int W_ROUNDS = 6;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const unsigned lane16 = (unsigned)lane * 16u;
+  const size_t slab_b = slab * 2;
+  auto w_goff = [&](int r) -> size_t { return (size_t)(r >> 1) * slab_b + (size_t)(4 * (r & 1) + wave_u) * 1024; };
+  auto w_loff = [&](int r) { return (4 * r + wave_u) * 1024; };
+  auto dma_w = [&](int stage, int buf, int r0, int n) {
+    const unsigned char* ws_ = (const unsigned char*)(wbase + (size_t)stage * 3 * slab);
+    unsigned char* bd_ = Bs + buf * (3 * SLAB_B);
+#pragma unroll
+    for (int r = r0; r < r0 + n; ++r) {
+      // (inline asm, not __builtin_amdgcn_global_load_lds: the compiler cannot tell the DMA's LDS destination (weights)
+      // from the halo buffers, and would drain vmcnt -- i.e. wait out the weight fetch it has just issued -- before
+      // every ds_write that parks a halo piece inside the stage.  Completion is waited for by hand at the stage start.)
+      const unsigned char* ub = ws_ + w_goff(r);
+      const unsigned lds = (unsigned)(__SIZE_TYPE__)(__attribute__((address_space(3))) unsigned char*)(bd_ + w_loff(r));
+      // (M0 is compiler-reserved and not preserved around a statement: it is written in the statement that reads it,
+      // with the one wait state an SALU write of M0 needs before the LDS-DMA that uses it -- nothing inside an asm string
+      // is padded by the compiler.  The "s" operands are SALU results; a value fresh from v_readfirstlane would need five
+      // wait states before the load.)
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds), "v"(lane16), "s"(ub));
+    }
+  };
+
+  // the first stage's weights only depend on the cout tile: requested BEFORE the tile decode (dozens of dependent scalar
+  // loads through the member table), so that their round trip runs under it
+  dma_w(0, 0, 0, W_ROUNDS);
+
   struct Geo { int ty0, tx0, H, W, b; const float* in; float* out; float* pool; const unsigned* in_amax; unsigned* out_amax; unsigned* pool_amax; };
   auto geometry = [&](int t) {
     Geo g;
@@ -555,10 +590,6 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4d_kernel(ConvK p) {
   const bool has1 = NTILE == 2 && t0 + 1 < ntiles;    // (an odd tile count: the last block's second tile is a dummy)
   const Geo g0 = geometry(t0), g1 = geometry(has1 ? t0 + 1 : t0);
 
-  const int nchunks = p.Cin / KC;
-  const int NST = nchunks * 3;
-  const size_t slab = (size_t)p.Cout * 32;            // halfs per tap slab of the whole layer
-  const _Float16* wbase = (const _Float16*)p.wph + (size_t)ct * BN * 32;
 
   // halo piece j of this thread (per tile): 16-byte piece q = idx & 3 of halo pixel idx >> 2, idx = tid + 256 j.
   //   split input : q = 0, 1: hi channels 0-7 / 8-15 of the 16-channel half chunk; q = 2, 3: lo (scaled by 2^11 in HBM)
@@ -661,36 +692,9 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4d_kernel(ConvK p) {
     }
   };
 
-  // weight DMA: round r (0..5) of a wave moves 1-KiB piece q = wave + 4 r of the stage's 24 (8 per tap slab: rounds
-  // 0-1 / 2-3 / 4-5 are slabs 0 / 1 / 2 for every wave).  LDS offset = q KiB; global offset = slab (q / 8) + (q % 8) KiB.
-  constexpr int W_ROUNDS = 6;
-  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-  const unsigned lane16 = (unsigned)lane * 16u;
-  const size_t slab_b = slab * 2;
-  auto w_goff = [&](int r) -> size_t { return (size_t)(r >> 1) * slab_b + (size_t)(4 * (r & 1) + wave_u) * 1024; };
-  auto w_loff = [&](int r) { return (4 * r + wave_u) * 1024; };
-  auto dma_w = [&](int stage, int buf, int r0, int n) {
-    const unsigned char* ws_ = (const unsigned char*)(wbase + (size_t)stage * 3 * slab);
-    unsigned char* bd_ = Bs + buf * (3 * SLAB_B);
-#pragma unroll
-    for (int r = r0; r < r0 + n; ++r) {
-      // (inline asm, not __builtin_amdgcn_global_load_lds: the compiler cannot tell the DMA's LDS destination (weights)
-      // from the halo buffers, and would drain vmcnt -- i.e. wait out the weight fetch it has just issued -- before
-      // every ds_write that parks a halo piece inside the stage.  Completion is waited for by hand at the stage start.)
-      const unsigned char* ub = ws_ + w_goff(r);
-      const unsigned lds = (unsigned)(__SIZE_TYPE__)(__attribute__((address_space(3))) unsigned char*)(bd_ + w_loff(r));
-      // (M0 is compiler-reserved and not preserved around a statement: it is written in the statement that reads it,
-      // with the one wait state an SALU write of M0 needs before the LDS-DMA that uses it -- nothing inside an asm string
-      // is padded by the compiler.  The "s" operands are SALU results; a value fresh from v_readfirstlane would need five
-      // wait states before the load.)
-      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds), "v"(lane16), "s"(ub));
-    }
-  };
-
   // prologue
   float4 areg0[ALD], areg1[ALD];  // (two named arrays, indexed by unrolled inner loops only: anything indexed by the
                                   // half-step variable stays in scratch memory)
-  dma_w(0, 0, 0, W_ROUNDS);
 #pragma unroll
   for (int j = 0; j < ALD; ++j) {
     areg0[j] = *(const float4*)((const char*)g0.in + a_goff[0][j]);
