@@ -575,7 +575,7 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4d_kernel(ConvK p) {
     Geo g;
     int pt = t;
     const int mi = conv_find_member(p, pt);
-    const ConvMember& mem = p.m[mi];
+    const ConvMember mem = p.m[mi];   // (a COPY: the whole record in a few wide scalar loads, not a dependent load per field)
     pt -= mem.tile_start;
     int ty_, tx_;
     conv_split_tile(mem, pt, g.b, ty_, tx_);
@@ -597,6 +597,10 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4d_kernel(ConvK p) {
   // a_goff = BYTE offset of the piece inside the member's input for chunk 0 (the chunk adds a uniform offset)
   unsigned a_goff[NTILE][ALD];
   unsigned a_valid = 0;                               // bit t * 8 + j
+  // (the pixel stride in a vector register: out of scalar registers here, the compiler re-read the kernel argument for
+  // each of the twelve pieces, a scalar load and a wait apiece)
+  int in_stride_v = p.in_stride;
+  asm volatile("" : "+v"(in_stride_v));
   auto halo_offsets = [&](const Geo& g, int t, bool exists) {
 #pragma unroll
     for (int j = 0; j < ALD; ++j) {
@@ -605,7 +609,7 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4d_kernel(ConvK p) {
       const int hy = hp / HTW, hx = hp - hy * HTW;
       const int gy = g.ty0 - 1 + hy, gx = g.tx0 - 1 + hx;
       const bool in = exists && (idx < HP * 4) && ((unsigned)gy < (unsigned)g.H) && ((unsigned)gx < (unsigned)g.W);
-      const unsigned pix = (unsigned)(((g.b * g.H + gy) * g.W + gx) * p.in_stride) * 4u;
+      const unsigned pix = (unsigned)(((g.b * g.H + gy) * g.W + gx) * in_stride_v) * 4u;
       a_goff[t][j] = in ? pix + (IN_SPLIT ? (unsigned)((q >> 1) * 64 + (q & 1) * 16) : (unsigned)(q * 16)) : 0u;
       a_valid |= in ? (1u << (t * 8 + j)) : 0u;
     }
