@@ -224,13 +224,16 @@ __device__ __forceinline__ void conv_publish_amax(unsigned* slot, unsigned* slot
 // exponent e >= 0 with amax * 2^e in [2^13, 2^14) (fp16 tops out at 65504): what a single-accumulator kernel multiplies
 // its input by (exactly, in fp16) so that lo = fp16(x - hi) keeps its bits whatever the layer's magnitude -- unscaled,
 // lo of |x| < 0.25 is an fp16 subnormal (quantum 2^-24) and a layer that lives around 1e-3 would keep 14 bits, not 22.
-// 0 when the slot is unknown, zero, or not finite (the range flag is up in that case).
+// 0 when the slot is unknown, zero, or not finite (the range flag is up in that case).  Capped at 15 -- the largest power of
+// two fp16 holds, so the lift is ONE exact multiplication: a unit whose max is below 0.25 lands lower than [2^13, 2^14),
+// at worst (max 2^-16 x a few) around 1, where the low parts still carry 2^-23 of the top (a bound 2^12 too large
+// passes every magnitude test: tools/experiments/exponent_bias_run.sh).
 __device__ __forceinline__ int conv_act_exponent(const unsigned* slot) {
   if (!slot) return 0;
   const unsigned b = *slot;
   if (b == 0u || b >= 0x7f800000u) return 0;
   const int e = 13 - ((int)(b >> 23) - 127);
-  return e < 0 ? 0 : (e > 30 ? 30 : e);
+  return e < 0 ? 0 : (e > 15 ? 15 : e);
 }
 // 2^k as an fp16 bit pattern, twice (v_pk_mul_f16 operand); k in [-14, 15]
 __device__ __forceinline__ unsigned conv_pk_pow2_f16(int k) {

@@ -624,20 +624,19 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4d_kernel(ConvK p) {
   // staging multiplies hi by 2^e and the format's lo (which carries 2^11) by 2^(e - 11), exactly, in fp16 -- the top of
   // the unit's input lands in [2^13, 2^14), so the UNSCALED low parts the single accumulator needs are normal fp16
   // numbers whatever the layer's magnitude (without it a layer living around 1e-3 kept 14 bits, not 22) -- and the
-  // epilogue multiplies 2^-e back together with the weights' scale.  e = e1 + e2 with both factors representable in
-  // fp16 (2^15 is the largest power of two); a scale-down (e < 11, the lo factor) is never followed by a scale-up.
+  // epilogue multiplies 2^-e back together with the weights' scale.  e <= 15, so 2^e and 2^(e - 11) are fp16 numbers and
+  // the lift is one exact multiplication per value.
   // e is a function of the unit alone, so every grouping of tiles into launches / blocks forms the same bits.
   const int e_t0 = __builtin_amdgcn_readfirstlane(conv_act_exponent(g0.in_amax));
   const int e_t1 = NTILE == 2 ? __builtin_amdgcn_readfirstlane(conv_act_exponent(g1.in_amax)) : 0;
   typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-  // pk_f1 = this thread's first factor for a split-format piece (its pieces are all hi or all lo: q = tid & 3), hi1 / lo1
-  // = the two first factors of an fp32 piece, f2 = the common second factor -- plain registers, no struct (hipcc parks a
-  // struct that is indexed by a lane-dependent select in scratch memory)
-  struct ActScale { unsigned pk_f1, hi1, lo1, f2; };
+  // pk_f1 = this thread's factor for a split-format piece (its pieces are all hi or all lo: q = tid & 3), hi1 / lo1 = the
+  // two factors of an fp32 piece -- plain registers, no struct (hipcc parks a struct that is indexed by a lane-dependent
+  // select in scratch memory)
+  struct ActScale { unsigned pk_f1, hi1, lo1; };
   const int lo_shift = (tid & 2) ? 11 : 0;
   auto act_scale = [&](int e) {
-    const int e1 = e < 15 ? e : 15;
-    return ActScale{conv_pk_pow2_f16(e1 - lo_shift), conv_pk_pow2_f16(e1), conv_pk_pow2_f16(e1 - 11), conv_pk_pow2_f16(e - e1)};
+    return ActScale{conv_pk_pow2_f16(e - lo_shift), conv_pk_pow2_f16(e), conv_pk_pow2_f16(e - 11)};
   };
   const ActScale as0 = act_scale(e_t0), as1 = act_scale(e_t1);
   // piece as fetched -> the 16 bytes (split input) / the hi half4 | lo half4 pair (fp32 input) that go to LDS.  A piece
@@ -646,15 +645,14 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4d_kernel(ConvK p) {
   // there would split the region the sched_group_barriers order
   auto convert = [&](float4& v, int vbit, const ActScale& sc_) {
     const unsigned keep = (unsigned)((int)(a_valid << (31 - vbit)) >> 31);   // all ones / zero
-    struct { h2 hi1, lo1, f2; } sc = {__builtin_bit_cast(h2, sc_.hi1 & keep), __builtin_bit_cast(h2, sc_.lo1 & keep),
-                                      __builtin_bit_cast(h2, sc_.f2)};
+    struct { h2 hi1, lo1; } sc = {__builtin_bit_cast(h2, sc_.hi1 & keep), __builtin_bit_cast(h2, sc_.lo1 & keep)};
     if constexpr (IN_SPLIT) {
       const h2 f1 = __builtin_bit_cast(h2, sc_.pk_f1 & keep);
       float* e = &v.x;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         h2 x = __builtin_bit_cast(h2, e[k]);
-        x = (x * f1) * sc.f2;
+        x = x * f1;
         e[k] = __builtin_bit_cast(float, x);
       }
     } else if constexpr (BF) {
@@ -670,8 +668,8 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4d_kernel(ConvK p) {
       const h2 h01 = __builtin_convertvector(x01, h2), h23 = __builtin_convertvector(x23, h2);
       const h2 l01 = __builtin_convertvector((x01 - __builtin_convertvector(h01, f32x2)) * LO_SCALE, h2);
       const h2 l23 = __builtin_convertvector((x23 - __builtin_convertvector(h23, f32x2)) * LO_SCALE, h2);
-      v = make_float4(__builtin_bit_cast(float, (h01 * sc.hi1) * sc.f2), __builtin_bit_cast(float, (h23 * sc.hi1) * sc.f2),
-                      __builtin_bit_cast(float, (l01 * sc.lo1) * sc.f2), __builtin_bit_cast(float, (l23 * sc.lo1) * sc.f2));
+      v = make_float4(__builtin_bit_cast(float, h01 * sc.hi1), __builtin_bit_cast(float, h23 * sc.hi1),
+                      __builtin_bit_cast(float, l01 * sc.lo1), __builtin_bit_cast(float, l23 * sc.lo1));
     }
   };
   // (set_off: byte offset of the buffer set the pieces go to)
