@@ -67,3 +67,15 @@ def test_committed_pmc_summary_and_layer_table():
     assert len(rows) == 19 and rows[0]["layer"] == "conv1_1+conv1_2"
     gf = sum(float(r["algorithmic_gflop"]) for r in rows)
     assert abs(gf - 5021.6) < 2.0          # 5021.62 GFLOP per image (the deconv's 0.1 GFLOP aside)
+
+
+def test_committed_counters_belong_to_the_committed_kernels():
+    """profiles/r03_pmc.json carries the hash of the kernel sources it was measured on (tools/kernel_hash.py: comments and
+    white space do not count); bench.py only quotes traffic / MFMA-busy from it while that matches -- so must the tree."""
+    import sys
+    sys.path.insert(0, ROOT)
+    from tools.kernel_hash import kernel_source_hash
+    d = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc.json")))
+    assert d["kernel_source_hash"] == kernel_source_hash()
+    b = json.load(open(os.path.join(ROOT, "profiles", "r03_bench.json")))
+    assert b["roofline"]["traffic"] is not None and b["roofline"]["mfma_busy"] is not None
