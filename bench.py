@@ -158,6 +158,14 @@ def main():
     ap.add_argument("--no-flip", action="store_true", help="TEST.FLIP = false")
     ap.add_argument("--no-calib", action="store_true", help="skip the matrix-pipe calibration (N=1, ~0.3 s after the timed region)")
     ap.add_argument("--no-latency", action="store_true", help="skip the single-image (un-pipelined) latency leg")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="N=1: run the N>1 code path on a ONE-rank process group (with --backend nccl: a 1-rank RCCL "
+                         "communicator) -- init_process_group, the device-tensor all_to_all_single and detect_import of the "
+                         "buffer RCCL produced all execute on a single-GPU box")
+    ap.add_argument("--sustain-seconds", type=float, default=6.0,
+                    help="N=1: after the timed region, back-to-back steps for this long in the headline mode -> 'sustained' "
+                         "(0 to skip); --steps still defines 'value'")
+    ap.add_argument("--no-mixed", action="store_true", help="skip the mixed-shape image stream leg ('mixed_shapes', N=1)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -176,9 +184,12 @@ def main():
                          "all ranks on one GPU for validation)" % (args.gpus, world, n_dev))
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    dist_path = world > 1 or args.force_dist      # the N>1 schedule (lane sets, export, gather, import); N=1 only with --force-dist
+    if dist_path:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", "29533")
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
@@ -223,7 +234,7 @@ def main():
         units[(i, u)] = (t, H, W, im_h, im_w, s, flip)
     del cache
     export = [torch.empty((cfg.TEST.N_DETS_PER_MODULE, 5), dtype=torch.float32, device=dev)
-              for _ in range(len(mine))] if world > 1 else None
+              for _ in range(len(mine))] if dist_path else None
     thresh = 0.05
     last = {}
 
@@ -232,6 +243,7 @@ def main():
     lanes = fd.lanes
     if world == 1:
         unit_list = [(units[(0, u)][0].data_ptr(),) + units[(0, u)][1:] for u in range(n_units)]
+    if not dist_path:
         if args.host_input == "blobs":
             host_list = [(units[(0, u)][0].cpu().numpy(),) + units[(0, u)][1:] for u in range(n_units)]
         elif args.host_input == "image":
@@ -258,26 +270,23 @@ def main():
     def finish_window(w):
         ls, ex = lane_sets[w], export_sets[w]
         counts = ls[0].detect_export_many(ls, [e.data_ptr() for e in ex], cfg.TEST.N_DETS_PER_MODULE) if ls else []
-        parts = {i: [] for i in range(world)}
+        local = {i: [] for i in range(world)}   # per image: the units' export buffers as they are (no concatenation)
         for m, (i, u) in enumerate(mine):
             if counts[m]:
-                parts[i].append(ex[m][:min(counts[m], cfg.TEST.N_DETS_PER_MODULE)])
-        empty = torch.zeros((0, 5), dtype=torch.float32, device=dev)
-        local = {i: (torch.cat(p, 0) if p else empty) for i, p in parts.items()}
-        got = pyramid.gather_window(local, world, rank, world, device=dev)
+                local[i].append(ex[m][:min(counts[m], cfg.TEST.N_DETS_PER_MODULE)])
+        got = pyramid.gather_window(local, world, rank, world, device=dev, force_collective=args.force_dist)
         state["collectives"] += 1
-        torch.cuda.synchronize()
-        for i, t in got.items():
+        for i, t in got.items():            # (gather_window has synchronised on the received header rows)
             net.detect_begin()
             t = t.contiguous()
             net.detect_import(t.data_ptr(), int(t.shape[0]))
             last[i] = net.detect_finish(cfg.TEST.NMS_METHOD, cfg.TEST.NMS_THRESH)
 
     def step():
-        if world == 1 and args.mode == "streams":  # the older per-unit-streams schedule: one image at a time
+        if not dist_path and args.mode == "streams":  # the older per-unit-streams schedule: one image at a time
             last[0] = fd.detect(unit_list, thresh, on_device=True)[0]
             return
-        if world == 1:
+        if not dist_path:
             # two images in flight: image k's box merging / read-back overlaps image k+1's convolutions
             if args.host_input == "blobs":
                 fd.submit(host_list, thresh, on_device=False)
@@ -306,9 +315,9 @@ def main():
         state["pending"] = w
 
     def fence():
-        while world == 1 and fd.pending() > 0:
+        while not dist_path and fd.pending() > 0:
             last[0] = fd.collect()[0]
-        if world > 1 and state["pending"] is not None:
+        if dist_path and state["pending"] is not None:
             finish_window(state["pending"])
             state["pending"] = None
         for ln in lanes + getattr(fd, "_heads", []):
@@ -347,14 +356,35 @@ def main():
                 for f in a:
                     a[f] += v[f]
             ln.prof_enable(False)
-    if dist is not None:
+    if dist is not None and world > 1:
         te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
 
+    # ---- sustained rate (N=1, headline mode): back-to-back steps for several seconds right after the timed region --
+    #      the timed region itself is a quarter of a second on a chip that is power-limited and drifts; `value` stays
+    #      what --steps defines.  HIP events are off here (they bracket every launch of the timed region).
+    sustained = None
+    if not dist_path and args.mode == "group" and args.sustain_seconds > 0 and not args.host_input:
+        marks = []
+        t1 = time.perf_counter()
+        while True:
+            step()
+            marks.append(time.perf_counter())
+            if marks[-1] - t1 >= args.sustain_seconds:
+                break
+        fence()
+        t2 = time.perf_counter()
+        marks = np.asarray(marks) - t1
+        sustained = {"seconds": t2 - t1, "steps": len(marks), "value": len(marks) / (t2 - t1), "unit": "images/s",
+                     "first_second": float(np.sum(marks <= 1.0)),
+                     "last_second": float(np.sum(marks > marks[-1] - 1.0)),
+                     "note": "same resident pyramid, same pipeline as the timed region, per-launch HIP events off; "
+                             "first / last second = steps completed in that second"}
+
     # ---- single-image latency: ONE image, nothing else in flight, submit -> merged detections on the host
     latency_ms = None
-    if world == 1 and args.mode == "group" and not args.no_latency and not args.host_input:
+    if not dist_path and args.mode == "group" and not args.no_latency and not args.host_input:
         lat = []
         for _ in range(7):
             torch.cuda.synchronize()
@@ -379,11 +409,60 @@ def main():
             return v.value
         pipe = {"operands_constant": pipe_rate(0, 1), "operands_random": pipe_rate(0, 0),
                 "operands_random_half_of_activations_zero": pipe_rate(4, 0)}
+    # ---- mixed-shape image stream (BASELINE config 4 "WIDER-val-shaped" as a RATE; the reference's hot loop runs images
+    #      of different sizes, lib/test.py:239-244): uint8 images of 8 WIDER-like shapes, consecutive images never of the
+    #      same shape, through DevicePyramid + FusedDetector.submit / collect exactly as test.inference_worker does --
+    #      upload, pyramid on the device, re-plan per shape, two images in flight.  Pass 1 lets every grow-only buffer
+    #      reach its largest shape; pass 2 is timed and must not allocate.
+    mixed = None
+    if not dist_path and args.mode == "group" and not args.no_mixed and not args.host_input and rank == 0:
+        from smallhardface_amd.test import DevicePyramid
+        from smallhardface_amd.test_utils import pyramid_scales
+        shapes = [(768, 1024), (683, 1024), (1024, 732), (1365, 1024), (576, 1024), (1024, 819), (1536, 1024), (1024, 1024)]
+        rngm = np.random.default_rng(4242)
+        stream = [rngm.integers(0, 256, shapes[k % len(shapes)] + (3,)).astype(np.uint8) for k in range(32)]
+        gflop = 0.0
+        for im_ in stream:
+            for sc_ in pyramid_scales(im_.shape):
+                _, _, H_, W_ = caffe.pyramid_level_shape(im_.shape[0], im_.shape[1], sc_, cfg.MAX_RESOLUTION)
+                gflop += n_flip * pyramid.level_flops(H_, W_) / 1e9
+        dpm = DevicePyramid(net, n_slots=2)
+
+        def run_stream():
+            n_boxes = 0
+            for im_ in stream:
+                fd.submit(dpm.units(im_, net=fd.next_head()), thresh, on_device=True)
+                if fd.pending() > 1:
+                    n_boxes += len(fd.collect()[0])
+            while fd.pending():
+                n_boxes += len(fd.collect()[0])
+            return n_boxes
+        fence()
+        a0 = caffe.alloc_counts()
+        run_stream()
+        fence()
+        a1 = caffe.alloc_counts()
+        t1 = time.perf_counter()
+        n_boxes = run_stream()
+        fence()
+        dtm = time.perf_counter() - t1
+        a2 = caffe.alloc_counts()
+        resident_tflops = (sum(pyramid.level_flops(v[1], v[2]) for v in unit_list) / 1e12) * (args.steps / elapsed)
+        mixed = {"value": len(stream) / dtm, "unit": "images/s", "images": len(stream),
+                 "shapes": ["%dx%d" % hw for hw in shapes], "gflop_per_image_mean": gflop / len(stream),
+                 "algorithmic_tflops": gflop / 1e3 / dtm, "resident_algorithmic_tflops": resident_tflops,
+                 "flop_normalised_vs_resident": (gflop / 1e3 / dtm) / resident_tflops,
+                 "hip_mallocs_first_pass": a1[0] - a0[0], "hip_mallocs_after_first_pass": a2[0] - a1[0],
+                 "pinned_host_allocs_after_first_pass": a2[1] - a1[1], "voted_boxes": int(n_boxes),
+                 "path": "host uint8 image -> upload (pageable, 2-3 MB) -> shf_make_pyramid_level x 10 -> grouped pass, two images "
+                         "in flight (test.inference_worker's loop); consecutive images always differ in shape"}
+        del dpm
+
     # ---- reduced-precision leg (BASELINE configs C3 / C5 name bf16; the headline above stays the fp32-class mode): after
     #      and outside the timed region -- throughput of the same image pipeline in the mode, its score drift against the
     #      exact fp32 mode on one mid-size level (every anchor), and how many of the fp32 mode's boxes it reproduces
     reduced = None
-    if world == 1 and args.mode == "group" and args.conv_mode == "f16x3" and not args.no_reduced and not args.host_input:
+    if not dist_path and args.mode == "group" and args.conv_mode == "f16x3" and not args.no_reduced and not args.host_input:
         def level_scores():
             d, H_, W_, im_h, im_w, sc_, _ = units[(0, 4 if n_units > 4 else 0)]
             net.blobs['data'].reshape(1, 3, H_, W_)
@@ -460,8 +539,8 @@ def main():
                                "/".join("%dx%d" % hw for hw in lv[::n_flip]), " x flip" if cfg.TEST.FLIP else "",
                                n_units, gflop_image, args.conv_mode, cfg.TEST.NMS_METHOD),
                 "images_per_step": world, "units_per_image": n_units, "lanes_per_gpu": len(lanes),
-                "unit_execution": args.mode, "shard": args.shard if world > 1 else None,
-                "parallelism": ("single GPU" if world == 1 else
+                "unit_execution": args.mode, "shard": args.shard if dist_path else None,
+                "parallelism": ("single GPU" if not dist_path else
                                 ("pyramid units sharded 1-of-each-kind per GPU per window" if args.shard == "window" else
                                  "strict one-scale-per-GPU: level l (all its flips, every image of the window) on rank "
                                  "l mod N") + "; one all_to_all of detections per window, each image's rows to its owner rank, over %s"
@@ -470,7 +549,7 @@ def main():
                 "detections_last_image": int(len(next(iter(last.values())))) if last else 0,
             },
         }
-        if world > 1:
+        if dist_path:
             out["rccl_ranks"] = int(dist.get_world_size()) if args.backend == "nccl" else 0
             out["collective_backend"] = str(dist.get_backend())
             out["collectives_issued_rank0"] = int(state["collectives"])
@@ -532,6 +611,10 @@ def main():
                                                  "activations this workload's convolutions read are 41-54 % zeros from conv3_2 on: "
                                                  "tools/diag_zero_fraction.py, profiles/r03_mfma_power.txt)",
             }
+        if sustained is not None:
+            out["sustained"] = sustained
+        if mixed is not None:
+            out["mixed_shapes"] = mixed
         if reduced is not None:
             out["reduced_precision"] = reduced
         if world == 1 and not args.no_cpu_baseline:

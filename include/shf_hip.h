@@ -104,6 +104,10 @@ int shf_net_set_layer_products(shf_net* net, const char* layer, int nprod);
  * shared by a net and its lanes); on the fused path shf_detect_finish / shf_detect_export(_many) fail with
  * "split-fp16 range exceeded ..." so that the caller can re-run the image in mode 0 -- never a silent inf/NaN. */
 long long shf_net_range_fallbacks(shf_net* net);
+/* (Re)allocations this process has made so far in the runtime's grow-only device / pinned-host buffers (Blob::Reshape
+ * semantics, caffe/src/caffe/blob.cpp:22-50: capacity only ever grows; syncedmem.cpp:15-50 is where Caffe allocates).  A
+ * stream of images whose shapes were all seen before must leave both counts unchanged.  Measurement only. */
+void shf_alloc_counts(long long* device_allocs, long long* pinned_host_allocs);
 
 /* ---- fused per-image path (device-resident pyramid; lib/test.py:109-178) ---- */
 /* detect(): begin an image */

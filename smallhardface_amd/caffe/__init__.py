@@ -409,3 +409,12 @@ def pyramid_level_shape(im_h, im_w, scale, max_resolution):
     if lib.shf_pyramid_level_shape(int(im_h), int(im_w), float(scale), int(max_resolution), *[C.byref(v) for v in o]):
         raise ValueError("pyramid_level_shape: bad geometry %r" % ((im_h, im_w, scale, max_resolution),))
     return tuple(v.value for v in o)
+
+
+def alloc_counts():
+    """(device, pinned host) (re)allocations the runtime's grow-only buffers have made in this process so far
+    (C ABI shf_alloc_counts): unchanged by a stream of images whose shapes were all seen before."""
+    lib = _lib.load(require_gpu=False)
+    d, h = C.c_longlong(0), C.c_longlong(0)
+    lib.shf_alloc_counts(C.byref(d), C.byref(h))
+    return int(d.value), int(h.value)

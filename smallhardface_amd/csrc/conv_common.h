@@ -145,6 +145,13 @@ typedef float cs_f32x2 __attribute__((ext_vector_type(2)));
 typedef float cs_f32x16 __attribute__((ext_vector_type(16)));
 // (ylim, xlim) = rows / columns of the block tile that are inside the image: only those count for `amax` -- the unit's
 // max must not depend on how the launch tiles the map
+// max(a, |v|) on the bit patterns (a >= 0): |NaN| > inf > every finite value, so a NaN output survives into the
+// range flag (conv_raise_range_flag tests !(amax <= 65504)) instead of being dropped by fmaxf
+__device__ __forceinline__ float conv_absmax_bits(float a, float v) {
+  const unsigned ua = __builtin_bit_cast(unsigned, a), uv = __builtin_bit_cast(unsigned, v) & 0x7fffffffu;
+  return __builtin_bit_cast(float, uv > ua ? uv : ua);
+}
+
 template <int BN, bool RELU>
 __device__ __forceinline__ void conv_stage_tile_pk(float* __restrict__ Cs, const cs_f32x16 am, const cs_f32x16 ac,
                                                    float inv, float bv, int ly0, int kh, int cl, float& amax, int ylim,
@@ -159,8 +166,8 @@ __device__ __forceinline__ void conv_stage_tile_pk(float* __restrict__ Cs, const
       v = v + cs_f32x2{bv, bv};
       if (RELU) v = __builtin_elementwise_max(v, cs_f32x2{0.f, 0.f});
       if (ly0 + (sp >> 1) < ylim) {  // fp16 range guard + activation exponent (v_max3 with abs modifiers)
-        if (lx < xlim) amax = fmaxf(amax, fabsf(v[0]));
-        if (lx + 1 < xlim) amax = fmaxf(amax, fabsf(v[1]));
+        if (lx < xlim) amax = conv_absmax_bits(amax, v[0]);   // (on the bit patterns: a NaN outranks everything
+        if (lx + 1 < xlim) amax = conv_absmax_bits(amax, v[1]);  // and raises the flag; fmaxf would drop it)
       }
       float* d = Cs + ((ly0 + (sp >> 1)) * 16 + lx) * (BN + CS_PAD) + cl;
       d[0] = v[0];

@@ -951,7 +951,7 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4d_kernel(ConvK p) {
     tile_out(acc0, g0, true, e_t0, amax0);
     if constexpr (NTILE == 2) tile_out(acc1, g1, has1, e_t1, amax1);
   }
-  conv_raise_range_flag(p.range_flag, fmaxf(amax0, amax1));
+  conv_raise_range_flag(p.range_flag, conv_absmax_bits(amax0, amax1));
   conv_amax_commit(g0.out_amax, seen0, g0.pool ? g0.pool_amax : nullptr, seen0p, amax0);
   if constexpr (NTILE == 2) {
     if (has1) conv_amax_commit(g1.out_amax, seen1, g1.pool ? g1.pool_amax : nullptr, seen1p, amax1);   // (wave-uniform)
@@ -1102,7 +1102,7 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
     for (int k = 0; k < NPATCH; ++k) {
       const int idx = tid + 512 * k;
       if (idx < 3 * PH * PW) patch[idx] = pv[k];
-      amax1 = fmaxf(amax1, fabsf(pv[k]));  // the image itself is split to fp16 hi/lo for conv1_1's MFMAs
+      amax1 = conv_absmax_bits(amax1, pv[k]);  // the image itself is split to fp16 hi/lo for conv1_1's MFMAs
     }
     if (tid < BN) bias2L[tid] = p.bias ? bias2v : 0.f;
     if (tid < HPP) {
@@ -1315,7 +1315,7 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
           for (int k = 0; k < NPF; ++k) {
             const int idx = ptid + 256 * k;
             if (idx < 3 * PH * PW) patch[idx] = pvn[k];
-            amax1 = fmaxf(amax1, fabsf(pvn[k]));
+            amax1 = conv_absmax_bits(amax1, pvn[k]);
           }
 #pragma unroll
           for (int k = 0; k < (HPP + 255) / 256; ++k) {
@@ -1374,7 +1374,7 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
     }
     conv_amax_commit(mem.out_amax, seen, mem.pool ? mem.pool_amax : nullptr, seenp, amax);   // (producers hold no outputs)
   }
-  conv_raise_range_flag(p.range_flag, fmaxf(amax, amax1));
+  conv_raise_range_flag(p.range_flag, conv_absmax_bits(amax, amax1));
   if (!PERSIST || !has_next) break;
   // the walk's next tile: its patch, flags and first weight stage are in flight or parked; conv1_1 may overwrite the halo
   // tiles once every consumer is out of the K loop (they are: the epilogue is behind it)

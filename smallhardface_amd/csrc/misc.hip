@@ -57,6 +57,16 @@ int launch_maxpool(const View& in, const View& out, int k, int stride, int pad, 
   return 0;
 }
 
+// A pooled blob's activation-exponent slot: max |pooled| <= max |input|, so the input's published maximum serves as
+// the bound.  RAISED, never copied: the slot may be shared (concat members use their owner's) and other producers raise it.
+__global__ void amax_raise_kernel(unsigned* dst, const unsigned* src) { atomicMax(dst, *src); }
+
+int launch_amax_raise(unsigned* dst, const unsigned* src, hipStream_t s) {
+  hipLaunchKernelGGL(amax_raise_kernel, dim3(1), dim3(1), 0, s, dst, src);
+  SHF_HIP_OK(hipGetLastError());
+  return 0;
+}
+
 // out[b,y,x,c] = sum_{a,bb} in[b,(y+pad-a)/s,(x+pad-bb)/s,c] * w[c,a,bb] over taps whose
 // source index is integral and in range (col2im accumulation order a-major, like im2col.cpp:168-185).
 // Grid: x over (ox, channel quad) of one output row, y = output row, z = batch -- 32-bit index math only (the

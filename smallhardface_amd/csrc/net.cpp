@@ -13,6 +13,7 @@
 //     one fused device-side tail (no D2H, no Python re-entry);
 //   * buffers are grow-only and shape changes re-plan nothing but pointers/sizes.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <deque>
@@ -40,11 +41,16 @@ void set_error(const std::string& msg) { g_err = msg; }
     if ((expr) != 0) throw std::runtime_error(g_err);      \
   } while (0)
 
+// (re)allocations made by the grow-only buffers of this process: a new level shape re-plans sizes and pointers and only
+// allocates where a buffer has to grow (shf_alloc_counts; bench.py's mixed-shape leg reports them after its first pass)
+static std::atomic<long long> g_dev_allocs{0}, g_host_allocs{0};
+
 struct DevBuf {
   void* p = nullptr;
   size_t cap = 0;
   void ensure(size_t bytes) {
     if (bytes <= cap) return;
+    ++g_dev_allocs;
     if (p) HIP_THROW(hipFree(p));
     p = nullptr;
     size_t want = bytes + bytes / 8;  // grow-only with slack (Blob::Reshape never shrinks, blob.cpp:46-50)
@@ -66,6 +72,7 @@ struct HostBuf {
   void ensure(size_t bytes) {
     if (bytes <= cap) return;
     float* np = nullptr;
+    ++g_host_allocs;
     size_t want = std::max<size_t>(bytes + bytes / 8, 64);
     HIP_THROW(hipHostMalloc((void**)&np, want, hipHostMallocDefault));
     if (p) {
@@ -1229,7 +1236,14 @@ void shf_net::forward_ops(bool fused_path, float im_h, float im_w, float im_scal
           a.in_split = ib.split_fused;
           a.out_split = blobs[L.tops[0]].split_fused;
         }
-        if (fused_path && split16 && L.first_src >= 0) {
+        // bf16 mode has the fused first pair on the producer/consumer kernel only: without its preconditions conv1_1
+        // runs on its own kernel and this layer as a plain bf16 convolution (the fp16 modes fall back to the 8-wave
+        // FUSE1 form instead)
+        auto pair_fused = [&](const Layer& F1, const Layer& F2) {
+          if (!bf) return true;
+          return conv_f16x3_uses_pc() && F1.params[0]->first_frag_b.p != nullptr && F1.nout == 64 && F2.nout == 64;
+        };
+        if (fused_path && split16 && L.first_src >= 0 && pair_fused(layers[L.first_src], L)) {
           Layer& F = layers[L.first_src];
           Blob& db = blobs[F.bottoms[0]];
           a.img = db.ext_dev ? db.ext_dev : (const float*)db.dev.p;
@@ -1238,7 +1252,8 @@ void shf_net::forward_ops(bool fused_path, float im_h, float im_w, float im_scal
           a.b1 = F.params.size() > 1 ? (const float*)F.params[1]->raw.p : nullptr;
         }
         if (fused_path && conv_mode >= 1 && L.first_dst >= 0 &&
-            (bf ? layers[L.first_dst].params[0]->packed16b.p : layers[L.first_dst].params[0]->packed16.p))
+            (bf ? layers[L.first_dst].params[0]->packed16b.p : layers[L.first_dst].params[0]->packed16.p) &&
+            pair_fused(L, layers[L.first_dst]))
           break;  // computed inside the next conv's halo staging
         const double fl = conv_flops(L, ib.shape, blobs[L.tops[0]].shape);
         const double by = 4.0 * (ib.count() + blobs[L.tops[0]].count() + L.params[0]->count());
@@ -1277,7 +1292,7 @@ void shf_net::forward_ops(bool fused_path, float im_h, float im_w, float im_scal
         ProfScope ps(pf, st, PC_POOL, 0, 4.0 * (blobs[L.bottoms[0]].count() + blobs[L.tops[0]].count()));
         CHECK_RC(launch_maxpool(view_of(L.bottoms[0]), view_of(L.tops[0]), L.k, L.stride, L.pad, st));
         if (amax_slot(L.tops[0]))  // max |pooled| <= max |input|: the bound serves as the pooled blob's activation exponent
-          HIP_THROW(hipMemcpyAsync(amax_slot(L.tops[0]), amax_slot(L.bottoms[0]), 4, hipMemcpyDeviceToDevice, st));
+          CHECK_RC(launch_amax_raise(amax_slot(L.tops[0]), amax_slot(L.bottoms[0]), st));
         break;
       }
       case OP_DECONV: {
@@ -1596,6 +1611,11 @@ int shf_net_set_layer_products(shf_net* net, const char* layer, int nprod) {
 }
 
 long long shf_net_range_fallbacks(shf_net* net) { return net->sh->range_fallbacks; }
+
+void shf_alloc_counts(long long* device_allocs, long long* pinned_host_allocs) {
+  if (device_allocs) *device_allocs = g_dev_allocs.load();
+  if (pinned_host_allocs) *pinned_host_allocs = g_host_allocs.load();
+}
 
 int shf_net_record_event(shf_net* net) {
   API_BEGIN
@@ -1962,10 +1982,14 @@ int shf_detect_add_levels(shf_net* net, int n, shf_net** members, const float* c
         HIP_THROW(hipStreamWaitEvent(net->stream, net->ev_convs, 0));
       } else {
         // (every n: a one-unit pass over two heads needs the same hand-over as a ten-unit one)
-        HIP_THROW(hipEventRecord(net->ev_convs, net->stream));
         if (net->pred && net->pred->ev_mark) HIP_THROW(hipStreamWaitEvent(net->stream, net->pred->ev_mark, 0));
-        ProfScope ps(net->prof, net->stream, PC_TAIL, tfl, tby);
-        CHECK_RC(launch_tail_group(targs, tws, tb, tp, n, net->stream, nullptr, 1));
+        {
+          ProfScope ps(net->prof, net->stream, PC_TAIL, tfl, tby);
+          CHECK_RC(launch_tail_group(targs, tws, tb, tp, n, net->stream, nullptr, 1));
+        }
+        // recorded AFTER phase 1: its reset kernel zeroes the member lanes' activation-exponent slots, which the
+        // successor head's first convolutions (early_start waits for this event only) publish into and read
+        HIP_THROW(hipEventRecord(net->ev_convs, net->stream));
       }
       for (int m = 0; m < n; ++m) {  // hand-over mark for passes issued from another head without a pipeline
         shf_net* mb = members[m];

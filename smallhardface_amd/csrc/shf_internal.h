@@ -92,6 +92,7 @@ size_t packed_conv_weight_floats(int Cout, int Cin, int k);
 
 // ---- misc layers -------------------------------------------------------------
 int launch_maxpool(const View& in, const View& out, int k, int stride, int pad, hipStream_t s);
+int launch_amax_raise(unsigned* dst, const unsigned* src, hipStream_t s);
 // depthwise transposed conv (group == C), weights (C,1,k,k) Caffe layout
 int launch_deconv_depthwise(const View& in, const View& out, const float* w, const float* bias, int k,
                             int stride, int pad, hipStream_t s, int* range_flag = nullptr, unsigned* out_amax = nullptr);

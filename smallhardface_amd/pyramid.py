@@ -46,14 +46,37 @@ def my_units(rank, world, n_images, n_units, shard="window", units_per_level=2):
 
 # rows a (sender, image) block can carry; grow-only, the same on every rank (see gather_window)
 _GATHER_CAP = {"rows": 4096}
+# the exchange's blocks, allocated once per (device, world, slots, cap) and reused by every window (two sets, used in
+# turn: a caller that pipelines windows may still hold views of the previous window's receive block)
+_GATHER_BUFS = {}
 
 
-def gather_window(local, n_images, rank, world, device=None, group=None):
+def _gather_buffers(dev, world, per_owner, cap):
+    import torch
+    key = (str(dev), world, per_owner, cap)
+    ent = _GATHER_BUFS.get(key)
+    if ent is None:
+        for k in [k for k in _GATHER_BUFS if k[:3] == key[:3]]:       # a smaller cap of the same geometry: drop it
+            del _GATHER_BUFS[k]
+        pin = torch.device(dev).type == "cuda"
+        ent = {"turn": 0, "sets": [
+            {"send": torch.zeros((world, per_owner, 1 + cap, 5), dtype=torch.float32, device=dev),
+             "recv": torch.zeros((world, per_owner, 1 + cap, 5), dtype=torch.float32, device=dev),
+             "hdr": torch.zeros((world, per_owner, 5), dtype=torch.float32, pin_memory=pin),
+             "head": torch.zeros((world, per_owner, 2), dtype=torch.float32, pin_memory=pin)} for _ in range(2)]}
+        _GATHER_BUFS[key] = ent
+    ent["turn"] ^= 1
+    return ent["sets"][ent["turn"]]
+
+
+def gather_window(local, n_images, rank, world, device=None, group=None, force_collective=False):
     """Exchange the window's detections: every rank sends each image's rows to the image's OWNER only.
 
-    ``local[i]`` is this rank's (n_i, 5) float32 tensor of detections for window image i
-    (possibly empty).  Returns {i: (N_i, 5) tensor} for the images this rank owns, rows
-    concatenated in rank order (deterministic).  Uses torch.distributed when world > 1.
+    ``local[i]`` is this rank's (n_i, 5) float32 tensor of detections for window image i (possibly empty), or a LIST
+    of such tensors (the per-unit export buffers: copied straight into the send block, no concatenation first).
+    Returns {i: (N_i, 5) tensor} for the images this rank owns, rows concatenated in rank order (deterministic).
+    Uses torch.distributed when world > 1 -- or with ``force_collective`` on a 1-rank group: the same code path, which
+    is how the RCCL branch is executed on a single-GPU box (tests/test_gpu_fullsize.py, bench.py --force-dist).
 
     ONE collective per window (all_to_all_single; RCCL on GPUs, gloo in the CPU tests) and one host
     synchronisation, on its result: the block rank s sends for an image is (1 + cap) rows of 5 floats, row 0 =
@@ -62,33 +85,65 @@ def gather_window(local, n_images, rank, world, device=None, group=None):
     everybody learns it from row 0 (every rank receives a block from every sender), so all ranks agree -- without
     another collective -- to repeat the exchange once with cap = the next power of two that fits.  An owner thus
     receives world x images-it-owns blocks instead of every rank receiving everything (the round-2 all_gather pair).
+
+    Host side (round 4): the send / receive blocks are allocated once and reused; all header rows of a window go up
+    as ONE host-built tensor copy (they were ~3 scalar device writes per image), rows beyond a block's count are never
+    read, so nothing is cleared; the header rows come back through one pinned copy.
     """
     import torch
-    if world == 1:
-        return {i: local[i] for i in range(n_images)}
+
+    def parts_of(i):
+        t = local[i]
+        return [p for p in (t if isinstance(t, (list, tuple)) else [t]) if p.shape[0] > 0]
+
+    if world == 1 and not force_collective:
+        out = {}
+        for i in range(n_images):
+            ps = parts_of(i)
+            first = local[i][0] if isinstance(local[i], (list, tuple)) and len(local[i]) else local[i]
+            out[i] = ps[0] if len(ps) == 1 else (torch.cat(ps, 0) if ps else
+                                                  torch.zeros((0, 5), dtype=torch.float32,
+                                                              device=device if device is not None else getattr(first, "device", "cpu")))
+        return out
     import torch.distributed as dist
-    dev = device if device is not None else local[0].device
+    if device is not None:
+        dev = device
+    else:
+        t0 = local[0]
+        dev = (t0[0] if isinstance(t0, (list, tuple)) else t0).device
     out_dev = dev
-    if dist.get_backend(group) == "gloo" and torch.device(dev).type != "cpu":
+    to_host = dist.get_backend(group) == "gloo" and torch.device(dev).type != "cpu"
+    if to_host:
         # gloo (CPU tests / one-GPU validation) exchanges host tensors; RCCL exchanges device tensors
-        local = {i: t.cpu() for i, t in local.items()}
         dev = torch.device("cpu")
     per_owner = (n_images + world - 1) // world          # image slots per destination rank (image i -> slot i // world)
-    counts = [int(local[i].shape[0]) for i in range(n_images)]   # host-known: shapes of this rank's own tensors
+    parts = [parts_of(i) for i in range(n_images)]
+    counts = [sum(int(p.shape[0]) for p in ps) for ps in parts]   # host-known: shapes of this rank's own tensors
     biggest = max(counts) if counts else 0
     while True:
         cap = _GATHER_CAP["rows"]
-        send = torch.zeros((world, per_owner, 1 + cap, 5), dtype=torch.float32, device=dev)
+        buf = _gather_buffers(dev, world, per_owner, cap)
+        send, recv, hdr = buf["send"], buf["recv"], buf["hdr"]
+        hdr.zero_()
+        hdr[:, :, 1] = float(biggest)
         for i in range(n_images):
             n = min(counts[i], cap)
-            blk = send[image_owner(i, world), i // world]
-            blk[0, 0] = float(n)
-            if n:
-                blk[1:1 + n] = local[i][:n]
-        send[:, :, 0, 1] = float(biggest)
-        recv = torch.empty_like(send)
+            hdr[image_owner(i, world), i // world, 0] = float(n)
+            blk, at = send[image_owner(i, world), i // world], 1
+            for p_ in parts[i]:
+                take = min(int(p_.shape[0]), 1 + n - at)
+                if take <= 0:
+                    break
+                blk[at:at + take].copy_(p_[:take], non_blocking=True)     # (device -> host for gloo-on-GPU validation)
+                at += take
+        send[:, :, 0, :].copy_(hdr, non_blocking=True)   # every header row of the window in one copy
+        if to_host:
+            torch.cuda.synchronize()                     # (validation path: the rows came down from the GPU)
         dist.all_to_all_single(recv.view(world, -1), send.view(world, -1), group=group)
-        head = recv[:, :, 0, :2].cpu().numpy()           # the one host synchronisation: [sender][slot] -> (rows, sender's max)
+        buf["head"].copy_(recv[:, :, 0, :2])             # the one host synchronisation: [sender][slot] -> (rows, sender's max)
+        if torch.device(dev).type == "cuda":
+            torch.cuda.current_stream(dev).synchronize()
+        head = buf["head"].numpy()
         need = int(head[:, :, 1].max())
         if need <= cap:
             break
@@ -98,8 +153,9 @@ def gather_window(local, n_images, rank, world, device=None, group=None):
     for i in range(n_images):
         if image_owner(i, world) != rank:
             continue
-        parts = [recv[s, i // world, 1:1 + int(head[s, i // world, 0])] for s in range(world) if head[s, i // world, 0] > 0]
-        out[i] = (torch.cat(parts, 0) if parts else torch.zeros((0, 5), dtype=torch.float32, device=dev)).to(out_dev)
+        got = [recv[s, i // world, 1:1 + int(head[s, i // world, 0])] for s in range(world) if head[s, i // world, 0] > 0]
+        out[i] = (got[0] if len(got) == 1 else
+                  (torch.cat(got, 0) if got else torch.zeros((0, 5), dtype=torch.float32, device=dev))).to(out_dev)
     return out
 
 

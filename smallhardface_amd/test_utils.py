@@ -19,6 +19,18 @@ offline, the functions are named instead):
   ``S[sx] * a0 + S[sx + cn] * a1`` with the float coefficients widened to double, rows first, then
   ``S0[x] * b0 + S1[x] * b1``; products and sums are separate roundings.
 
+
+One exception to the two-tap path, also restated (round 4): ``cv::resize`` turns INTER_LINEAR into INTER_AREA when both
+scale factors are exactly 2x down -- ``iscale = saturate_cast<int>(scale)`` (= cvRound), ``is_area_fast = |scale_x -
+iscale_x| < DBL_EPSILON && |scale_y - iscale_y| < DBL_EPSILON``, ``if (interpolation == INTER_LINEAR && is_area_fast &&
+iscale_x == 2 && iscale_y == 2) interpolation = INTER_AREA`` -- and then runs ``resizeAreaFast_Invoker<double, double,
+ResizeAreaFastNoVec>``: interior outputs are ``(S[y][x] + S[y][x+1] + S[y+1][x] + S[y+1][x+1]) * (double)0.25f`` summed
+left to right in one chain (the unrolled ``sum += S[ofs[0]] + S[ofs[1]] + S[ofs[2]] + S[ofs[3]]``, offsets row-major);
+outputs whose 2x2 window leaves an odd-sized source (the last column when the width is odd and rounds up, every output
+of the last row when the height is) take the border loop: the in-image taps added one by one, row-major, and
+``(float)sum / count`` -- a FLOAT division, widened back to double.  A level scale of exactly 0.5 is reachable
+(TEST.SCALES 600 on a 1200-short-side image).
+
 The benchmarks and GPU parity tests start from blobs *after* the resize; csrc/pre.hip is kept bit-equal to this file.
 """
 import numpy as np
@@ -66,6 +78,46 @@ def _axis_coeffs(n_src, n_dst, f):
     return i0, i1, a0, fx.astype(np.float32)
 
 
+def is_area_fast_2x(fx, fy):
+    """cv::resize's switch from INTER_LINEAR to the INTER_AREA fast path (module docstring): both scales exactly 2x down."""
+    eps = np.finfo(np.float64).eps
+    sx, sy = 1.0 / float(fx), 1.0 / float(fy)
+    ix, iy = int(np.round(sx)), int(np.round(sy))             # saturate_cast<int>(double) = cvRound
+    return abs(sx - ix) < eps and abs(sy - iy) < eps and ix == 2 and iy == 2
+
+
+def _resize_area_fast_2x(im, nh, nw):
+    """resizeAreaFast_Invoker<double, double, NoVec> with scale_x = scale_y = 2 (module docstring)."""
+    h, w = im.shape[:2]
+    out = np.zeros((nh, nw) + im.shape[2:], dtype=im.dtype)
+    full_w = w // 2                                           # dwidth1 / cn
+    full_h = h // 2                                           # rows with sy0 + 2 <= ssize.height
+    fh, fw = min(full_h, nh), min(full_w, nw)
+    a = im[0:2 * fh:2, 0:2 * fw:2]
+    b = im[0:2 * fh:2, 1:2 * fw:2]
+    c = im[1:2 * fh:2, 0:2 * fw:2]
+    d = im[1:2 * fh:2, 1:2 * fw:2]
+    out[:fh, :fw] = (((a + b) + c) + d) * im.dtype.type(np.float32(0.25))
+    for dy in range(nh):
+        for dx in (range(nw) if dy >= full_h else range(full_w, nw)):
+            sy0, sx0 = 2 * dy, 2 * dx
+            if sy0 >= h:
+                continue                                      # D[dx] = 0
+            s = np.zeros(im.shape[2:], dtype=im.dtype)
+            count = 0
+            for sy in range(2):
+                if sy0 + sy >= h:
+                    break
+                for sx in range(2):
+                    if sx0 + sx >= w:
+                        break
+                    s = s + im[sy0 + sy, sx0 + sx]
+                    count += 1
+            if count:
+                out[dy, dx] = (s.astype(np.float32) / np.float32(count)).astype(im.dtype)   # (float)sum / count
+    return out
+
+
 def resize_bilinear(im, fx, fy):
     """cv2.resize(im, None, None, fx=fx, fy=fy, interpolation=cv2.INTER_LINEAR) of an HxWxC float image, restated
     (module docstring).  Computes in the image's own dtype: the reference hands cv2 a float64 image
@@ -76,6 +128,8 @@ def resize_bilinear(im, fx, fy):
     h, w = im.shape[:2]
     nh = int(np.round(h * fy))  # cvRound: round-half-to-even, same as np.round
     nw = int(np.round(w * fx))
+    if is_area_fast_2x(fx, fy):
+        return _resize_area_fast_2x(im, nh, nw)
     y0, y1, b0, b1 = _axis_coeffs(h, nh, fy)
     x0, x1, a0, a1 = _axis_coeffs(w, nw, fx)
     a0 = a0[None, :, None].astype(im.dtype)

@@ -83,7 +83,11 @@ def written(d):
     return np.stack([x1, y1, x2 - x1, y2 - y1], 1)
 
 
-def compare_detection_lists(key, got, want, max_unmatched_frac=0.01):
+def compare_detection_lists(key, got, want, max_unmatched=2, max_pixel_rows=2):
+    """Absolute bars set from what is measured (round 3: 0 unmatched boxes at every config, 0 written-pixel rows at C4 / C5,
+    1 of 1107 at C3 -- a box coordinate within float noise of an integer): a handful of boxes crossing the > 0.05 cut or an
+    integer boundary on one side only is legitimate, twenty are a regression.  The north star's bar is 0-pixel index
+    difference (lib/datasets/wider.py:160-167 writes the truncated integers); callers that measured 0 / 0 assert 0 / 0."""
     pairs, miss, extra = match_detections(got, want)
     assert len(pairs) > 0
     gi = np.array([p[0] for p in pairs])
@@ -99,9 +103,9 @@ def compare_detection_lists(key, got, want, max_unmatched_frac=0.01):
     _report(key, n_got=len(got), n_want=len(want), matched=len(pairs), unmatched_oracle=len(miss),
             unmatched_gpu=len(extra), max_abs_dscore=ds, max_abs_dcoord=dc, rows_with_written_pixel_diff=px_rows)
     assert ds < SCORE_TOL, ds
-    assert len(miss) <= max(2, max_unmatched_frac * len(want)), (len(miss), len(want))
-    assert len(extra) <= max(2, max_unmatched_frac * len(want)), (len(extra), len(want))
-    assert px_rows <= max(2, 0.02 * len(pairs)), px_rows
+    assert len(miss) <= max_unmatched, (len(miss), len(want))
+    assert len(extra) <= max_unmatched, (len(extra), len(want))
+    assert px_rows <= max_pixel_rows, px_rows
     return pairs
 
 
@@ -225,7 +229,7 @@ def test_c5_whole_image_vs_oracle_driver():
         gnet.set_conv_mode(mode)
         fd = T.FusedDetector(gnet, n_lanes=10, mode="group")
         got = fd.detect(units, thresh=0.05)[0]
-        compare_detection_lists("C5_image_" + mode, got, want, max_unmatched_frac=0.02)
+        compare_detection_lists("C5_image_" + mode, got, want, max_unmatched=0, max_pixel_rows=0)
         del fd
 
 
@@ -281,7 +285,7 @@ def _run_bench(tmp_path, world, extra, tag):
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
         env.pop(k, None)
     base = [os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "0", "--no-cpu-baseline",
-            "--no-latency", "--dump-dets", out] + extra
+            "--no-latency", "--no-calib", "--no-reduced", "--no-mixed", "--sustain-seconds", "0", "--dump-dets", out] + extra
     if world == 1:
         cmd = [sys.executable] + base
     else:
@@ -324,6 +328,21 @@ def test_c5_two_and_four_ranks_equal_one_rank(tmp_path):
     d4, j4 = _run_bench(tmp_path, 4, ["--shard", "strict"], "c5_n4_strict")
     np.testing.assert_array_equal(d1, d4)
     assert j4["config"]["shard"] == "strict"
+
+
+@pytest.mark.timeout(1800)
+def test_rccl_one_rank_group_runs_the_collective_path(tmp_path):
+    """The RCCL branch executed for real on the one GPU there is: a fresh process initialises a ONE-rank
+    `nccl` process group (device_id given, before any other GPU call), and bench.py --force-dist runs the N>1 schedule
+    on it -- per-member lists, shf_detect_export_many, gather_window's device-tensor all_to_all_single over RCCL,
+    shf_detect_import of the buffer RCCL produced, merge on the owner -- and must reproduce the plain 1-GPU detections
+    bit for bit.  (What 8 GPUs add is more peers in the same collective; the reference's analogue is the Queue gather of
+    lib/test.py:327-344.)"""
+    d1, _ = _run_bench(tmp_path, 1, [], "c5_n1_plain")
+    dr, jr = _run_bench(tmp_path, 1, ["--force-dist", "--backend", "nccl"], "c5_n1_rccl")
+    assert jr["rccl_ranks"] == 1 and jr["collective_backend"] == "nccl" and jr["collectives_issued_rank0"] >= 2
+    assert len(d1) > 0
+    np.testing.assert_array_equal(d1, dr)
 
 
 # ------------------------------------------------------------------------------------------------------------

@@ -1,11 +1,18 @@
-"""Split-fp16 mode at SMALL magnitudes and after weight changes made in fp32 mode.
+"""Split-fp16 mode at SMALL and LARGE magnitudes and after weight changes made in
+fp32 mode.
 
 The reference computes in fp32 at any magnitude (caffe/python/caffe/_caffe.cpp:46-48).  The dual-tile 4-wave family
 keeps ONE accumulator per output, which needs the low parts unscaled in LDS: lo = fp16(x - hi) of |x| < 0.25 is an fp16
 subnormal, and a layer whose activations live around 1e-3 would keep ~14 bits instead of 22 (numpy emulation of the
 scheme: 6.8e-5 relative error per layer at 2^-12, 1e-3 at 2^-16).  The kernels therefore lift every unit's input to the
 top of the fp16 range with an exact power of two taken from the producer's running max |output| (conv_common.h
-conv_act_exponent) -- these tests hold the same 2e-5 / 1e-4 bars as the O(1) cases at 2^-8, 2^-12 and 2^-16."""
+conv_act_exponent) -- these tests hold the same 2e-5 / 1e-4 bars as the O(1) cases at 2^-8, 2^-12 and 2^-16.
+
+Round 4, the other end: conv_act_exponent clamps e to [0, 15], so a unit whose max |x| is 2^14 or more gets e = 0 and
+its hi part lives in fp16's top binades (quantum 16-32 below 65 504).  A trained VGG-16 on mean-subtracted pixels has
+activations of 10^2-10^4 -- the band between the O(1)-O(100) cases and the range guard's 65 504.  The large-magnitude tests
+put max |activation| of the layer stack at 2^8, 2^11, 2^14 and 6.0e4 (just inside fp16) and hold the same bars, with no
+fp32 redo (range_fallbacks == 0)."""
 import numpy as np
 import pytest
 
@@ -48,7 +55,43 @@ def test_conv_small_magnitudes(cin, cout, k, dil, h, w, log2_scale):
     assert gnet.range_fallbacks == 0
 
 
-@pytest.mark.parametrize("log2_scale", [-8, -12])
+@pytest.mark.parametrize("top", [2.0 ** 8, 2.0 ** 11, 2.0 ** 14, 6.0e4])
+@pytest.mark.parametrize("cin,cout,k,dil,h,w", [
+    (128, 256, 3, 1, 35, 41), (512, 512, 3, 1, 16, 24), (256, 128, 3, 1, 9, 70), (64, 128, 3, 1, 32, 48),
+    (128, 128, 3, 2, 22, 26), (512, 256, 1, 1, 9, 13),          # the shapes of test_conv_small_magnitudes
+])
+def test_conv_large_magnitudes(cin, cout, k, dil, h, w, top):
+    """conv + bias + ReLU is positively homogeneous in (input, biases): the oracle at scale 1 gives the stack's largest
+    |activation| M, and input and biases scaled by top / M put it at `top` (the reference is fp32 at any magnitude,
+    caffe/python/caffe/_caffe.cpp:46-48)."""
+    pad = dil if k == 3 else 0
+    txt = H.single_layer_net(conv_layer("c0", "data", cin, 3, 1) + conv_layer("c1", "c0", cout, k, pad, dil) +
+                             conv_layer("c2", "c1", 128, 3, 1), 3, h, w)
+    gnet, onet = H.make_pair(P.parse(txt), seed=5)
+    gnet.set_conv_mode("f16x3")
+    rng = np.random.default_rng(3)
+    bias0 = {name: rng.normal(0, 0.5, onet.params[name][1].shape).astype(np.float32) for name in ("c0", "c1", "c2")}
+    data0 = rng.normal(0, 1, (1, 3, h, w)).astype(np.float32)
+    info = np.array([[h, w, 1]], np.float32)
+    for name in bias0:
+        onet.params[name][1][...] = bias0[name]
+    onet.blobs['data'].reshape(*data0.shape)
+    onet.blobs['im_info'].reshape(1, 3)
+    onet.forward(data=data0, im_info=info)
+    M = max(float(np.abs(onet.blobs[name].data).max()) for name in ("c0", "c1", "c2"))
+    sc = np.float32(top / M)
+    for name in bias0:
+        onet.params[name][1][...] = bias0[name] * sc
+    H.load_params(gnet, onet.params)
+    go, oo = H.run_both(gnet, onet, data0 * sc, info)
+    got_top = max(float(np.abs(onet.blobs[name].data).max()) for name in ("c0", "c1", "c2"))
+    assert 0.98 * top < got_top < 1.02 * top and got_top < 65504.0    # the case really is where it says
+    for name in ("c0", "c1", "c2"):
+        assert H.rel_err(gnet.blobs[name].data, onet.blobs[name].data) < ACT_TOL, name
+    assert gnet.range_fallbacks == 0
+
+
+@pytest.mark.parametrize("log2_scale", [-8, -12, "top 2^11", "top 2^15"])
 def test_detector_with_small_activations_fused_path(log2_scale):
     """The whole detector with the input blob and every bias scaled by 2^k: every activation up to the head
     feature maps sits 2^k lower (conv + ReLU + max-pool + bilinear upsampling are positively homogeneous), the logits
@@ -58,6 +101,18 @@ def test_detector_with_small_activations_fused_path(log2_scale):
     from smallhardface_amd import caffe, test as T
     msg = H.detector_msg(True)
     params = O.synth_params(msg, seed=1234, cls_bias=1.0)
+    if isinstance(log2_scale, str):
+        # LARGE activations (round 4): the power of two that puts the largest activation of the whole net (image blob
+        # included) into [top / 2, top] -- 2^11: the 10^3 band a trained VGG-16 runs in; 2^15: fp16's last binade
+        probe = O.OracleNet(msg, params=params)
+        d1 = H.synth_image_blob(96, 128, seed=21)
+        probe.blobs['data'].reshape(*d1.shape)
+        probe.blobs['im_info'].reshape(1, 3)
+        probe.forward(data=d1, im_info=np.array([[96, 128, 1.0]], np.float32))
+        M = max(float(np.abs(b.data).max()) for n, b in probe.blobs.items() if n == "data" or n.startswith("conv"))
+        top = 2.0 ** int(log2_scale.split("^")[1])
+        log2_scale = int(np.floor(np.log2(top / M)))
+        assert top / 2 < M * 2.0 ** log2_scale <= top
     sc = np.float32(2.0 ** log2_scale)
     tail = [n for n in params if n.startswith("cls_score") or n.startswith("bbox_pred")]
     seen = set()                                   # (layers sharing a `param { name }` hold ONE array)
@@ -75,6 +130,7 @@ def test_detector_with_small_activations_fused_path(log2_scale):
     info = np.array([[96, 128, 1.0]], np.float32)
     go, oo = H.run_both(gnet, onet, data, info)
     assert np.abs(onet.blobs["conv4_fuse_final"].data).max() < 4096 * sc
+    assert gnet.range_fallbacks == 0
     gp, op = gnet.blobs["cls_prob_reshape_output"].data, onet.blobs["cls_prob_reshape_output"].data
     assert float(np.abs(gp - op).max()) < SCORE_TOL
     assert H.rel_err(gnet.blobs["conv5_3"].data, onet.blobs["conv5_3"].data) < 5e-5

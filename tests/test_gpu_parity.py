@@ -429,10 +429,65 @@ def test_image_pipeline_submit_collect():
         np.testing.assert_array_equal(a, b)
 
 
+def test_image_pipeline_without_the_shared_conv_stream(tmp_path):
+    """SHF_PIPE_SHARED_CONV_STREAM=0 (each head's convolutions on its own stream, hand-over by events):
+    the successor head's first convolutions start on the predecessor's `ev_convs` alone, so that event must come after
+    the predecessor's tail reset kernel, which zeroes the member lanes' activation-exponent slots.  Images of
+    very different magnitudes back to back: a slot zeroed late, or a stale one, changes bits or raises the range flag."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "run.py"
+    script.write_text('''
+import sys, numpy as np
+from smallhardface_amd.config import cfg
+from smallhardface_amd import test as T
+from tests import helpers as H
+cfg.MODEL.DIFFERENT_DILATION.ENABLE = True
+cfg.TEST.SCALES = [100, 300, 500]
+gnet, _ = H.make_pair(H.detector_msg(True), cls_bias=1.0)
+gnet.set_conv_mode("f16x3")
+fd = T.FusedDetector(gnet, n_lanes=6, mode="group")
+units = []
+for i in range(8):
+    im = np.random.default_rng(40 + i).integers(0, 256, (150 + 10 * (i % 3), 200, 3)).astype(np.uint8)
+    us = list(T.pyramid_units(im))
+    g = np.float32([1.0, 2.0 ** -9, 2.0, 2.0 ** -4][i % 4])      # units whose exponents differ by up to 10
+    units.append([(u[0] * g,) + u[1:] for u in us])
+got = []
+for rep in range(3):
+    for us in units:
+        fd.submit(us, thresh=0.05)
+        if fd.pending() > 1:
+            got.append(fd.collect()[0])
+while fd.pending():
+    got.append(fd.collect()[0])
+assert fd.range_fallbacks == 0 and gnet.range_fallbacks == 0
+np.savez(sys.argv[1], *got)
+''')
+    outs = {}
+    for name, env in (("shared", {}), ("own_streams", {"SHF_PIPE_SHARED_CONV_STREAM": "0"})):
+        out = str(tmp_path / (name + ".npz"))
+        r = subprocess.run([sys.executable, str(script), out], env=dict(os.environ, PYTHONPATH=root, **env), cwd=root,
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (name, r.stderr[-1500:])
+        z = np.load(out)
+        outs[name] = [z[k] for k in z.files]
+    assert len(outs["shared"]) == 24 and sum(len(a) for a in outs["shared"]) > 0
+    for k in range(8, 24):                                   # every repetition reproduces the first
+        np.testing.assert_array_equal(outs["shared"][k], outs["shared"][k - 8])
+    for a, b in zip(outs["shared"], outs["own_streams"]):
+        np.testing.assert_array_equal(a, b)
+
+
 @pytest.mark.parametrize("shape,scales,flip", [
     ((97, 131), [1.0, 0.5, 1.7, 2.25, 0.3125], True),     # identity, down, up, exact-binary factor
     ((64, 64), [0.25, 3.0], True),                          # already a multiple of MAX_RESOLUTION
     ((33, 250), [0.0625, 1.0 / 3.0, 1.28], False),          # tiny level (3 rows), non-terminating factor
+    ((96, 130), [0.5], True),                               # exactly 2x down: cv::resize's INTER_AREA fast path, interior only
+    ((97, 130), [0.5], True),                               # 97 -> cvRound(48.5) = 48 rows: the odd row is dropped
+    ((99, 135), [0.5], True),                               # 99 -> 50 rows, 135 -> 68 columns: border loop in both axes
 ])
 def test_device_preprocessing_bit_exact(shape, scales, flip, conv_mode):
     """shf_make_pyramid_level == _get_image_blob + flip + pad of the host mirror, bit for bit

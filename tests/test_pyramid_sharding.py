@@ -54,7 +54,9 @@ def _worker(rank, world, port, q, n_images, scenario):
         got = {}
         for window in range(2):                           # twice: the grown capacity persists, results stay the same
             local = {i: torch.from_numpy(_contribution(rank, i, scenario)) for i in range(n_images)}
-            got = pyramid.gather_window(local, n_images, rank, world)
+            if scenario == "parts":                       # the per-unit export buffers as they are: lists of pieces
+                local = {i: [t[:2], t[2:2], t[2:]] for i, t in local.items()}
+            got = pyramid.gather_window(local, n_images, rank, world, force_collective=(world == 1))
         q.put((rank, {i: t.numpy() for i, t in got.items()}, pyramid._GATHER_CAP["rows"]))
     finally:
         dist.destroy_process_group()
@@ -62,11 +64,12 @@ def _worker(rank, world, port, q, n_images, scenario):
 
 @pytest.mark.timeout(300)
 @pytest.mark.parametrize("world,n_images,scenario", [(2, 2, "plain"), (3, 5, "plain"), (2, 2, "overflow"),
-                                                     (8, 8, "strict8")])
+                                                     (8, 8, "strict8"), (2, 3, "parts"), (1, 2, "parts"), (1, 1, "overflow")])
 def test_gather_window_gloo(world, n_images, scenario):
     """One all_to_all per window, rows to the image's owner only: uneven ownership (5 images on 3 ranks), contributions
     larger than the block capacity (agreed re-exchange), and the strict one-scale-per-GPU form on 8 ranks with 5
-    levels -- three ranks contribute nothing, one image has no detection on any rank."""
+    levels -- three ranks contribute nothing, one image has no detection on any rank; contributions handed over as
+    lists of pieces; and a ONE-rank group with the collective forced (how the RCCL branch runs on a single-GPU box)."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -115,6 +118,9 @@ def test_gather_window_single():
     import torch
     local = {0: torch.zeros((3, 5))}
     assert pyramid.gather_window(local, 1, 0, 1)[0] is local[0]
+    parts = {0: [torch.ones((2, 5)), torch.zeros((0, 5)), 2 * torch.ones((1, 5))], 1: []}
+    got = pyramid.gather_window(parts, 2, 0, 1)
+    assert got[0].shape == (3, 5) and float(got[0][2, 0]) == 2.0 and got[1].shape == (0, 5)
 
 
 def test_pyramid_level_shape_matches_host_rounding():

@@ -77,3 +77,47 @@ def test_scale_one_is_not_resized():
     blob = TU._get_image_blob(im, [1.0])[0]['data']
     want = (im.astype(np.float32) - np.array(cfg.PIXEL_MEANS)).astype(np.float32).transpose(2, 0, 1)[None]
     np.testing.assert_array_equal(blob, want.reshape(blob.shape))
+
+
+def test_exact_half_scale_takes_the_area_fast_path():
+    """cv::resize: INTER_LINEAR with both scales exactly 2x down runs INTER_AREA's fast path (VERDICT r3 #8): interior
+    outputs are the four taps summed left to right times 0.25 in the image's double, outputs whose window leaves an
+    odd-sized source are (float)sum / count.  Expected values are formed here with plain Python floats and struct
+    float32 roundings, not with the implementation."""
+    import struct
+
+    def f32(v):
+        return struct.unpack('f', struct.pack('f', v))[0]
+
+    assert TU.is_area_fast_2x(0.5, 0.5)
+    assert not TU.is_area_fast_2x(0.5, 0.25) and not TU.is_area_fast_2x(0.5000000000000002, 0.5)
+    assert not TU.is_area_fast_2x(1.0 / 3.0, 1.0 / 3.0) and not TU.is_area_fast_2x(0.25, 0.25)
+    rng = np.random.default_rng(5)
+    means = [102.9801, 115.9465, 122.7717]
+    for (h, w) in [(6, 8), (7, 9), (5, 10), (6, 11)]:     # even/even, odd/odd (9 -> cvRound(4.5) = 4, 7 -> 4), mixed
+        u8 = rng.integers(0, 256, (h, w, 3)).astype(np.uint8)
+        im = u8.astype(np.float32) - np.array(means)
+        out = TU.resize_bilinear(im, 0.5, 0.5)
+        nh, nw = int(np.round(h * 0.5)), int(np.round(w * 0.5))
+        assert out.shape == (nh, nw, 3) and out.dtype == np.float64
+        for dy in range(nh):
+            for dx in range(nw):
+                for c in range(3):
+                    taps = [float(u8[2 * dy + sy, 2 * dx + sx, c]) - means[c]
+                            for sy in range(2) if 2 * dy + sy < h for sx in range(2) if 2 * dx + sx < w]
+                    if len(taps) == 4:
+                        want = (((taps[0] + taps[1]) + taps[2]) + taps[3]) * 0.25
+                    else:
+                        acc = 0.0
+                        for t in taps:
+                            acc = acc + t
+                        want = f32(f32(acc) / len(taps))
+                    assert out[dy, dx, c] == want, (h, w, dy, dx, c)
+    # and it is NOT what the two-tap path gives everywhere: the switch is observable in the last double bit
+    im = rng.integers(0, 256, (64, 64, 3)).astype(np.float32) - np.array(means)
+    y0, y1, b0, b1 = TU._axis_coeffs(64, 32, 0.5)
+    x0, x1, a0, a1 = TU._axis_coeffs(64, 32, 0.5)
+    assert np.all(a0 == 0.5) and np.all(b1 == 0.5) and np.array_equal(x0, 2 * np.arange(32))
+    two_tap = (im[y0][:, x0] * 0.5 + im[y0][:, x1] * 0.5) * 0.5 + (im[y1][:, x0] * 0.5 + im[y1][:, x1] * 0.5) * 0.5
+    area = TU.resize_bilinear(im, 0.5, 0.5)
+    assert np.abs(area - two_tap).max() < 1e-12 and np.any(area != two_tap)
