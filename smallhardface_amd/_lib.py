@@ -112,6 +112,7 @@ def _declare(lib):
         "shf_bbox_vote": (ci, [fp, ci, cf, dp, ci, ip]),
         "shf_generate_anchors": (ci, [ci, dp, ci, dp, ci, dp, ci, dp, dp, ci]),
         "shf_prof_enable": (ci, [vp, ci]),
+        "shf_prof_only": (ci, [vp, ci]),
         "shf_prof_num_classes": (ci, [vp]),
         "shf_prof_class_name": (C.c_char_p, [vp, ci]),
         "shf_prof_read": (ci, [vp, ci, C.POINTER(C.c_int64), dp, dp, dp]),

@@ -262,6 +262,14 @@ class Net(object):
     def prof_enable(self, on=True):
         self._lib.shf_prof_enable(self._h, 1 if on else 0)
 
+    def prof_only(self, class_name=None):
+        """Bracket only launches of the named kernel class (None: every class) -- C ABI shf_prof_only."""
+        cls = -1
+        if class_name is not None:
+            names = [self._lib.shf_prof_class_name(self._h, c).decode() for c in range(self._lib.shf_prof_num_classes(self._h))]
+            cls = names.index(class_name)
+        self._lib.shf_prof_only(self._h, cls)
+
     def prof_reset(self):
         _lib.check(self._lib.shf_prof_reset(self._h), "prof_reset")
 

@@ -586,6 +586,73 @@ __device__ __forceinline__ void conv_epilogue_regs_tail(float (&v)[16], const fl
   }
 }
 
+// POOL-ONLY register epilogue (round 4): the layer's un-pooled map is not stored (conv1_2, conv2_2, conv3_3 of VGG-16 feed
+// their 2x2/2 MAX pool and nothing else).  The generic tail above forms all 16 pooled values in every lane of a pooling quad
+// and lets one lane split and store them: the split of a pooled value was done four times over, after a half-wave exchange
+// nothing here needs.  Here: bias, then the quad max on the raw accumulator order -- registers 4q..4q+3 of a lane are the
+// couts 8q + 4kh .. + 3 of the 32-cout tile, the same in all four lanes of a quad --, then lane ql of the quad keeps register
+// quad q = ql (three selects per value), applies ReLU to those FOUR values, splits them and stores 8 B of hi + 8 B of lo:
+// the eight lanes (4 of the quad x 2 half-waves) of a pooled pixel write its 32 couts.  ~80 vector instructions per
+// accumulator tile instead of ~175, and the SAME bits: max commutes with the ReLU (max over the quad and 0, as signed
+// integers on the bit patterns: any positive value beats every negative one and 0 beats them all), the bias is added before
+// the max like before, and the unit's max |output| over the pooled values equals that over all in-image outputs (every
+// in-image pixel lies in exactly one clipped window).  getv(r): register r's value before the bias; bias32 = the 32-cout tile's biases (in LDS);
+// `window` = the quad's top-left pixel is inside the image (the pooled pixel exists); `valid` = this lane's own pixel is.
+template <bool RELU, typename GetV>
+__device__ __forceinline__ void conv_epilogue_pool_only(GetV getv, const float* bias32, bool valid, bool window,
+                                                        bool interior, float* __restrict__ pix_pool, int cout32, int kh,
+                                                        int ql, bool pool_split, float& amax) {
+  auto quad_max = [&](float xf) {
+    if (RELU) {
+      int x = __builtin_bit_cast(int, xf);
+      if (!interior) x = valid ? x : 0;        // (a pixel outside the image: 0 is neutral under the ReLU that follows)
+      int y = __builtin_amdgcn_mov_dpp(x, 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
+      x = x > y ? x : y;
+      y = __builtin_amdgcn_mov_dpp(x, 0x4E, 0xf, 0xf, true);       // quad_perm [2,3,0,1]
+      return __builtin_bit_cast(float, x > y ? x : y);
+    } else {
+      float x = valid ? xf : -3.402823466e+38f;
+      int xi = __builtin_bit_cast(int, x);
+      x = fmaxf(x, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(xi, xi, 0xB1, 0xf, 0xf, false)));
+      xi = __builtin_bit_cast(int, x);
+      return fmaxf(x, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(xi, xi, 0x4E, 0xf, 0xf, false)));
+    }
+  };
+  // a register quad at a time (four values + the four kept so far are live, not sixteen): bias from LDS, the quad max by
+  // ALL lanes (a DPP operand must not be read inside a lane-dependent branch), then lane ql keeps quad q = ql
+  float w0 = 0.f, w1 = 0.f, w2 = 0.f, w3 = 0.f;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float4 bq = *(const float4*)(bias32 + 8 * q + 4 * kh);
+    const cs_f32x2 a = cs_f32x2{getv(4 * q), getv(4 * q + 1)} + cs_f32x2{bq.x, bq.y};
+    const cs_f32x2 b = cs_f32x2{getv(4 * q + 2), getv(4 * q + 3)} + cs_f32x2{bq.z, bq.w};
+    const float m0 = quad_max(a[0]), m1 = quad_max(a[1]), m2 = quad_max(b[0]), m3 = quad_max(b[1]);
+    const bool mine = ql == q;
+    w0 = mine ? m0 : w0;
+    w1 = mine ? m1 : w1;
+    w2 = mine ? m2 : w2;
+    w3 = mine ? m3 : w3;
+  }
+  if (RELU) {   // on the bit patterns: negatives and -0 -> +0
+    auto relu1 = [](float x) { const int q = __builtin_bit_cast(int, x); return __builtin_bit_cast(float, q > 0 ? q : 0); };
+    w0 = relu1(w0); w1 = relu1(w1); w2 = relu1(w2); w3 = relu1(w3);
+  }
+  {
+    const unsigned q0 = __builtin_bit_cast(unsigned, w0) & 0x7fffffffu, q1 = __builtin_bit_cast(unsigned, w1) & 0x7fffffffu;
+    const unsigned q2 = __builtin_bit_cast(unsigned, w2) & 0x7fffffffu, q3 = __builtin_bit_cast(unsigned, w3) & 0x7fffffffu;
+    const unsigned t01 = q0 > q1 ? q0 : q1, t23 = q2 > q3 ? q2 : q3, t = t01 > t23 ? t01 : t23;
+    const unsigned am = __builtin_bit_cast(unsigned, amax);
+    amax = __builtin_bit_cast(float, window && t > am ? t : am);
+  }
+  if (window) {
+    const int c = cout32 + 8 * ql + 4 * kh;
+    if (pool_split)
+      conv_store_split4(pix_pool, c, make_float4(w0, w1, w2, w3));
+    else
+      *(float4*)(pix_pool + c) = make_float4(w0, w1, w2, w3);
+  }
+}
+
 template <bool RELU>
 __device__ __forceinline__ void conv_epilogue_regs(const cs_f32x16 am, const cs_f32x16 ac, float inv, const float4* bias16,
                                                    bool valid, bool interior, float* __restrict__ pix_main, int cout16,

@@ -56,6 +56,20 @@ constexpr int TH = 16, TW = 16, HTW = TW + 2, HTH = TH + 2, HP = HTH * HTW;
 constexpr float LO_SCALE = 2048.0f, LO_INV = 1.0f / 2048.0f;
 }  // namespace f16x3
 
+// conv1_1 on the matrix cores (fused first pair): which tap (ci * 9 + ky * 3 + kx; -1: none, zero weight) K slot
+// (k-step kk, half-wave kh, element j) of the 27 -> 32 padded reduction multiplies.  Chosen so that a lane's sixteen patch
+// reads are base(kk, kh) + a compile-time offset: kk = 0 is input channel kh at kernel positions 0..7 (the half-waves' taps
+// lie one channel plane apart), kk = 1 holds channel 2 -- half-wave kh reads column kx = kh of the three kernel rows in
+// j = 0..2 (the taps lie one pixel apart), column 2 in j = 3..5 -- and position 8 of channels 0 / 1 in j = 6 / 7; the
+// slots half-wave 1 has no tap for read the patch one pixel further (a finite value) against a zero weight.
+__host__ __device__ constexpr int first_conv_slot_tap(int kk, int kh, int j) {
+  if (kk == 0) return kh * 9 + j;
+  if (j < 3) return 18 + j * 3 + kh;
+  if (kh != 0) return -1;
+  if (j < 6) return 18 + (j - 3) * 3 + 2;
+  return (j - 6) * 9 + 8;
+}
+
 // bf16 mode (BF = true kernels; conv mode "bf16"): ONE product per fp32 product on v_mfma_f32_32x32x16_bf16, operands
 // rounded to bf16 (8 mantissa bits, fp32's exponent range: no fp16 range guard, no activation exponent).  The 16-bit
 // "hi" halves of the LDS rows / weight packs then hold bf16 bit patterns and the "lo" halves are never read.
@@ -948,8 +962,36 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4d_kernel(ConvK p) {
         }
       }
     };
-    tile_out(acc0, g0, true, e_t0, amax0);
-    if constexpr (NTILE == 2) tile_out(acc1, g1, has1, e_t1, amax1);
+    // POOL-ONLY layers (conv2_2, conv3_3 of VGG-16: the un-pooled map has no other reader): conv_epilogue_pool_only -- the
+    // quad max on the raw accumulator order, then each lane of a quad finishes a quarter of the couts; same bits
+    auto tile_out_pool = [&](f32x16 (&acc)[MT][2], const Geo& g, bool exists, int e_act, float& amax) {
+      const float out_scale = wscale_inv_e * __builtin_bit_cast(float, (unsigned)(127 - e_act) << 23);   // 2^-e, exact
+      const int Hp = (g.H + 1) >> 1, Wp = (g.W + 1) >> 1;
+      const bool interior = exists && g.ty0 + TH <= g.H && g.tx0 + TW <= g.W;
+      const int x = g.tx0 + px_e;
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn) {
+#pragma unroll
+        for (int tm = 0; tm < MT; ++tm) {
+          int y = g.ty0 + wm * 2 * MT + tm * 2 + dy_e;
+          asm volatile("" : "+v"(y));
+          const bool valid = exists && y < g.H && x < g.W;
+          const bool window = exists && y - dy_e < g.H && x - (i_e & 1) < g.W;
+          const unsigned pix_q = (unsigned)((g.b * Hp + (y >> 1)) * Wp + (x >> 1));
+          float* pq = g.pool + (size_t)pix_q * (unsigned)pool_stride_e;
+          const f32x16 a_ = acc[tm][tn];
+          conv_epilogue_pool_only<true>([&](int r) { return a_[r] * out_scale; }, biasL + wn * 64 + tn * 32, valid, window, interior,
+                                        pq, ct * BN + wn * 64 + tn * 32, kh_e, i_e & 3, pool_split, amax);
+        }
+      }
+    };
+    if (relu && !write_main && g0.pool) {   // (wave-uniform; a launch's members share the layer)
+      tile_out_pool(acc0, g0, true, e_t0, amax0);
+      if constexpr (NTILE == 2) tile_out_pool(acc1, g1, has1, e_t1, amax1);
+    } else {
+      tile_out(acc0, g0, true, e_t0, amax0);
+      if constexpr (NTILE == 2) tile_out(acc1, g1, has1, e_t1, amax1);
+    }
   }
   conv_raise_range_flag(p.range_flag, conv_absmax_bits(amax0, amax1));
   conv_amax_commit(g0.out_amax, seen0, g0.pool ? g0.pool_amax : nullptr, seen0p, amax0);
@@ -994,8 +1036,13 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
   unsigned char* As0 = smem;                        // [HPP][ROWB] channels  0..31 of conv1_1's output
   unsigned char* As1 = smem + HPP * ROWB;           // [HPP][ROWB] channels 32..63
   unsigned char* Bs = smem + 2 * HPP * ROWB;        // [2][3][BN][ROWB]
-  float* patch = (float*)(Bs + 2 * 3 * BN * ROWB);  // [3][PH][PW] raw image patch
-  unsigned char* valid = (unsigned char*)(patch + 3 * PH * PW);  // [HPP] halo pixel inside the image? (0 in the padding)
+  // [3][PH][PW] image patch, already split: fp16 hi in the low half of a dword, fp16 lo (x 2^11) in the high half (bf16 mode:
+  // the bf16 pattern | 0) -- conv1_1's fragments are then gathered with one byte permute per register, no conversion
+  // (round 4; the conversions used to be redone for every fragment element: ~200 vector instructions per row tile).
+  // (+ 8 dwords: half-wave 1's zero-weight slots read one element past a tap)
+  unsigned* patch = (unsigned*)(Bs + 2 * 3 * BN * ROWB);
+  constexpr int PATCH_DW = 3 * PH * PW + 8;
+  unsigned char* valid = (unsigned char*)(patch + PATCH_DW);  // [HPP] halo pixel inside the image? (0 in the padding)
   float* bias2L = (float*)(valid + HPP);                          // [BN] conv1_2's biases (read by the register epilogue)
 
   int tid = threadIdx.x, lane = tid & 63;
@@ -1077,6 +1124,15 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
 
   float amax1 = 0.f;  // fp16 range guard for conv1_1's outputs (split right here, never seen by another epilogue)
   bool first_tile = true;
+  auto patch_word = [](float x) -> unsigned {   // fp16 hi | fp16 lo (x 2^11) << 16; bf16 mode: the bf16 pattern
+    if constexpr (BF) {
+      return (unsigned)__builtin_bit_cast(unsigned short, bf16_as_half(x));
+    } else {
+      const _Float16 h = (_Float16)x;
+      const _Float16 l = (_Float16)((x - (float)h) * LO_SCALE);
+      return (unsigned)__builtin_bit_cast(unsigned short, h) | ((unsigned)__builtin_bit_cast(unsigned short, l) << 16);
+    }
+  };
   for (;;) {   // (PERSIST: the walk over this block's tiles; otherwise one turn)
   {  // prologue, all eight waves: conv1_1 + ReLU of the whole halo tile ON THE MATRIX CORES
     // [324 halo px x 27 taps (padded to 32)] x [32 x 64 couts] as split-fp16 MFMAs: 11 row tiles of 32 pixels,
@@ -1101,10 +1157,11 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
 #pragma unroll
     for (int k = 0; k < NPATCH; ++k) {
       const int idx = tid + 512 * k;
-      if (idx < 3 * PH * PW) patch[idx] = pv[k];
+      if (idx < 3 * PH * PW) patch[idx] = patch_word(pv[k]);
       amax1 = conv_absmax_bits(amax1, pv[k]);  // the image itself is split to fp16 hi/lo for conv1_1's MFMAs
     }
     if (tid < BN) bias2L[tid] = p.bias ? bias2v : 0.f;
+    if (tid < 8) patch[3 * PH * PW + tid] = 0u;
     if (tid < HPP) {
       const int qy = (tid * 58255) >> 20, qx = tid - qy * HTW;
       valid[tid] = (tid < HP && (unsigned)(ty0 - 1 + qy) < (unsigned)H && (unsigned)(tx0 - 1 + qx) < (unsigned)W) ? 1 : 0;
@@ -1126,25 +1183,40 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
     constexpr int NMT = (HP + 31) / 32;  // 11 row tiles
     // work items: tiles 0..7 whole (one per wave), tiles 8..10 split by N tile over waves 0..5: the longest
     // wave does 1.5 tiles instead of 2
+    const bool halo_inside = ty0 >= 1 && tx0 >= 1 && ty0 + TH < H && tx0 + TW < W;   // (wave-uniform)
+    half2v amax1h = {(_Float16)0, (_Float16)0};
     auto conv1_tile = [&](int m, int n_lo, int n_hi) {
       const int hp = m * 32 + i1 < HP ? m * 32 + i1 : HP - 1;
       const int hy = (hp * 58255) >> 20, hx = hp - hy * HTW;
-      const float* pb = patch + hy * PW + hx;
+      // sixteen packed patch words at base(kk, kh) + a compile-time offset (first_conv_slot_tap), then one byte permute per
+      // fragment register: the low halves of two words are two hi values, the high halves the two lo values
+      const unsigned* pb = patch + hy * PW + hx;
+      const unsigned* b0 = pb + kh1 * (PH * PW);
+      const unsigned* b1 = pb + kh1;
+      unsigned e0[8], e1[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        e0[j] = b0[(j / 3) * PW + j % 3];
+        constexpr int T1[8] = {18, 21, 24, 20, 23, 26, 8, 17};   // first_conv_slot_tap(1, 0, j)
+        static_assert(first_conv_slot_tap(1, 0, 3) == 20 && first_conv_slot_tap(1, 0, 7) == 17 && first_conv_slot_tap(1, 1, 2) == 25, "slot map");
+        e1[j] = b1[((T1[j] / 9) * PH + (T1[j] % 9) / 3) * PW + T1[j] % 3];
+      }
       half8 ah[2], al[2];
+      {
+        unsigned h0[4], l0[4], h1[4], l1[4];
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          // tap k = kk*16 + kh*8 + j -> (ci, ky, kx); taps 27..31 are padding
-          const int k0 = kk * 16 + j, k1 = kk * 16 + 8 + j;
-          const int o0 = ((k0 / 9) * PH + (k0 % 9) / 3) * PW + k0 % 3;
-          const int o1 = k1 < 27 ? ((k1 / 9) * PH + (k1 % 9) / 3) * PW + k1 % 3 : 0;
-          float x = pb[kh1 ? o1 : o0];
-          if (k1 >= 27 && kh1) x = 0.f;
-          const _Float16 h = BF ? bf16_as_half(x) : (_Float16)x;
-          ah[kk][j] = h;
-          al[kk][j] = BF ? (_Float16)0 : (_Float16)((x - (float)h) * LO_SCALE);
+        for (int r = 0; r < 4; ++r) {
+          h0[r] = __builtin_amdgcn_perm(e0[2 * r + 1], e0[2 * r], 0x05040100u);
+          l0[r] = __builtin_amdgcn_perm(e0[2 * r + 1], e0[2 * r], 0x07060302u);
+          h1[r] = __builtin_amdgcn_perm(e1[2 * r + 1], e1[2 * r], 0x05040100u);
+          l1[r] = __builtin_amdgcn_perm(e1[2 * r + 1], e1[2 * r], 0x07060302u);
         }
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        ah[0] = __builtin_bit_cast(half8, u32x4{h0[0], h0[1], h0[2], h0[3]});
+        al[0] = __builtin_bit_cast(half8, u32x4{l0[0], l0[1], l0[2], l0[3]});
+        ah[1] = __builtin_bit_cast(half8, u32x4{h1[0], h1[1], h1[2], h1[3]});
+        al[1] = __builtin_bit_cast(half8, u32x4{l1[0], l1[1], l1[2], l1[3]});
+      }
 #pragma unroll
       for (int n = 0; n < 2; ++n) {
         if (n < n_lo || n >= n_hi) continue;  // wave-uniform
@@ -1161,15 +1233,17 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
           for (int kk = 0; kk < 2; ++kk) cc = mma16<BF>(bw[n][kk][0], al[kk], cc);
         }
         // C row (cout) = (r & 3) + 8 (r >> 2) + 4 kh, C column (halo pixel) = lane & 31
-        const bool ok = valid[m * 32 + i1] != 0;   // 0 outside the image (conv1_2's zero padding, not conv1_1 evaluated out there)
         float v[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const float4 bq = bias1v[n][r >> 2];
           const float bias = (r & 3) == 0 ? bq.x : (r & 3) == 1 ? bq.y : (r & 3) == 2 ? bq.z : bq.w;
-          const float pre = cm[r] + cc[r] * LO_INV + bias;
-          v[r] = ok ? fmaxf(pre, 0.f) : 0.f;
-          amax1 = fmaxf(amax1, v[r]);   // (an inf here comes from an inf in the patch, which amax1 has seen already)
+          v[r] = fmaxf(cm[r] + cc[r] * LO_INV + bias, 0.f);
+        }
+        if (!(halo_inside && m + 1 < NMT)) {   // (wave-uniform: most row tiles have every halo pixel inside the image)
+          const bool ok = valid[m * 32 + i1] != 0;   // 0 outside the image (conv1_2's zero padding, not conv1_1 evaluated out there)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v[r] = ok ? v[r] : 0.f;
         }
         conv_swap_halves(v);   // kh = 0 now holds couts 0..15, kh = 1 couts 16..31, register order 0-3, 8-11, 4-7, 12-15
         constexpr int ORD[4] = {0, 8, 4, 12};
@@ -1187,6 +1261,8 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
               h = __builtin_convertvector(f32x2{x0, x1}, half2v);
               l = __builtin_convertvector((f32x2{x0, x1} - __builtin_convertvector(h, f32x2)) * LO_SCALE, half2v);
             }
+            // fp16 range guard of conv1_1's outputs, on the PACKED hi halves (values >= 0; an overflow is an inf there)
+            if constexpr (!BF) amax1h = __builtin_elementwise_max(amax1h, h);
             hi8[g * 2 + (t >> 1)] = __builtin_bit_cast(float, h);
             lo8[g * 2 + (t >> 1)] = __builtin_bit_cast(float, l);
           }
@@ -1201,6 +1277,7 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
     };
     conv1_tile(wave_u, 0, 2);
     if (wave_u < 2 * (NMT - 8)) conv1_tile(8 + wave_u % (NMT - 8), wave_u / (NMT - 8), wave_u / (NMT - 8) + 1);
+    amax1 = conv_absmax_bits(amax1, fmaxf((float)amax1h[0], (float)amax1h[1]));
   }
 
   // consumer geometry: wave wm = rows 4 wm .. 4 wm + 3 (two 2x16-pixel MFMA row tiles), all 64 couts
@@ -1314,7 +1391,7 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
 #pragma unroll
           for (int k = 0; k < NPF; ++k) {
             const int idx = ptid + 256 * k;
-            if (idx < 3 * PH * PW) patch[idx] = pvn[k];
+            if (idx < 3 * PH * PW) patch[idx] = patch_word(pvn[k]);
             amax1 = conv_absmax_bits(amax1, pvn[k]);
           }
 #pragma unroll
@@ -1349,6 +1426,25 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
     const int Hp = (H + 1) >> 1, Wp = (W + 1) >> 1;
     const bool interior = ty0 + TH <= H && tx0 + TW <= W;
     const int x = tx0 + px_e;
+    if (relu && !write_main && mem.pool) {
+      // the un-pooled map is not stored (conv1_2 -> pool1 of VGG-16): the pool-only epilogue (conv_common.h), same bits
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn) {
+#pragma unroll
+        for (int tm = 0; tm < MT; ++tm) {
+          int y = ty0 + wm * 2 * MT + tm * 2 + dy_e;
+          asm volatile("" : "+v"(y));
+          const bool vld = y < H && x < W;
+          const bool window = y - dy_e < H && x - (i_e & 1) < W;
+          const unsigned pix_q = (unsigned)((b * Hp + (y >> 1)) * Wp + (x >> 1));
+          float* pq = mem.pool + (size_t)pix_q * (unsigned)pool_stride_e;
+          const f32x16 am_ = accm[tm][tn], ac_ = accc[tm][tn];
+          conv_epilogue_pool_only<true>([&](int r) { return __builtin_fmaf(ac_[r], LO_INV, am_[r]); }, bias2L + tn * 32, vld, window,
+                                        interior, pq, tn * 32, kh_e, i_e & 3, pool_split, amax);
+        }
+        PC_T();
+      }
+    } else {
 #pragma unroll
     for (int tn = 0; tn < 2; ++tn) {
       const int cout16 = tn * 32 + kh_e * 16;
@@ -1371,6 +1467,7 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
                                     vld && (i_e & 3) == 0, pool_split, amax);
       }
       PC_T();
+    }
     }
     conv_amax_commit(mem.out_amax, seen, mem.pool ? mem.pool_amax : nullptr, seenp, amax);   // (producers hold no outputs)
   }
@@ -1531,8 +1628,8 @@ void pack_first_conv_frags(const float* w, void* dst_, bool bf) {
     for (int kk = 0; kk < 2; ++kk)
       for (int lane = 0; lane < 64; ++lane)
         for (int j = 0; j < 8; ++j) {
-          const int i = lane & 31, kh = lane >> 5, k = kk * 16 + kh * 8 + j;
-          const float x = k < 27 ? w[(size_t)(n * 32 + i) * 27 + k] : 0.f;
+          const int i = lane & 31, kh = lane >> 5, k = first_conv_slot_tap(kk, kh, j);
+          const float x = k >= 0 ? w[(size_t)(n * 32 + i) * 27 + k] : 0.f;
           const _Float16 h = bf ? host_bf16_as_half(x) : (_Float16)x;
           const _Float16 l = bf ? (_Float16)0 : (_Float16)((x - (float)h) * f16x3::LO_SCALE);
           dst[(((size_t)(n * 2 + kk) * 2 + 0) * 64 + lane) * 8 + j] = h;
@@ -1658,7 +1755,7 @@ static int launch_f16x3_t(const ConvArgs* as, int n, hipStream_t s) {
   if (FUSE1 && BN == 64 && conv_f16x3_uses_pc() && vec_ok && p.Cin == 64 && p.Cout == 64 && p.w1f) {
     // two halo tiles (both channel chunks of conv1_1's output) + the weight double buffer + the image patch
     constexpr size_t HPP = (HP + 31) / 32 * 32;
-    const size_t lds_pc = 2 * HPP * ROWB + 2 * 3 * (size_t)BN * ROWB + 3 * (TH + 4) * (TW + 4) * sizeof(float) + HPP + BN * sizeof(float);
+    const size_t lds_pc = 2 * HPP * ROWB + 2 * 3 * (size_t)BN * ROWB + (3 * (TH + 4) * (TW + 4) + 8) * sizeof(float) + HPP + BN * sizeof(float);
     if (knobs().pc_persist) {
       // one block per CU walks the tiles (tile = block, block + grid, ...)
       p.ntile_blocks = (int)tiles;

@@ -41,6 +41,16 @@ void set_error(const std::string& msg) { g_err = msg; }
     if ((expr) != 0) throw std::runtime_error(g_err);      \
   } while (0)
 
+// hipMemset on the null stream may return before the fill has run, and the null stream is not ordered with the runtime's
+// non-blocking streams: a fill that must be in place before the first kernel touches the buffer is waited for here.  (A
+// lane cloned inside FusedDetector.submit launches its first convolutions microseconds after its slots are cleared: a
+// late fill zeroed slots the first kernels had already published into -- the first image of a process then ran a unit with
+// e = 0 and differed from the same image processed later in the last bit.)
+static void fill_now(void* p, int byte, size_t n) {
+  HIP_THROW(hipMemsetAsync(p, byte, n, nullptr));
+  HIP_THROW(hipStreamSynchronize(nullptr));
+}
+
 // (re)allocations made by the grow-only buffers of this process: a new level shape re-plans sizes and pointers and only
 // allocates where a buffer has to grow (shf_alloc_counts; bench.py's mixed-shape leg reports them after its first pass)
 static std::atomic<long long> g_dev_allocs{0}, g_host_allocs{0};
@@ -57,6 +67,10 @@ struct DevBuf {
     want = (want + 255) & ~(size_t)255;
     HIP_THROW(hipMalloc(&p, want));
     cap = want;
+    // SHF_POISON_ALLOC=<byte> (tests): fresh device buffers start filled with that byte (0xff: NaNs) instead of whatever the
+    // allocator hands out -- a kernel whose result depends on memory it never wrote shows up as a changed detection
+    static const char* poison = getenv("SHF_POISON_ALLOC");
+    if (poison) fill_now(p, (int)strtol(poison, nullptr, 0), want);
   }
   ~DevBuf() {
     if (p) (void)hipFree(p);
@@ -167,6 +181,8 @@ static const char* kProfNames[PC_COUNT] = {"conv_mfma_f32_kernel<3, 1, 128, 8, 1
 
 struct Prof {
   bool on = false;
+  int only = -1;   // >= 0: only launches of this class are bracketed (shf_prof_only)
+  bool wants(int cls) const { return on && (only < 0 || only == cls); }
   struct Rec { int cls; hipEvent_t a, b; double flops, bytes; };
   std::vector<Rec> pending;
   std::vector<hipEvent_t> pool;
@@ -224,7 +240,7 @@ struct ProfScope {
   hipStream_t s;
   Prof::Rec r;
   bool on;
-  ProfScope(Prof& p_, hipStream_t s_, int cls, double flops, double bytes) : p(p_), s(s_), on(p_.on) {
+  ProfScope(Prof& p_, hipStream_t s_, int cls, double flops, double bytes) : p(p_), s(s_), on(p_.wants(cls)) {
     if (!on) return;
     r.cls = cls; r.flops = flops; r.bytes = bytes;
     r.a = p.get(); r.b = p.get();
@@ -245,7 +261,7 @@ struct SubProf {
   Prof::Rec r;
   static void hook(void* ctx, int after, int variant, double share) {
     SubProf* sp = (SubProf*)ctx;
-    if (!sp->p->on) return;
+    if (!sp->p->wants(PC_CONV_F16X3_W4D_0 + variant)) return;
     if (!after) {
       sp->r.cls = PC_CONV_F16X3_W4D_0 + variant;
       sp->r.flops = sp->flops * share;
@@ -567,7 +583,7 @@ void shf_net::build(const std::string& text, const char* caffemodel) {
   proto_text = text;
   if (!clone_src && getenv("SHF_CONV_MODE")) conv_mode = atoi(getenv("SHF_CONV_MODE"));
   range_flag.ensure(64);
-  HIP_THROW(hipMemset(range_flag.p, 0, 64));
+  fill_now(range_flag.p, 0, 64);
   TextParser tp(proto_text);
   root = tp.parse();
   HIP_THROW(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
@@ -926,7 +942,7 @@ void shf_net::build(const std::string& text, const char* caffemodel) {
   }
   alloc_buffers();
   amax_slots.ensure(std::max<size_t>(blobs.size(), 1) * 4);
-  HIP_THROW(hipMemset(amax_slots.p, 0, std::max<size_t>(blobs.size(), 1) * 4));
+  fill_now(amax_slots.p, 0, std::max<size_t>(blobs.size(), 1) * 4);
   if (clone_src) {
     wgen = clone_src->wgen;
     return;
@@ -2084,7 +2100,10 @@ int shf_detect_import(shf_net* net, const float* src_dev5, int n_rows) {
     while (npad < (size_t)ncap) npad <<= 1;
     nk.ensure(npad * 8);
     if (net->img_dets.p && have > 0)
-      HIP_THROW(hipMemcpy(nd.p, net->img_dets.p, (size_t)have * 5 * 4, hipMemcpyDeviceToDevice));
+    {   // (on the list's own stream, and finished before the old buffer is released below)
+      HIP_THROW(hipMemcpyAsync(nd.p, net->img_dets.p, (size_t)have * 5 * 4, hipMemcpyDeviceToDevice, net->stream));
+      HIP_THROW(hipStreamSynchronize(net->stream));
+    }
     std::swap(net->img_dets.p, nd.p); std::swap(net->img_dets.cap, nd.cap);
     std::swap(net->img_keys.p, nk.p); std::swap(net->img_keys.cap, nk.cap);
     net->img_cap = ncap;
@@ -2302,6 +2321,10 @@ int shf_generate_anchors(int base_size, const double* ratios, int n_ratios, cons
 
 int shf_prof_enable(shf_net* net, int enable) {
   net->prof.on = enable != 0;
+  return 0;
+}
+int shf_prof_only(shf_net* net, int cls) {
+  net->prof.only = (cls >= 0 && cls < PC_COUNT) ? cls : -1;
   return 0;
 }
 int shf_prof_num_classes(shf_net*) { return PC_COUNT; }
