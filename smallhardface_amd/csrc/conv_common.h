@@ -596,10 +596,10 @@ __device__ __forceinline__ void conv_epilogue_regs_tail(float (&v)[16], const fl
 // accumulator tile instead of ~175, and the SAME bits: max commutes with the ReLU (max over the quad and 0, as signed
 // integers on the bit patterns: any positive value beats every negative one and 0 beats them all), the bias is added before
 // the max like before, and the unit's max |output| over the pooled values equals that over all in-image outputs (every
-// in-image pixel lies in exactly one clipped window).  getv(r): register r's value before the bias; bias32 = the 32-cout tile's biases (in LDS);
+// in-image pixel lies in exactly one clipped window).  getv(r): register r's value before the bias; getb(q): the biases of couts 8q + 4kh .. + 3 (from LDS, or preloaded);
 // `window` = the quad's top-left pixel is inside the image (the pooled pixel exists); `valid` = this lane's own pixel is.
-template <bool RELU, typename GetV>
-__device__ __forceinline__ void conv_epilogue_pool_only(GetV getv, const float* bias32, bool valid, bool window,
+template <bool RELU, typename GetV, typename GetB>
+__device__ __forceinline__ void conv_epilogue_pool_only(GetV getv, GetB getb, bool valid, bool window,
                                                         bool interior, float* __restrict__ pix_pool, int cout32, int kh,
                                                         int ql, bool pool_split, float& amax) {
   auto quad_max = [&](float xf) {
@@ -623,7 +623,7 @@ __device__ __forceinline__ void conv_epilogue_pool_only(GetV getv, const float* 
   float w0 = 0.f, w1 = 0.f, w2 = 0.f, w3 = 0.f;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    const float4 bq = *(const float4*)(bias32 + 8 * q + 4 * kh);
+    const float4 bq = getb(q);   // biases of couts 8q + 4kh .. + 3
     const cs_f32x2 a = cs_f32x2{getv(4 * q), getv(4 * q + 1)} + cs_f32x2{bq.x, bq.y};
     const cs_f32x2 b = cs_f32x2{getv(4 * q + 2), getv(4 * q + 3)} + cs_f32x2{bq.z, bq.w};
     const float m0 = quad_max(a[0]), m1 = quad_max(a[1]), m2 = quad_max(b[0]), m3 = quad_max(b[1]);

@@ -980,8 +980,9 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4d_kernel(ConvK p) {
           const unsigned pix_q = (unsigned)((g.b * Hp + (y >> 1)) * Wp + (x >> 1));
           float* pq = g.pool + (size_t)pix_q * (unsigned)pool_stride_e;
           const f32x16 a_ = acc[tm][tn];
-          conv_epilogue_pool_only<true>([&](int r) { return a_[r] * out_scale; }, biasL + wn * 64 + tn * 32, valid, window, interior,
-                                        pq, ct * BN + wn * 64 + tn * 32, kh_e, i_e & 3, pool_split, amax);
+          conv_epilogue_pool_only<true>([&](int r) { return a_[r] * out_scale; },
+                                        [&](int q) { return *(const float4*)(biasL + wn * 64 + tn * 32 + 8 * q + 4 * kh_e); }, valid, window,
+                                        interior, pq, ct * BN + wn * 64 + tn * 32, kh_e, i_e & 3, pool_split, amax);
         }
       }
     };
@@ -1033,9 +1034,9 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
   constexpr int PW = TW + 4, PH = TH + 4;
   constexpr int HPP = (HP + 31) / 32 * 32;          // 352: tile rows padded to whole 32-row MFMA tiles, so that
                                                     // conv1_1's epilogue stores need no per-row guard
-  unsigned char* As0 = smem;                        // [HPP][ROWB] channels  0..31 of conv1_1's output
-  unsigned char* As1 = smem + HPP * ROWB;           // [HPP][ROWB] channels 32..63
-  unsigned char* Bs = smem + 2 * HPP * ROWB;        // [2][3][BN][ROWB]
+  unsigned char* As0 = smem;                        // [HP][ROWB] channels  0..31 of conv1_1's output
+  unsigned char* As1 = smem + HP * ROWB;            // [HP][ROWB] channels 32..63 (the last row tile's stores are guarded)
+  unsigned char* Bs = smem + 2 * HP * ROWB;         // [2][3][BN][ROWB]
   // [3][PH][PW] image patch, already split: fp16 hi in the low half of a dword, fp16 lo (x 2^11) in the high half (bf16 mode:
   // the bf16 pattern | 0) -- conv1_1's fragments are then gathered with one byte permute per register, no conversion
   // (round 4; the conversions used to be redone for every fragment element: ~200 vector instructions per row tile).
@@ -1044,6 +1045,13 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
   constexpr int PATCH_DW = 3 * PH * PW + 8;
   unsigned char* valid = (unsigned char*)(patch + PATCH_DW);  // [HPP] halo pixel inside the image? (0 in the padding)
   float* bias2L = (float*)(valid + HPP);                          // [BN] conv1_2's biases (read by the register epilogue)
+  // conv1_1's operands live in LDS (round 4): its weight fragments [n][kk][hi/lo][lane][8 halfs] (8 KiB, the global pack
+  // as it is) and biases -- read where a row tile needs them (ds_read latency, no registers held across anything), by
+  // whichever wave has claimed the row tile
+  unsigned char* w1L = (unsigned char*)(bias2L + BN);             // 8192 B
+  float* b1L = (float*)(w1L + 8192);                              // [64]
+  unsigned* ctrL = (unsigned*)(b1L + 64);                         // [0] next row tile of the next tile's conv1_1 to claim, [1] its halo_inside
+  unsigned* geoL = ctrL + 4;                                      // [16] the next tile's geometry (TileGeo), decoded ONCE, by a producer
 
   int tid = threadIdx.x, lane = tid & 63;
   const int wave = tid >> 6;
@@ -1053,26 +1061,14 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
   // biases for LDS -- so that their round trip runs under the tile decode and the image patch's (they used to be
   // requested after the patch was parked: 2 k cycles of a second, serial round trip per tile)
   int i1 = lane & 31, kh1 = lane >> 5;
-  half8 bw[2][2][2];  // [n][kk][hi/lo]
-  // (unconditional loads -- a missing bias vector reads the weight pack instead and is zeroed where it is first used: a
-  // branch around a load up here makes the compiler wait for everything requested so far)
-  const float* b1p = p.b1 ? p.b1 : (const float*)p.w1f;
   const float* b2p = p.bias ? p.bias : (const float*)p.w1f;
-  float4 bias1v[2][4];
-  auto load_conv1_operands = [&]() {   // (PERSIST: once per tile -- 64 registers that cannot stay alive across the K loop)
-#pragma unroll
-    for (int n = 0; n < 2; ++n)
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-        for (int hl = 0; hl < 2; ++hl)
-          bw[n][kk][hl] = *(const half8*)((const _Float16*)p.w1f + ((size_t)((n * 2 + kk) * 2 + hl) * 64 + (i1 + 32 * kh1)) * 8);
-#pragma unroll
-    for (int n = 0; n < 2; ++n)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) bias1v[n][q] = *(const float4*)(b1p + n * 32 + 8 * q + 4 * kh1);
-  };
-  load_conv1_operands();
+  {   // (requested first: the round trip runs under the tile decode and the image patch's)
+    const float4 wv = ((const float4*)p.w1f)[tid];                 // 512 threads x 16 B = the 8 KiB pack
+    const float b1v = p.b1 ? p.b1[tid & 63] : 0.f;
+    ((float4*)w1L)[tid] = wv;
+    if (tid < 64) b1L[tid] = b1v;
+    if (tid == 0) ctrL[0] = 0u;
+  }
   const float bias2v = b2p[tid & (BN - 1)];
   const int bid = blockIdx.x;
   // the tile's geometry (wave-uniform; PERSIST: re-formed for every tile of the walk).  nct == 1: tile = pixel tile
@@ -1123,7 +1119,7 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
 #endif
 
   float amax1 = 0.f;  // fp16 range guard for conv1_1's outputs (split right here, never seen by another epilogue)
-  bool first_tile = true;
+  half2v amax1h = {(_Float16)0, (_Float16)0};   // ... its packed form, raised by conv1_tile on the hi halves
   auto patch_word = [](float x) -> unsigned {   // fp16 hi | fp16 lo (x 2^11) << 16; bf16 mode: the bf16 pattern
     if constexpr (BF) {
       return (unsigned)__builtin_bit_cast(unsigned short, bf16_as_half(x));
@@ -1133,14 +1129,14 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
       return (unsigned)__builtin_bit_cast(unsigned short, h) | ((unsigned)__builtin_bit_cast(unsigned short, l) << 16);
     }
   };
-  for (;;) {   // (PERSIST: the walk over this block's tiles; otherwise one turn)
-  {  // prologue, all eight waves: conv1_1 + ReLU of the whole halo tile ON THE MATRIX CORES
+  // prologue, all eight waves (first tile of a walk; later tiles: the producers, under the previous tile's epilogue -- below):
+  // conv1_1 + ReLU of the whole halo tile ON THE MATRIX CORES
     // [324 halo px x 27 taps (padded to 32)] x [32 x 64 couts] as split-fp16 MFMAs: 11 row tiles of 32 pixels,
     // 12 MFMAs each; a lane builds its A fragments (pixel lane&31, 8 taps) from the LDS image patch, the B
     // fragments (weights) come pre-packed from global memory.  N tile 0 / 1 = channel chunk 0 / 1 = halo tile
     // As0 / As1.  (On the vector ALUs this was 15-18 k cycles per tile, a third of the block.)
     static_assert(PH == 20 && PW == 20 && HTW == 18, "the multiply-shift divisions below are exact for these sizes");
-    if (first_tile) {   // (a later tile's patch, flags and first weights were fetched by the producers under the previous K loop)
+    {   // (a later tile's patch, flags and first weights are fetched by the producers under the previous tile's K loop)
     const float* img = mem.img;
     constexpr int NPATCH = (3 * PH * PW + 511) / 512;   // 3 values per thread (the last round ragged): all requested, then parked
     float pv[NPATCH];
@@ -1171,21 +1167,13 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
     // conv1_1 runs as D[cout][pixel] (weights = A operand): a lane owns ONE halo pixel and the 16 couts
     // (r & 3) + 8 (r >> 2) + 4 kh of each 32-channel chunk -- one validity flag per lane, and after the half-wave
     // exchange 16 consecutive couts = two 16-byte LDS stores each for hi and lo (the D[pixel][cout] form wrote 32 two-byte
-    // values per lane and chunk and read 16 flags).  bias1v[n][q] = biases of couts 8 q + 4 kh .. + 3 of chunk n.
-    if (first_tile) __syncthreads();   // (wave-uniform; a later tile starts behind the walk's barrier)
-    if (!p.b1) {   // (wave-uniform, rare)
-#pragma unroll
-      for (int n = 0; n < 2; ++n)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) bias1v[n][q] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+    // values per lane and chunk and read 16 flags).
+    __syncthreads();
     PC_T();
     constexpr int NMT = (HP + 31) / 32;  // 11 row tiles
     // work items: tiles 0..7 whole (one per wave), tiles 8..10 split by N tile over waves 0..5: the longest
     // wave does 1.5 tiles instead of 2
-    const bool halo_inside = ty0 >= 1 && tx0 >= 1 && ty0 + TH < H && tx0 + TW < W;   // (wave-uniform)
-    half2v amax1h = {(_Float16)0, (_Float16)0};
-    auto conv1_tile = [&](int m, int n_lo, int n_hi) {
+    auto conv1_tile = [&](int m, int n_lo, int n_hi, bool halo_inside) {
       const int hp = m * 32 + i1 < HP ? m * 32 + i1 : HP - 1;
       const int hy = (hp * 58255) >> 20, hx = hp - hy * HTW;
       // sixteen packed patch words at base(kk, kh) + a compile-time offset (first_conv_slot_tap), then one byte permute per
@@ -1217,69 +1205,84 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
         ah[1] = __builtin_bit_cast(half8, u32x4{h1[0], h1[1], h1[2], h1[3]});
         al[1] = __builtin_bit_cast(half8, u32x4{l1[0], l1[1], l1[2], l1[3]});
       }
+      const bool row_ok = m + 1 < NMT || m * 32 + i1 < HP;   // (the last row tile is ragged: 324 = 10 x 32 + 4)
 #pragma unroll
       for (int n = 0; n < 2; ++n) {
         if (n < n_lo || n >= n_hi) continue;  // wave-uniform
+        half8 bwn[2][2];   // [kk][hi / lo] of chunk n, from LDS
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+          for (int hl = 0; hl < 2; ++hl)
+            bwn[kk][hl] = *(const half8*)(w1L + ((size_t)((n * 2 + kk) * 2 + hl) * 64 + (i1 + 32 * kh1)) * 16);
         f32x16 cm, cc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { cm[r] = 0.f; cc[r] = 0.f; }
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-          cm = mma16<BF>(bw[n][kk][0], ah[kk], cm);
-          if constexpr (!BF) cc = mma16<BF>(bw[n][kk][1], ah[kk], cc);
+          cm = mma16<BF>(bwn[kk][0], ah[kk], cm);
+          if constexpr (!BF) cc = mma16<BF>(bwn[kk][1], ah[kk], cc);
         }
         if constexpr (!BF) {
 #pragma unroll
-          for (int kk = 0; kk < 2; ++kk) cc = mma16<BF>(bw[n][kk][0], al[kk], cc);
+          for (int kk = 0; kk < 2; ++kk) cc = mma16<BF>(bwn[kk][0], al[kk], cc);
         }
-        // C row (cout) = (r & 3) + 8 (r >> 2) + 4 kh, C column (halo pixel) = lane & 31
+        // C row (cout) = (r & 3) + 8 (r >> 2) + 4 kh, C column (halo pixel) = lane & 31: registers 4q .. 4q + 3 are the FOUR
+        // CONSECUTIVE couts 8q + 4kh .. + 3 -- 8 bytes of hi and 8 bytes of lo in the pixel's LDS row, stored as they are (the
+        // half-wave exchange that made 16-byte stores of them cost eight permlane swaps with their wait states)
         float v[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float4 bq = bias1v[n][r >> 2];
-          const float bias = (r & 3) == 0 ? bq.x : (r & 3) == 1 ? bq.y : (r & 3) == 2 ? bq.z : bq.w;
-          v[r] = fmaxf(cm[r] + cc[r] * LO_INV + bias, 0.f);
+        for (int q = 0; q < 4; ++q) {
+          const float4 bq = *(const float4*)(b1L + n * 32 + 8 * q + 4 * kh1);
+          v[4 * q] = fmaxf(cm[4 * q] + cc[4 * q] * LO_INV + bq.x, 0.f);
+          v[4 * q + 1] = fmaxf(cm[4 * q + 1] + cc[4 * q + 1] * LO_INV + bq.y, 0.f);
+          v[4 * q + 2] = fmaxf(cm[4 * q + 2] + cc[4 * q + 2] * LO_INV + bq.z, 0.f);
+          v[4 * q + 3] = fmaxf(cm[4 * q + 3] + cc[4 * q + 3] * LO_INV + bq.w, 0.f);
         }
         if (!(halo_inside && m + 1 < NMT)) {   // (wave-uniform: most row tiles have every halo pixel inside the image)
           const bool ok = valid[m * 32 + i1] != 0;   // 0 outside the image (conv1_2's zero padding, not conv1_1 evaluated out there)
 #pragma unroll
           for (int r = 0; r < 16; ++r) v[r] = ok ? v[r] : 0.f;
         }
-        conv_swap_halves(v);   // kh = 0 now holds couts 0..15, kh = 1 couts 16..31, register order 0-3, 8-11, 4-7, 12-15
-        constexpr int ORD[4] = {0, 8, 4, 12};
-        float hi8[8], lo8[8];
+        unsigned char* row = (n ? As1 : As0) + (m * 32 + i1) * ROWB + kh1 * 8;
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
-#pragma unroll
-          for (int t = 0; t < 4; t += 2) {
-            const float x0 = v[ORD[g] + t], x1 = v[ORD[g] + t + 1];
-            half2v h, l;
-            if constexpr (BF) {
-              h = __builtin_bit_cast(half2v, pk_bf16(x0, x1));
-              l = half2v{(_Float16)0, (_Float16)0};
-            } else {
-              h = __builtin_convertvector(f32x2{x0, x1}, half2v);
-              l = __builtin_convertvector((f32x2{x0, x1} - __builtin_convertvector(h, f32x2)) * LO_SCALE, half2v);
-            }
+        for (int q = 0; q < 4; ++q) {
+          half2v h0, h1, l0, l1;
+          const f32x2 x0 = {v[4 * q], v[4 * q + 1]}, x1 = {v[4 * q + 2], v[4 * q + 3]};
+          if constexpr (BF) {
+            h0 = __builtin_bit_cast(half2v, pk_bf16(x0[0], x0[1]));
+            h1 = __builtin_bit_cast(half2v, pk_bf16(x1[0], x1[1]));
+          } else {
+            h0 = __builtin_convertvector(x0, half2v);
+            h1 = __builtin_convertvector(x1, half2v);
+            l0 = __builtin_convertvector((x0 - __builtin_convertvector(h0, f32x2)) * LO_SCALE, half2v);
+            l1 = __builtin_convertvector((x1 - __builtin_convertvector(h1, f32x2)) * LO_SCALE, half2v);
             // fp16 range guard of conv1_1's outputs, on the PACKED hi halves (values >= 0; an overflow is an inf there)
-            if constexpr (!BF) amax1h = __builtin_elementwise_max(amax1h, h);
-            hi8[g * 2 + (t >> 1)] = __builtin_bit_cast(float, h);
-            lo8[g * 2 + (t >> 1)] = __builtin_bit_cast(float, l);
+            amax1h = __builtin_elementwise_max(amax1h, __builtin_elementwise_max(h0, h1));
           }
-        unsigned char* row = (n ? As1 : As0) + (m * 32 + i1) * ROWB + kh1 * 32;
-        *(float4*)row = make_float4(hi8[0], hi8[1], hi8[2], hi8[3]);
-        *(float4*)(row + 16) = make_float4(hi8[4], hi8[5], hi8[6], hi8[7]);
-        if constexpr (!BF) {
-          *(float4*)(row + 64) = make_float4(lo8[0], lo8[1], lo8[2], lo8[3]);
-          *(float4*)(row + 80) = make_float4(lo8[4], lo8[5], lo8[6], lo8[7]);
+          if (row_ok) {
+            *(float2*)(row + q * 16) = make_float2(__builtin_bit_cast(float, h0), __builtin_bit_cast(float, h1));
+            if constexpr (!BF)
+              *(float2*)(row + 64 + q * 16) = make_float2(__builtin_bit_cast(float, l0), __builtin_bit_cast(float, l1));
+          }
         }
       }
     };
-    conv1_tile(wave_u, 0, 2);
-    if (wave_u < 2 * (NMT - 8)) conv1_tile(8 + wave_u % (NMT - 8), wave_u / (NMT - 8), wave_u / (NMT - 8) + 1);
-    amax1 = conv_absmax_bits(amax1, fmaxf((float)amax1h[0], (float)amax1h[1]));
-  }
+    {
+      const bool halo_inside = ty0 >= 1 && tx0 >= 1 && ty0 + TH < H && tx0 + TW < W;   // (wave-uniform)
+      conv1_tile(wave_u, 0, 2, halo_inside);
+      if (wave_u < 2 * (NMT - 8)) conv1_tile(8 + wave_u % (NMT - 8), wave_u / (NMT - 8), wave_u / (NMT - 8) + 1, halo_inside);
+      amax1 = conv_absmax_bits(amax1, fmaxf((float)amax1h[0], (float)amax1h[1]));
+    }
 
+#ifdef SHF_CONV_TIMING
+  unsigned long long ts_k = 0, ts_bar = 0, ts_role = 0, ts_tail = 0, t_role_end = 0;
+  int n_walk = 0;
+#endif
+  for (;;) {   // (PERSIST: the walk over this block's tiles; otherwise one turn)
+#ifdef SHF_CONV_TIMING
+  nt = 3;
+#endif
   // consumer geometry: wave wm = rows 4 wm .. 4 wm + 3 (two 2x16-pixel MFMA row tiles), all 64 couts
   const int i = lane & 31, kh = lane >> 5;
   int dy, px;
@@ -1374,7 +1377,9 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
     } else {
       if (st + 1 < 6) dma_w(st + 1, (st + 1) & 1);
       if constexpr (PERSIST) {
-        const int ptid = tid - 256;
+        int lane_p = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));   // (not kept across the stages)
+        asm volatile("" : "+v"(lane_p));
+        const int ptid = (wave_u - 4) * 64 + lane_p;
         if (st == 0 && has_next) {
           nxt = decode(tile + gstride);
 #pragma unroll
@@ -1386,6 +1391,19 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
             const bool in = idx < 3 * PH * PW && (unsigned)gy < (unsigned)nxt.H && (unsigned)gx < (unsigned)nxt.W;
             pvn[k] = in ? nxt.img[((size_t)ci * nxt.H + gy) * nxt.W + gx] : 0.f;
           }
+        }
+        if (st == 3 && has_next && ptid == 0) {   // (the previous tile's claims ended before stage 0; read behind the post-K barrier)
+          ctrL[0] = 0u;
+          ctrL[1] = (nxt.ty0 >= 1 && nxt.tx0 >= 1 && nxt.ty0 + TH < nxt.H && nxt.tx0 + TW < nxt.W) ? 1u : 0u;
+          // the tile's geometry for every wave of the block (the decode is ~2 k cycles of dependent scalar loads: it ran on
+          // this wave under stage 0; the others used to repeat it at the end of their tile)
+          geoL[0] = (unsigned)nxt.b; geoL[1] = (unsigned)nxt.ty0; geoL[2] = (unsigned)nxt.tx0; geoL[3] = (unsigned)nxt.H;
+          geoL[4] = (unsigned)nxt.W;
+          const unsigned long long q0 = (unsigned long long)nxt.img, q1 = (unsigned long long)nxt.out, q2 = (unsigned long long)nxt.pool,
+                                   q3 = (unsigned long long)nxt.out_amax, q4 = (unsigned long long)nxt.pool_amax;
+          geoL[6] = (unsigned)q0; geoL[7] = (unsigned)(q0 >> 32); geoL[8] = (unsigned)q1; geoL[9] = (unsigned)(q1 >> 32);
+          geoL[10] = (unsigned)q2; geoL[11] = (unsigned)(q2 >> 32); geoL[12] = (unsigned)q3; geoL[13] = (unsigned)(q3 >> 32);
+          geoL[14] = (unsigned)q4; geoL[15] = (unsigned)(q4 >> 32);
         }
         if (st == 2 && has_next) {
 #pragma unroll
@@ -1404,19 +1422,37 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
         }
         // (buffer 0 held stage 4's weights; every consumer is past them behind this stage's barrier)
         if (st == 5 && has_next) dma_w(0, 0);
+
       }
     }
   }
 
   PC_T();
+  // PERSIST (round 4): conv1_1 of the NEXT tile runs on the four producer waves WHILE the consumers store this tile -- both
+  // are vector-ALU phases, the epilogue latency-bound on one wave per SIMD (~10 cycles per instruction), so the two streams
+  // share a SIMD's issue slots instead of queueing (measured: a matrix stream leaves a partner wave ~3 vector issues per
+  // MFMA, tools/scratch/coissue.hip -- conv1_1 under the K loop was the wrong place).  The halo tiles are free once every
+  // consumer has issued its last fragment read: one more barrier; the next tile's patch and flags were parked in stage 2.
+  if (PERSIST && has_next) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();   // every consumer has issued its last fragment read: the halo tiles are the producers'
+  }
+#ifdef SHF_CONV_TIMING
+  const unsigned long long t_barx = __builtin_amdgcn_s_memtime();
+#endif
   // epilogue: the four consumer waves store from registers (conv_common.h conv_epilogue_regs: half-wave exchange, 16
   // consecutive couts per lane, fused 2x2 max-pool as a DPP quad max) -- no LDS round trip, no barrier
   float amax = 0.f;  // this layer's stored outputs: fp16 range guard (with conv1_1's, amax1) + activation exponent
   if (consumer) {
     const bool relu = (p.relu & 1) != 0, write_main = !(p.relu & 8), main_split = (p.relu & 32) != 0,
                pool_split = (p.relu & 64) != 0;
-    int px_e = px, dy_e = dy, kh_e = kh, i_e = i;
-    asm volatile("" : "+v"(px_e), "+v"(dy_e), "+v"(kh_e), "+v"(i_e));
+    // (the lane's coordinates are formed AGAIN here, from the lane id the hardware hands out: kept alive across the K loop
+    // they are spilled, and a scratch reload between the stores waits for every store issued so far)
+    int lane_e = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    asm volatile("" : "+v"(lane_e));
+    const int i_e = lane_e & 31, kh_e = lane_e >> 5;
+    int px_e, dy_e;
+    row_to_pixel(i_e, dy_e, px_e);
     asm volatile("" : "+v"(seen), "+v"(seenp));   // (the compiler's wait for the peeks goes here, before the first store)
     seen = __builtin_amdgcn_readfirstlane(seen);
     seenp = __builtin_amdgcn_readfirstlane(seenp);
@@ -1430,6 +1466,9 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
       // the un-pooled map is not stored (conv1_2 -> pool1 of VGG-16): the pool-only epilogue (conv_common.h), same bits
 #pragma unroll
       for (int tn = 0; tn < 2; ++tn) {
+        float4 bias_q[4];   // (one LDS round trip per cout half, not one per register quad of every tile)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bias_q[q] = *(const float4*)(bias2L + tn * 32 + 8 * q + 4 * kh_e);
 #pragma unroll
         for (int tm = 0; tm < MT; ++tm) {
           int y = ty0 + wm * 2 * MT + tm * 2 + dy_e;
@@ -1439,8 +1478,8 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
           const unsigned pix_q = (unsigned)((b * Hp + (y >> 1)) * Wp + (x >> 1));
           float* pq = mem.pool + (size_t)pix_q * (unsigned)pool_stride_e;
           const f32x16 am_ = accm[tm][tn], ac_ = accc[tm][tn];
-          conv_epilogue_pool_only<true>([&](int r) { return __builtin_fmaf(ac_[r], LO_INV, am_[r]); }, bias2L + tn * 32, vld, window,
-                                        interior, pq, tn * 32, kh_e, i_e & 3, pool_split, amax);
+          conv_epilogue_pool_only<true>([&](int r) { return __builtin_fmaf(ac_[r], LO_INV, am_[r]); }, [&](int q) { return bias_q[q]; },
+                                        vld, window, interior, pq, tn * 32, kh_e, i_e & 3, pool_split, amax);
         }
         PC_T();
       }
@@ -1471,29 +1510,69 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
     }
     conv_amax_commit(mem.out_amax, seen, mem.pool ? mem.pool_amax : nullptr, seenp, amax);   // (producers hold no outputs)
   }
+  if (PERSIST && has_next) {
+    // the next tile's conv1_1: its 11 row tiles are CLAIMED one at a time (an LDS counter) by whichever wave is free -- the
+    // producers from the barrier on, the consumers once their epilogue is out.  (Measured and dropped: row tiles split per
+    // channel chunk -- 22 finer items -- cost more than their better balance gives, 1633 vs 1595 us: the fragments are built
+    // twice and an item is one dependent chain; channel chunk 0 under stages 3-5 on the producer waves lengthens the K
+    // loop by exactly what the producers run, with or without s_setprio: a matrix stream leaves its SIMD partner ~3 vector
+    // issues per MFMA, tools/scratch/coissue.hip.)
+    int lane_p = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));   // (not kept across the K loop)
+    asm volatile("" : "+v"(lane_p));
+    i1 = lane_p & 31;
+    kh1 = lane_p >> 5;
+    const bool halo_inside = __builtin_amdgcn_readfirstlane((int)ctrL[1]) != 0;
+#pragma unroll 1
+    for (;;) {
+      unsigned got = 0u;
+      if (lane_p == 0) got = atomicAdd(ctrL, 1u);
+      const int m = __builtin_amdgcn_readfirstlane((int)got);
+      if (m >= NMT) break;
+      conv1_tile(m, 0, 2, halo_inside);
+    }
+    amax1 = conv_absmax_bits(amax1, fmaxf((float)amax1h[0], (float)amax1h[1]));
+  }
   conv_raise_range_flag(p.range_flag, conv_absmax_bits(amax, amax1));
+#ifdef SHF_CONV_TIMING
+  {
+    asm volatile("s_nop 0" ::: "memory");
+    const unsigned long long t_now = __builtin_amdgcn_s_memtime();
+    // per tile: first stage's barrier passed (tt[3]) .. K loop done (tt[9]) .. barrier X .. role work done; tail = from the
+    // previous tile's role end to this tile's first stage start (the wait for the other role)
+    if (n_walk > 0) ts_tail += tt[3] - t_role_end;
+    ts_k += tt[9] - tt[3];
+    ts_bar += t_barx - tt[9];
+    ts_role += t_now - t_barx;
+    t_role_end = t_now;
+    ++n_walk;
+  }
+#endif
   if (!PERSIST || !has_next) break;
   // the walk's next tile: its patch, flags and first weight stage are in flight or parked; conv1_1 may overwrite the halo
   // tiles once every consumer is out of the K loop (they are: the epilogue is behind it)
   tile += gstride;
-  mem = decode(tile);
+  {
+    auto rd = [&](int k) { return (unsigned)__builtin_amdgcn_readfirstlane((int)geoL[k]); };
+    auto rd64 = [&](int k) { return (unsigned long long)rd(k) | ((unsigned long long)rd(k + 1) << 32); };
+    mem = TileGeo{(int)rd(0), (int)rd(1), (int)rd(2), (int)rd(3), (int)rd(4), (const float*)rd64(6), (float*)rd64(8), (float*)rd64(10),
+                  (unsigned*)rd64(12), (unsigned*)rd64(14)};
+  }
   b = mem.b; ty0 = mem.ty0; tx0 = mem.tx0; H = mem.H; W = mem.W; gout = mem.out;
   amax1 = 0.f;
-  first_tile = false;
+  amax1h = half2v{(_Float16)0, (_Float16)0};
   // (opaque per tile: what conv1_1 derives from the lane's coordinates -- 16 patch offsets, row addresses -- is formed again
   // for every tile instead of living in registers across the K loop)
-  asm volatile("" : "+v"(i1), "+v"(kh1), "+v"(lane), "+v"(tid));
-  load_conv1_operands();
-  __syncthreads();
+  asm volatile("" : "+v"(lane));
+  // (no barrier here: stage 0's orders the producers' conv1_1 stores before the consumers' first fragment reads)
   }
   PC_T();
 #ifdef SHF_CONV_TIMING
   // tt: 0 entry, 1 patch requested + parked, 2 barrier, 3..8 the six stages' starts, 9 K loop done, (consumers: 10, 11 the
   // two cout halves stored,) last: flags published.  A first-round block (100) and two steady-state ones.
   if ((bid == 100 || bid == 9000 || bid == 20000) && lane == 0 && (wave == 0 || wave == 4))
-    printf("[pc] blk%d wave%d decode %llu dma-issue %llu | patch %llu barrier %llu conv1_1 %llu | stages %llu %llu %llu %llu %llu %llu | epilogue %llu %llu %llu\n",
-           bid, wave, t_dec - tt[0], t_dma - t_dec, tt[1] - tt[0], tt[2] - tt[1], tt[3] - tt[2], tt[4] - tt[3], tt[5] - tt[4], tt[6] - tt[5],
-           tt[7] - tt[6], tt[8] - tt[7], tt[9] - tt[8], tt[10] - tt[9], nt > 11 ? tt[11] - tt[10] : 0ull, nt > 12 ? tt[12] - tt[11] : 0ull);
+    printf("[pc] blk%d wave%d tiles %d | per tile: K loop %llu, wait at the post-K barrier %llu, role work (wave 0: epilogue, wave 4: next tile's conv1_1) %llu, wait for stage 0 %llu | last tile's stages %llu %llu %llu %llu %llu %llu\n",
+           bid, wave, n_walk, ts_k / n_walk, ts_bar / n_walk, ts_role / n_walk,
+           n_walk > 1 ? ts_tail / (n_walk - 1) : 0ull, tt[4] - tt[3], tt[5] - tt[4], tt[6] - tt[5], tt[7] - tt[6], tt[8] - tt[7], tt[9] - tt[8]);
 #endif
 #undef PC_T
 }
@@ -1755,7 +1834,10 @@ static int launch_f16x3_t(const ConvArgs* as, int n, hipStream_t s) {
   if (FUSE1 && BN == 64 && conv_f16x3_uses_pc() && vec_ok && p.Cin == 64 && p.Cout == 64 && p.w1f) {
     // two halo tiles (both channel chunks of conv1_1's output) + the weight double buffer + the image patch
     constexpr size_t HPP = (HP + 31) / 32 * 32;
-    const size_t lds_pc = 2 * HPP * ROWB + 2 * 3 * (size_t)BN * ROWB + (3 * (TH + 4) * (TW + 4) + 8) * sizeof(float) + HPP + BN * sizeof(float);
+    // (+ conv1_1's weight fragments 8 KiB, its 64 biases, the row-tile counter: 162 512 B of the 160 KiB)
+    const size_t lds_pc = 2 * (size_t)HP * ROWB + 2 * 3 * (size_t)BN * ROWB + (3 * (TH + 4) * (TW + 4) + 8) * sizeof(float) + HPP +
+                          BN * sizeof(float) + 8192 + 64 * sizeof(float) + 16 + 64;
+if (lds_pc > 160 * 1024) { set_error("conv f16x3: the fused first pair does not fit the LDS"); return -1; }
     if (knobs().pc_persist) {
       // one block per CU walks the tiles (tile = block, block + grid, ...)
       p.ntile_blocks = (int)tiles;
