@@ -1052,6 +1052,8 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
   float* b1L = (float*)(w1L + 8192);                              // [64]
   unsigned* ctrL = (unsigned*)(b1L + 64);                         // [0] next row tile of the next tile's conv1_1 to claim, [1] its halo_inside
   unsigned* geoL = ctrL + 4;                                      // [16] the next tile's geometry (TileGeo), decoded ONCE, by a producer
+  constexpr int PC_TABN = 300;
+  unsigned* tabL = geoL + 16;                                     // [PC_TABN] packed geometry of the tiles this block walks (ConvK::pc_tab)
 
   int tid = threadIdx.x, lane = tid & 63;
   const int wave = tid >> 6;
@@ -1069,6 +1071,31 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
     if (tid < 64) b1L[tid] = b1v;
     if (tid == 0) ctrL[0] = 0u;
   }
+  if (PERSIST && p.pc_tab) {
+    // this block's tiles (blockIdx + k gridDim), decoded by all lanes in parallel, once: in the walk the decode is then one LDS
+    // word + the member's record instead of ~2-4 k cycles of dependent scalar loads on a producer wave beside the consumers'
+    // MFMAs (scalar-register spills are vector instructions, and a matrix stream leaves its SIMD partner ~3 of those per MFMA)
+    for (int k = tid; (int)blockIdx.x + k * (int)gridDim.x < p.ntile_blocks; k += 512) {
+      int pt = (int)blockIdx.x + k * (int)gridDim.x, mi = 0;
+      int ts = 0;
+      unsigned tpi = (unsigned)p.m[0].tiles_per_img, itpi = p.m[0].inv_tiles_per_img, tlx = (unsigned)p.m[0].tiles_x, itlx = p.m[0].inv_tiles_x;
+#pragma unroll
+      for (int q = 1; q < MAX_GROUP; ++q) {
+        const bool ge = pt >= p.tile_starts[q];   // (unused entries are INT_MAX)
+        mi = ge ? q : mi;
+        ts = ge ? p.tile_starts[q] : ts;
+        tpi = ge ? (unsigned)p.m[q].tiles_per_img : tpi;
+        itpi = ge ? p.m[q].inv_tiles_per_img : itpi;
+        tlx = ge ? (unsigned)p.m[q].tiles_x : tlx;
+        itlx = ge ? p.m[q].inv_tiles_x : itlx;
+      }
+      pt -= ts;
+      const unsigned b_ = conv_div((unsigned)pt, tpi, itpi);
+      pt -= (int)(b_ * tpi);
+      const unsigned ty_ = conv_div((unsigned)pt, tlx, itlx), tx_ = (unsigned)pt - ty_ * tlx;
+      tabL[k] = (unsigned)mi | (b_ << 4) | (ty_ << 12) | (tx_ << 22);
+    }
+  }
   const float bias2v = b2p[tid & (BN - 1)];
   const int bid = blockIdx.x;
   // the tile's geometry (wave-uniform; PERSIST: re-formed for every tile of the walk).  nct == 1: tile = pixel tile
@@ -1081,7 +1108,13 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
     conv_split_tile(m, pt, b_, ty_, tx_);
     return TileGeo{b_, ty_ * TH, tx_ * TW, m.H, m.W, m.img + (size_t)b_ * 3 * m.H * m.W, m.out, m.pool, m.out_amax, m.pool_amax};
   };
-  int tile = bid;
+  auto decode_tab = [&](int k) {   // the k-th tile of this block's walk, from the LDS table
+    const unsigned w = (unsigned)__builtin_amdgcn_readfirstlane((int)tabL[k]);
+    const ConvMember& m = p.m[w & 15u];
+    const int b_ = (int)((w >> 4) & 255u), ty_ = (int)((w >> 12) & 1023u), tx_ = (int)(w >> 22);
+    return TileGeo{b_, ty_ * TH, tx_ * TW, m.H, m.W, m.img + (size_t)b_ * 3 * m.H * m.W, m.out, m.pool, m.out_amax, m.pool_amax};
+  };
+  int tile = bid, k_walk = 0;
   const int ntiles = PERSIST ? p.ntile_blocks : 0, gstride = (int)gridDim.x;
   TileGeo mem = decode(tile);
   int b = mem.b, ty0 = mem.ty0, tx0 = mem.tx0, H = mem.H, W = mem.W;
@@ -1206,45 +1239,63 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
         al[1] = __builtin_bit_cast(half8, u32x4{l1[0], l1[1], l1[2], l1[3]});
       }
       const bool row_ok = m + 1 < NMT || m * 32 + i1 < HP;   // (the last row tile is ragged: 324 = 10 x 32 + 4)
+      // THREE PHASES, each over both channel chunks: every LDS operand read (weight fragments, biases) issued up front, then
+      // all the MFMAs (two independent chains), then the two epilogues.  Written chunk by chunk -- operands, MFMAs, epilogue,
+      // stores, next chunk -- the compiler waited for each bias quad on its own (eight serial LDS round trips) and could not
+      // start chunk 1's reads before chunk 0's LDS stores: a row tile was one ~2.8 k-cycle dependent chain.
+      half8 bwn[2][2][2];   // [n][kk][hi / lo]
+      float4 bq[2][4];      // [n][register quad]: biases of couts 8q + 4kh .. + 3
 #pragma unroll
       for (int n = 0; n < 2; ++n) {
         if (n < n_lo || n >= n_hi) continue;  // wave-uniform
-        half8 bwn[2][2];   // [kk][hi / lo] of chunk n, from LDS
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
           for (int hl = 0; hl < 2; ++hl)
-            bwn[kk][hl] = *(const half8*)(w1L + ((size_t)((n * 2 + kk) * 2 + hl) * 64 + (i1 + 32 * kh1)) * 16);
-        f32x16 cm, cc;
+            bwn[n][kk][hl] = *(const half8*)(w1L + ((size_t)((n * 2 + kk) * 2 + hl) * 64 + (i1 + 32 * kh1)) * 16);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { cm[r] = 0.f; cc[r] = 0.f; }
+        for (int q = 0; q < 4; ++q) bq[n][q] = *(const float4*)(b1L + n * 32 + 8 * q + 4 * kh1);
+      }
+      unsigned char okb = 1;
+      const bool need_ok = !(halo_inside && m + 1 < NMT);   // (wave-uniform: most row tiles have every halo pixel inside the image)
+      if (need_ok) okb = valid[m * 32 + i1];               // 0 outside the image (conv1_2's zero padding, not conv1_1 evaluated out there)
+      f32x16 cm[2], cc[2];
+#pragma unroll
+      for (int n = 0; n < 2; ++n) {
+        if (n < n_lo || n >= n_hi) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { cm[n][r] = 0.f; cc[n][r] = 0.f; }
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-          cm = mma16<BF>(bwn[kk][0], ah[kk], cm);
-          if constexpr (!BF) cc = mma16<BF>(bwn[kk][1], ah[kk], cc);
+          cm[n] = mma16<BF>(bwn[n][kk][0], ah[kk], cm[n]);
+          if constexpr (!BF) cc[n] = mma16<BF>(bwn[n][kk][1], ah[kk], cc[n]);
         }
         if constexpr (!BF) {
 #pragma unroll
-          for (int kk = 0; kk < 2; ++kk) cc = mma16<BF>(bwn[kk][0], al[kk], cc);
+          for (int kk = 0; kk < 2; ++kk) cc[n] = mma16<BF>(bwn[n][kk][0], al[kk], cc[n]);
         }
+      }
+#pragma unroll
+      for (int n = 0; n < 2; ++n) {
+        if (n < n_lo || n >= n_hi) continue;
         // C row (cout) = (r & 3) + 8 (r >> 2) + 4 kh, C column (halo pixel) = lane & 31: registers 4q .. 4q + 3 are the FOUR
         // CONSECUTIVE couts 8q + 4kh .. + 3 -- 8 bytes of hi and 8 bytes of lo in the pixel's LDS row, stored as they are (the
         // half-wave exchange that made 16-byte stores of them cost eight permlane swaps with their wait states)
         float v[16];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const float4 bq = *(const float4*)(b1L + n * 32 + 8 * q + 4 * kh1);
-          v[4 * q] = fmaxf(cm[4 * q] + cc[4 * q] * LO_INV + bq.x, 0.f);
-          v[4 * q + 1] = fmaxf(cm[4 * q + 1] + cc[4 * q + 1] * LO_INV + bq.y, 0.f);
-          v[4 * q + 2] = fmaxf(cm[4 * q + 2] + cc[4 * q + 2] * LO_INV + bq.z, 0.f);
-          v[4 * q + 3] = fmaxf(cm[4 * q + 3] + cc[4 * q + 3] * LO_INV + bq.w, 0.f);
+          v[4 * q] = fmaxf(cm[n][4 * q] + cc[n][4 * q] * LO_INV + bq[n][q].x, 0.f);
+          v[4 * q + 1] = fmaxf(cm[n][4 * q + 1] + cc[n][4 * q + 1] * LO_INV + bq[n][q].y, 0.f);
+          v[4 * q + 2] = fmaxf(cm[n][4 * q + 2] + cc[n][4 * q + 2] * LO_INV + bq[n][q].z, 0.f);
+          v[4 * q + 3] = fmaxf(cm[n][4 * q + 3] + cc[n][4 * q + 3] * LO_INV + bq[n][q].w, 0.f);
         }
-        if (!(halo_inside && m + 1 < NMT)) {   // (wave-uniform: most row tiles have every halo pixel inside the image)
-          const bool ok = valid[m * 32 + i1] != 0;   // 0 outside the image (conv1_2's zero padding, not conv1_1 evaluated out there)
+        if (need_ok) {
+          const bool ok = okb != 0;
 #pragma unroll
           for (int r = 0; r < 16; ++r) v[r] = ok ? v[r] : 0.f;
         }
         unsigned char* row = (n ? As1 : As0) + (m * 32 + i1) * ROWB + kh1 * 8;
+        float2 sh[4], sl[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           half2v h0, h1, l0, l1;
@@ -1252,6 +1303,7 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
           if constexpr (BF) {
             h0 = __builtin_bit_cast(half2v, pk_bf16(x0[0], x0[1]));
             h1 = __builtin_bit_cast(half2v, pk_bf16(x1[0], x1[1]));
+            l0 = l1 = half2v{(_Float16)0, (_Float16)0};
           } else {
             h0 = __builtin_convertvector(x0, half2v);
             h1 = __builtin_convertvector(x1, half2v);
@@ -1260,10 +1312,14 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
             // fp16 range guard of conv1_1's outputs, on the PACKED hi halves (values >= 0; an overflow is an inf there)
             amax1h = __builtin_elementwise_max(amax1h, __builtin_elementwise_max(h0, h1));
           }
-          if (row_ok) {
-            *(float2*)(row + q * 16) = make_float2(__builtin_bit_cast(float, h0), __builtin_bit_cast(float, h1));
-            if constexpr (!BF)
-              *(float2*)(row + 64 + q * 16) = make_float2(__builtin_bit_cast(float, l0), __builtin_bit_cast(float, l1));
+          sh[q] = make_float2(__builtin_bit_cast(float, h0), __builtin_bit_cast(float, h1));
+          sl[q] = make_float2(__builtin_bit_cast(float, l0), __builtin_bit_cast(float, l1));
+        }
+        if (row_ok) {   // (one branch for the row's eight stores)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            *(float2*)(row + q * 16) = sh[q];
+            if constexpr (!BF) *(float2*)(row + 64 + q * 16) = sl[q];
           }
         }
       }
@@ -1275,8 +1331,10 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
       amax1 = conv_absmax_bits(amax1, fmaxf((float)amax1h[0], (float)amax1h[1]));
     }
 
+  TileGeo nxt_pre = mem;
+  if (PERSIST && !consumer && tile + gstride < ntiles) nxt_pre = decode(tile + gstride);
 #ifdef SHF_CONV_TIMING
-  unsigned long long ts_k = 0, ts_bar = 0, ts_role = 0, ts_tail = 0, t_role_end = 0;
+  unsigned long long ts_k = 0, ts_bar = 0, ts_role = 0, ts_tail = 0, t_role_end = 0, ts_st[6] = {0, 0, 0, 0, 0, 0}, ts_own[6] = {0, 0, 0, 0, 0, 0};
   int n_walk = 0;
 #endif
   for (;;) {   // (PERSIST: the walk over this block's tiles; otherwise one turn)
@@ -1357,15 +1415,26 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
   };
 
   unsigned seen = 0xffffffffu, seenp = 0xffffffffu;
-  // PERSIST, producers: the next tile of the walk -- its patch is requested in stage 0 and parked (with the validity flags)
-  // in stage 2: the patch and the flags are only read by conv1_1, which is behind stage 0's barrier
+  // PERSIST, producers: the next tile of the walk -- its patch is requested in stage 1 and parked (with the validity flags)
+  // in stage 3: the patch and the flags are only read by conv1_1 -- this tile's ended before stage 0, the next tile's starts
+  // behind the post-K barrier
   constexpr int NPF = (3 * PH * PW + 255) / 256;   // 5 patch values per producer thread
+  constexpr int NPF2 = (3 * PH * (PW / 2) + 255) / 256;   // 3 x-pairs per producer thread
+  static_assert(NPF2 == 3 && PW % 2 == 0, "stage 2's s_waitcnt vmcnt(3) counts the patch loads");
   const bool has_next = PERSIST && tile + gstride < ntiles;
-  TileGeo nxt = mem;
-  float pvn[NPF];
+  TileGeo nxt = nxt_pre;   // (decoded a tile ago by the producers, under stage 4: the decode is ~2 k cycles of dependent scalar loads,
+                           // and in stage 0 -- in front of the patch requests -- it held up the stage's barrier: 5.1 k cycles, not 2.7)
+  float pvn[2 * NPF2];
 #pragma unroll
   for (int st = 0; st < 6; ++st) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // producers: their share of W(st) has landed
+    // producers: their share of W(st) has landed.  (PERSIST, stage 2: the next tile's image patch was requested in stage 1
+    // AFTER W(2)'s pieces -- cold HBM reads, 2-4 k cycles; the counter retires in order, so "at most NPF outstanding" waits
+    // for the weights and lets the patch fly on until stage 3 parks it)
+#ifdef SHF_CONV_TIMING
+    if (st > 0) { asm volatile("s_nop 0" ::: "memory"); ts_own[st - 1] += __builtin_amdgcn_s_memtime() - tt[2 + st]; }
+#endif
+    if (PERSIST && st == 2) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     PC_T();
     if (consumer) {
@@ -1377,19 +1446,34 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
     } else {
       if (st + 1 < 6) dma_w(st + 1, (st + 1) & 1);
       if constexpr (PERSIST) {
+        // (measured, not kept: s_setprio 3 around these chores -- no change: what makes a producer's stage-1 work 4.3 k cycles
+        // is not issue arbitration but the patch loads queueing behind the stage's seven 1-KiB weight pieces)
         int lane_p = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));   // (not kept across the stages)
         asm volatile("" : "+v"(lane_p));
         const int ptid = (wave_u - 4) * 64 + lane_p;
-        if (st == 0 && has_next) {
-          nxt = decode(tile + gstride);
+        if (st == 4 && tile + 2 * gstride < ntiles) nxt_pre = p.pc_tab ? decode_tab(k_walk + 2) : decode(tile + 2 * gstride);
+        if (st == 1 && has_next) {   // (stage 1: the producers' lightest -- stage 0 carries the walk's bookkeeping)
+          // x-PAIRS of patch elements, one 8-byte load each (a load instruction costs a producer wave 100-200 cycles beside
+          // the consumers' stream: 12 wave-level loads instead of 20).  With an even level width a pair is inside or outside
+          // the image as a whole and 8-byte aligned: the patch starts at column tx0 - 2 (even).
 #pragma unroll
-          for (int k = 0; k < NPF; ++k) {
-            const int idx = ptid + 256 * k;
-            const int ci = (idx * 2622) >> 20, r = idx - ci * (PH * PW);
-            const int py = (r * 52429) >> 20, pxx = r - py * PW;
-            const int gy = nxt.ty0 - 2 + py, gx = nxt.tx0 - 2 + pxx;
-            const bool in = idx < 3 * PH * PW && (unsigned)gy < (unsigned)nxt.H && (unsigned)gx < (unsigned)nxt.W;
-            pvn[k] = in ? nxt.img[((size_t)ci * nxt.H + gy) * nxt.W + gx] : 0.f;
+          for (int k = 0; k < NPF2; ++k) {
+            const int pi = ptid + 256 * k;                       // pair index: row (ci, py) = pi / 10, column pair pi % 10
+            const int row = (pi * 6554) >> 16, c2 = pi - row * (PW / 2);
+            const int ci = (row * 3277) >> 16, py = row - ci * PH;
+            const int gy = nxt.ty0 - 2 + py, gx = nxt.tx0 - 2 + 2 * c2;
+            const bool in = pi < 3 * PH * (PW / 2) && (unsigned)gy < (unsigned)nxt.H && (unsigned)gx < (unsigned)nxt.W;
+            const unsigned off = (unsigned)((ci * nxt.H + gy) * nxt.W + gx);
+            const bool in1 = in && gx + 1 < nxt.W;
+            float2 v2 = make_float2(0.f, 0.f);
+            if (in1 && !(off & 1u)) {
+              v2 = *(const float2*)(nxt.img + off);
+            } else {   // (an odd level width -- never the detector's, whose levels are padded to multiples of 16: element by element)
+              if (in) v2.x = nxt.img[off];
+              if (in1) v2.y = nxt.img[off + 1];
+            }
+            pvn[2 * k] = v2.x;
+            pvn[2 * k + 1] = v2.y;
           }
         }
         if (st == 3 && has_next && ptid == 0) {   // (the previous tile's claims ended before stage 0; read behind the post-K barrier)
@@ -1405,12 +1489,12 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
           geoL[10] = (unsigned)q2; geoL[11] = (unsigned)(q2 >> 32); geoL[12] = (unsigned)q3; geoL[13] = (unsigned)(q3 >> 32);
           geoL[14] = (unsigned)q4; geoL[15] = (unsigned)(q4 >> 32);
         }
-        if (st == 2 && has_next) {
+        if (st == 3 && has_next) {
 #pragma unroll
-          for (int k = 0; k < NPF; ++k) {
-            const int idx = ptid + 256 * k;
-            if (idx < 3 * PH * PW) patch[idx] = patch_word(pvn[k]);
-            amax1 = conv_absmax_bits(amax1, pvn[k]);
+          for (int k = 0; k < NPF2; ++k) {
+            const int pi = ptid + 256 * k;
+            if (pi < 3 * PH * (PW / 2)) *(uint2*)(patch + 2 * pi) = make_uint2(patch_word(pvn[2 * k]), patch_word(pvn[2 * k + 1]));
+            amax1 = conv_absmax_bits(conv_absmax_bits(amax1, pvn[2 * k]), pvn[2 * k + 1]);
           }
 #pragma unroll
           for (int k = 0; k < (HPP + 255) / 256; ++k) {
@@ -1422,7 +1506,6 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
         }
         // (buffer 0 held stage 4's weights; every consumer is past them behind this stage's barrier)
         if (st == 5 && has_next) dma_w(0, 0);
-
       }
     }
   }
@@ -1541,6 +1624,7 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
     // previous tile's role end to this tile's first stage start (the wait for the other role)
     if (n_walk > 0) ts_tail += tt[3] - t_role_end;
     ts_k += tt[9] - tt[3];
+    for (int q = 0; q < 6; ++q) ts_st[q] += tt[4 + q] - tt[3 + q];
     ts_bar += t_barx - tt[9];
     ts_role += t_now - t_barx;
     t_role_end = t_now;
@@ -1551,6 +1635,7 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
   // the walk's next tile: its patch, flags and first weight stage are in flight or parked; conv1_1 may overwrite the halo
   // tiles once every consumer is out of the K loop (they are: the epilogue is behind it)
   tile += gstride;
+  ++k_walk;
   {
     auto rd = [&](int k) { return (unsigned)__builtin_amdgcn_readfirstlane((int)geoL[k]); };
     auto rd64 = [&](int k) { return (unsigned long long)rd(k) | ((unsigned long long)rd(k + 1) << 32); };
@@ -1570,9 +1655,12 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
   // tt: 0 entry, 1 patch requested + parked, 2 barrier, 3..8 the six stages' starts, 9 K loop done, (consumers: 10, 11 the
   // two cout halves stored,) last: flags published.  A first-round block (100) and two steady-state ones.
   if ((bid == 100 || bid == 9000 || bid == 20000) && lane == 0 && (wave == 0 || wave == 4))
-    printf("[pc] blk%d wave%d tiles %d | per tile: K loop %llu, wait at the post-K barrier %llu, role work (wave 0: epilogue, wave 4: next tile's conv1_1) %llu, wait for stage 0 %llu | last tile's stages %llu %llu %llu %llu %llu %llu\n",
+    printf("[pc-own] blk%d wave%d own work per stage (before its closing barrier) %llu %llu %llu %llu %llu\n", bid, wave,
+           ts_own[0] / n_walk, ts_own[1] / n_walk, ts_own[2] / n_walk, ts_own[3] / n_walk, ts_own[4] / n_walk);
+  if ((bid == 100 || bid == 9000 || bid == 20000) && lane == 0 && (wave == 0 || wave == 4))
+    printf("[pc] blk%d wave%d tiles %d | per tile: K loop %llu, wait at the post-K barrier %llu, role work (wave 0: epilogue, wave 4: next tile's conv1_1) %llu, wait for stage 0 %llu | mean stages %llu %llu %llu %llu %llu %llu\n",
            bid, wave, n_walk, ts_k / n_walk, ts_bar / n_walk, ts_role / n_walk,
-           n_walk > 1 ? ts_tail / (n_walk - 1) : 0ull, tt[4] - tt[3], tt[5] - tt[4], tt[6] - tt[5], tt[7] - tt[6], tt[8] - tt[7], tt[9] - tt[8]);
+           n_walk > 1 ? ts_tail / (n_walk - 1) : 0ull, ts_st[0] / n_walk, ts_st[1] / n_walk, ts_st[2] / n_walk, ts_st[3] / n_walk, ts_st[4] / n_walk, ts_st[5] / n_walk);
 #endif
 #undef PC_T
 }
@@ -1768,6 +1856,7 @@ static int launch_f16x3_t(const ConvArgs* as, int n, hipStream_t s) {
   p.tile_base = 0;
   p.ntile_blocks = 0;
   p.xcd_remap = knobs().xcd_remap;
+  p.pc_tab = 0;
   p.bias = a.bias;
   p.Cin = a.in.C; p.Cout = a.out.C;
   p.in_stride = a.in.cstride; p.out_stride = a.out.cstride;
@@ -1836,12 +1925,18 @@ static int launch_f16x3_t(const ConvArgs* as, int n, hipStream_t s) {
     constexpr size_t HPP = (HP + 31) / 32 * 32;
     // (+ conv1_1's weight fragments 8 KiB, its 64 biases, the row-tile counter: 162 512 B of the 160 KiB)
     const size_t lds_pc = 2 * (size_t)HP * ROWB + 2 * 3 * (size_t)BN * ROWB + (3 * (TH + 4) * (TW + 4) + 8) * sizeof(float) + HPP +
-                          BN * sizeof(float) + 8192 + 64 * sizeof(float) + 16 + 64;
+                          BN * sizeof(float) + 8192 + 64 * sizeof(float) + 16 + 64 + 300 * 4;
 if (lds_pc > 160 * 1024) { set_error("conv f16x3: the fused first pair does not fit the LDS"); return -1; }
     if (knobs().pc_persist) {
       // one block per CU walks the tiles (tile = block, block + grid, ...)
       p.ntile_blocks = (int)tiles;
       const dim3 gp((unsigned)std::min<long long>(tiles, knobs().cus));
+      {   // the per-block tile table: fits (300 tiles per block) and packs (image < 256, tile row / column < 1024)?
+        bool ok = (tiles + gp.x - 1) / gp.x <= 300;
+        for (int i = 0; i < n; ++i)
+          ok = ok && as[i].in.B <= 255 && p.m[i].tiles_x <= 1023 && p.m[i].tiles_per_img / std::max(1, p.m[i].tiles_x) <= 1023;
+        p.pc_tab = ok ? 1 : 0;
+      }
       if (a.bf16) hipLaunchKernelGGL((conv_mfma_f16x3_pc_kernel<1, true, true>), gp, dim3(512), lds_pc, s, p);
       else if (a.nprod >= 3) hipLaunchKernelGGL((conv_mfma_f16x3_pc_kernel<3, false, true>), gp, dim3(512), lds_pc, s, p);
       else if (a.nprod == 2) hipLaunchKernelGGL((conv_mfma_f16x3_pc_kernel<2, false, true>), gp, dim3(512), lds_pc, s, p);
