@@ -1416,25 +1416,22 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
 
   unsigned seen = 0xffffffffu, seenp = 0xffffffffu;
   // PERSIST, producers: the next tile of the walk -- its patch is requested in stage 1 and parked (with the validity flags)
-  // in stage 3: the patch and the flags are only read by conv1_1 -- this tile's ended before stage 0, the next tile's starts
+  // in stage 2: the patch and the flags are only read by conv1_1 -- this tile's ended before stage 0, the next tile's starts
   // behind the post-K barrier
-  constexpr int NPF = (3 * PH * PW + 255) / 256;   // 5 patch values per producer thread
   constexpr int NPF2 = (3 * PH * (PW / 2) + 255) / 256;   // 3 x-pairs per producer thread
-  static_assert(NPF2 == 3 && PW % 2 == 0, "stage 2's s_waitcnt vmcnt(3) counts the patch loads");
+  static_assert(PW % 2 == 0, "x-pairs");
   const bool has_next = PERSIST && tile + gstride < ntiles;
   TileGeo nxt = nxt_pre;   // (decoded a tile ago by the producers, under stage 4: the decode is ~2 k cycles of dependent scalar loads,
                            // and in stage 0 -- in front of the patch requests -- it held up the stage's barrier: 5.1 k cycles, not 2.7)
   float pvn[2 * NPF2];
 #pragma unroll
   for (int st = 0; st < 6; ++st) {
-    // producers: their share of W(st) has landed.  (PERSIST, stage 2: the next tile's image patch was requested in stage 1
-    // AFTER W(2)'s pieces -- cold HBM reads, 2-4 k cycles; the counter retires in order, so "at most NPF outstanding" waits
-    // for the weights and lets the patch fly on until stage 3 parks it)
+    // producers: their share of W(st) has landed (PERSIST, stage 2: and the next tile's image patch, requested in stage 1
+    // in front of W(2)'s pieces)
 #ifdef SHF_CONV_TIMING
     if (st > 0) { asm volatile("s_nop 0" ::: "memory"); ts_own[st - 1] += __builtin_amdgcn_s_memtime() - tt[2 + st]; }
 #endif
-    if (PERSIST && st == 2) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     PC_T();
     if (consumer) {
@@ -1444,10 +1441,10 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
       }
       mma_stage(st < 3 ? As0 : As1, st % 3, st & 1);
     } else {
-      if (st + 1 < 6) dma_w(st + 1, (st + 1) & 1);
+      if (!(PERSIST && st == 1) && st + 1 < 6) dma_w(st + 1, (st + 1) & 1);   // (stage 1: behind the patch requests, below)
       if constexpr (PERSIST) {
-        // (measured, not kept: s_setprio 3 around these chores -- no change: what makes a producer's stage-1 work 4.3 k cycles
-        // is not issue arbitration but the patch loads queueing behind the stage's seven 1-KiB weight pieces)
+        // (measured, not kept: s_setprio 3 around these chores -- no change: what made a producer's stage-1 work 4.3 k cycles
+        // was not issue arbitration but the patch loads queueing behind the stage's seven 1-KiB weight pieces)
         int lane_p = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));   // (not kept across the stages)
         asm volatile("" : "+v"(lane_p));
         const int ptid = (wave_u - 4) * 64 + lane_p;
@@ -1476,6 +1473,9 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
             pvn[2 * k + 1] = v2.y;
           }
         }
+        // (the patch requests go out FIRST in their stage: issued behind the stage's seven 1-KiB weight pieces they queued for
+        // 2-3 k cycles with the wave stuck at the issue -- a stage 1 of 4.3 k cycles instead of 3.7; 2.7 is the consumers')
+        if (st == 1) dma_w(2, 0);
         if (st == 3 && has_next && ptid == 0) {   // (the previous tile's claims ended before stage 0; read behind the post-K barrier)
           ctrL[0] = 0u;
           ctrL[1] = (nxt.ty0 >= 1 && nxt.tx0 >= 1 && nxt.ty0 + TH < nxt.H && nxt.tx0 + TW < nxt.W) ? 1u : 0u;
@@ -1489,7 +1489,7 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
           geoL[10] = (unsigned)q2; geoL[11] = (unsigned)(q2 >> 32); geoL[12] = (unsigned)q3; geoL[13] = (unsigned)(q3 >> 32);
           geoL[14] = (unsigned)q4; geoL[15] = (unsigned)(q4 >> 32);
         }
-        if (st == 3 && has_next) {
+        if (st == 2 && has_next) {   // (stage 2: the producers' lightest; the loads were waited for at its top)
 #pragma unroll
           for (int k = 0; k < NPF2; ++k) {
             const int pi = ptid + 256 * k;
