@@ -27,7 +27,8 @@ SOURCES = [
     ("calib.hip", []),
     ("net.cpp", []),
 ]
-HEADERS = ["shf_internal.h", "conv_common.h", "proto_text.h", os.path.join("..", "..", "include", "shf_hip.h")]
+HEADERS = ["shf_internal.h", "conv_common.h", "conv_f16x3_types.h", "conv_f16x3_8w.h", "conv_f16x3_w4d.h", "conv_f16x3_pc.h",
+           "proto_text.h", os.path.join("..", "..", "include", "shf_hip.h")]
 
 
 def _newer(target, deps):

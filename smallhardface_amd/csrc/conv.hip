@@ -406,7 +406,7 @@ static int launch_mfma_t(const ConvArgs* as, int n, hipStream_t s) {
   p.wscale_inv = 1.f;
   p.tile_base = 0;
   p.ntile_blocks = 0;
-  p.xcd_remap = 0;
+  p.pc_tab = 0;
   long long tiles = 0;
   for (int i = 0; i < n; ++i) {
     const ConvArgs& q = as[i];

@@ -40,8 +40,6 @@ struct ConvK {
   int nct, nmem;
   int ntile_blocks;  // persistent / dual-tile kernels: (pixel tiles of the group this launch ends at) x cout tiles
   int tile_base;     // dual-tile kernels: first pixel tile of this launch (a group may be covered by two launches)
-  int xcd_remap;     // dual-tile kernels: 1 = block b works on virtual block start(b % 8) + b / 8, so that the blocks an XCD
-                     // (b % 8) receives are CONSECUTIVE virtual blocks: all cout tiles of a pixel tile share one XCD's L2
   int pc_tab;        // fused first pair, persistent form: 1 = every block keeps the packed geometry of the tiles it walks in LDS
                      // (member 4 bits | image 8 | tile row 10 | tile column 10), decoded once by all its lanes in parallel
   const float* w1t;  // FUSE1: first-layer weights transposed to [27][64]

@@ -444,12 +444,7 @@ struct NetShared {
   // image pipeline (shf_net_set_pipeline): ONE in-order stream carries the convolutions + logits kernels of every
   // image; each head's own (high-priority) stream carries the rest of its image's tails, appends and the merge
   hipStream_t conv_stream = nullptr;
-  hipStream_t side_stream = nullptr;  // an independent branch of the graph beside the main chain (add_levels)
   ~NetShared() {
-    if (side_stream) {
-      (void)hipStreamSynchronize(side_stream);
-      (void)hipStreamDestroy(side_stream);
-    }
     if (conv_stream) {
       (void)hipStreamSynchronize(conv_stream);
       (void)hipStreamDestroy(conv_stream);
@@ -490,7 +485,7 @@ struct shf_net {
   shf_net* clone_src = nullptr;     // lanes share the parameter tensors of the net they were cloned from
   std::shared_ptr<int> wgen = std::make_shared<int>(0);  // bumped by every param commit
   int tail_gen = -1;
-  hipEvent_t ev_mark = nullptr, ev_side_a = nullptr, ev_side_b = nullptr;
+  hipEvent_t ev_mark = nullptr;
   hipEvent_t ev_logits = nullptr;  // recorded by every fused tail pass right after its logits kernel
   hipEvent_t logits_done = nullptr;  // (not owned) what a later pass over this member waits for: its own ev_logits, or --
                                      // after a pipelined grouped pass -- the head's ev_convs (ONE record for the group:
@@ -529,8 +524,6 @@ struct shf_net {
     if (ev_logits) (void)hipEventDestroy(ev_logits);
     if (ev_convs) (void)hipEventDestroy(ev_convs);
     if (ev_mark) (void)hipEventDestroy(ev_mark);
-    if (ev_side_a) (void)hipEventDestroy(ev_side_a);
-    if (ev_side_b) (void)hipEventDestroy(ev_side_b);
     if (stream) {
       (void)hipStreamSynchronize(stream);
       (void)hipStreamDestroy(stream);
@@ -1890,53 +1883,12 @@ int shf_detect_add_levels(shf_net* net, int n, shf_net** members, const float* c
       CHECK_RC(launch_conv_mfma_group(group.data(), n, st));
     }
   };
-  // side-stream candidate: a grouped 1x1 conv whose input was produced at least two grouped 3x3 convs earlier
-  int side_j = -1, side_e = -1;
-  // (measured +0.3 % images/s, inside the noise: the 1x1 branch only moves into CUs the conv5_x launches then run
-  // slower on -- off unless SHF_SIDE_STREAM=1)
-  static const bool side_on = getenv("SHF_SIDE_STREAM") && atoi(getenv("SHF_SIDE_STREAM")) != 0;
-  if (side_on && n > 1) {
-    for (size_t j = 0; j < net->layers.size() && side_j < 0; ++j) {
-      Layer& J = net->layers[j];
-      if (J.op != OP_CONV || J.kclass != 0 || J.k != 1) continue;
-      int pidx = -1;
-      for (size_t q = 0; q < j; ++q)
-        for (int t : net->layers[q].tops)
-          if (t == J.bottoms[0]) pidx = (int)q;
-      if (pidx < 0) continue;
-      int first = -1, big = 0;
-      for (size_t q = pidx + 1; q < j; ++q) {
-        Layer& Q = net->layers[q];
-        if (Q.op == OP_CONV && Q.kclass == 0) {
-          if (first < 0) first = (int)q;
-          big += Q.k == 3 ? 1 : 0;
-        }
-      }
-      if (big >= 2) { side_j = (int)j; side_e = first; }
-    }
-    if (side_j >= 0 && !net->sh->side_stream)
-      HIP_THROW(hipStreamCreateWithFlags(&net->sh->side_stream, hipStreamNonBlocking));
-  }
   for (size_t li = 0; li < net->layers.size(); ++li) {
     Layer& L = net->layers[li];
     if (early_start && (int)li == first_feat_writer)
       for (int m = 0; m < n; ++m)
         if (members[m]->logits_done) HIP_THROW(hipStreamWaitEvent(net->stream, members[m]->logits_done, 0));
     if (L.op == OP_SKIP) continue;
-    if (side_j >= 0 && (int)li == side_e) {
-      // an independent 1x1 branch (conv4_256 reads conv4_3, nothing before conv4_fuse needs it): on a side stream,
-      // beside the conv5_x launches whose last round leaves most CUs idle
-      if (!net->ev_side_a) HIP_THROW(hipEventCreateWithFlags(&net->ev_side_a, hipEventDisableTiming));
-      if (!net->ev_side_b) HIP_THROW(hipEventCreateWithFlags(&net->ev_side_b, hipEventDisableTiming));
-      HIP_THROW(hipEventRecord(net->ev_side_a, cs));
-      HIP_THROW(hipStreamWaitEvent(net->sh->side_stream, net->ev_side_a, 0));
-      launch_group_conv((size_t)side_j, net->sh->side_stream);
-      HIP_THROW(hipEventRecord(net->ev_side_b, net->sh->side_stream));
-    }
-    if (side_j >= 0 && (int)li == side_j) {
-      HIP_THROW(hipStreamWaitEvent(cs, net->ev_side_b, 0));
-      continue;
-    }
     if (L.op == OP_CONV && L.kclass == 0) {
       launch_group_conv(li, cs);
     } else if (L.op == OP_DECONV && n > 1) {

@@ -244,20 +244,15 @@ class FusedDetector(object):
         same stream: DevicePyramid.units(im, net=fd.next_head()))."""
         if not hasattr(self, "_heads"):
             self._heads = [self.net.clone(), self.net.clone()]
-            # SHF_PIPE_OVERLAP=1 (experiment): each head owns a full lane set, so the two images in flight share no
-            # buffers and their kernels are free to overlap (tail rounds of one grid filled by the other image's
-            # blocks); default: one lane set, image k+1's convolutions queue behind image k's
-            self._overlap = os.environ.get("SHF_PIPE_OVERLAP", "0") == "1"
-            if self._overlap:
-                self._lane_sets = [self.lanes, [self.net.clone() for _ in self.lanes]]
-            else:
-                self._heads[0].set_predecessor(self._heads[1])
-                self._heads[1].set_predecessor(self._heads[0])
-                if os.environ.get("SHF_PIPE_SHARED_CONV_STREAM", "1") != "0":
-                    # convolutions of consecutive images on one in-order stream, tails + merge on the heads' own
-                    # high-priority streams: does not depend on how the runtime maps streams to hardware queues
-                    for h in self._heads:
-                        h.set_pipeline(True)
+            # one lane set: image k + 1's convolutions queue behind image k's (both images' convolutions overlapped on two
+            # lane sets measured +3 % images/s in round 2, but then no kernel's duration is its own: removed in round 4)
+            self._heads[0].set_predecessor(self._heads[1])
+            self._heads[1].set_predecessor(self._heads[0])
+            if os.environ.get("SHF_PIPE_SHARED_CONV_STREAM", "1") != "0":
+                # convolutions of consecutive images on one in-order stream, tails + merge on the heads' own
+                # high-priority streams: does not depend on how the runtime maps streams to hardware queues
+                for h in self._heads:
+                    h.set_pipeline(True)
             self._turn = 0
             self._inflight = []
         return self._heads[self._turn]
@@ -285,7 +280,7 @@ class FusedDetector(object):
         units = list(units)
         assert self.mode == "group" and len(units) <= 16
         head = self.next_head()
-        lanes = self._lane_sets[self._turn] if self._overlap else self.lanes
+        lanes = self.lanes
         while len(lanes) < len(units):
             lanes.append(self.net.clone())
         head.detect_begin()
