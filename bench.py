@@ -46,7 +46,7 @@ def build_units(image_index, src_hw=(SRC_H, SRC_W)):
     return list(pyramid_units(im))
 
 
-PMC_FILE = "profiles/r03_pmc.json"   # written by tools/make_profiles.sh (separate rocprofv3 --pmc passes of this command)
+PMC_FILE = "profiles/r04_pmc.json"   # written by tools/make_profiles.sh (separate rocprofv3 --pmc passes of this command)
 
 
 def committed_pmc(kernel_name):
