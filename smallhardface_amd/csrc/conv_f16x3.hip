@@ -118,6 +118,7 @@ struct Knobs {
   int w4_mode;         // SHF_F16X3_W4: -1 auto (Cin >= 64), 0 never, 1 always -- which layers take the 4-wave dual-tile family
   int w4_mt;           // SHF_F16X3_W4_MT: 0 auto, 2 / 4 force 8- / 16-row tiles
   int w4d_ntile;       // SHF_F16X3_W4D_NTILE: 0 auto (hybrid launches), 1 / 2 force single- / two-tile blocks
+  int dil_w4;          // SHF_F16X3_DIL_W4: 1 (default) = the dilated heads on the dual-tile family's DIL form, 0 = the 8-wave kernel
   bool pc, dilated, k1, scalar_epilogue;   // SHF_F16X3_PC, SHF_F16X3_DILATED, SHF_F16X3_1X1 (default on), SHF_CONV_SCALAR_EPILOGUE (off)
   bool pc_persist;     // SHF_F16X3_PC_PERSIST (default on): the fused first pair as one block per CU walking the tiles
   int cus;
@@ -129,6 +130,7 @@ const Knobs& knobs() {
     q.w4_mode = env_int("SHF_F16X3_W4", -1);
     q.w4_mt = env_int("SHF_F16X3_W4_MT", 0);
     q.w4d_ntile = env_int("SHF_F16X3_W4D_NTILE", 0);
+    q.dil_w4 = env_int("SHF_F16X3_DIL_W4", 1);
     q.pc = env_int("SHF_F16X3_PC", 1) != 0;
     q.pc_persist = env_int("SHF_F16X3_PC_PERSIST", 1) != 0;
     q.dilated = env_int("SHF_F16X3_DILATED", 1) != 0;
@@ -158,6 +160,17 @@ bool views_aligned(const ConvArgs* as, int n) {
 // unaligned views (scalar epilogue), take the 8-wave kernel.
 bool conv_f16x3_group_is_dual(const ConvArgs* as, int n) {
   if (!as[0].wsplit16h || as[0].img || as[0].k != 3 || as[0].dil != 1 || as[0].out.C % 128) return false;
+  if (!conv_f16x3_uses_w4(as[0].in.C) || knobs().scalar_epilogue || !views_aligned(as, n)) return false;
+  for (int i = 0; i < n; ++i)
+    if ((unsigned long long)as[i].in.B * as[i].in.H * as[i].in.W * as[i].in.cstride * 4ull >= (1ull << 32)) return false;
+  return true;
+}
+
+// the dilated shared-weight heads (dilation 2 / 4) on the family's DIL form: the same conditions but for the dilation
+bool conv_f16x3_dilated_uses_w4() { return knobs().dil_w4 != 0 && knobs().dilated; }
+bool conv_f16x3_group_is_dilated_w4(const ConvArgs* as, int n) {
+  if (!conv_f16x3_dilated_uses_w4() || !as[0].wsplit16h || as[0].img || as[0].k != 3 || (as[0].dil != 2 && as[0].dil != 4) || as[0].out.C % 128)
+    return false;
   if (!conv_f16x3_uses_w4(as[0].in.C) || knobs().scalar_epilogue || !views_aligned(as, n)) return false;
   for (int i = 0; i < n; ++i)
     if ((unsigned long long)as[i].in.B * as[i].in.H * as[i].in.W * as[i].in.cstride * 4ull >= (1ull << 32)) return false;
@@ -319,6 +332,27 @@ if (lds_pc > 160 * 1024) { set_error("conv f16x3: the fused first pair does not 
     else if (a.nprod >= 3) hipLaunchKernelGGL(conv_mfma_f16x3_pc_kernel<3>, dim3((unsigned)tiles), dim3(512), lds_pc, s, p);
     else if (a.nprod == 2) hipLaunchKernelGGL(conv_mfma_f16x3_pc_kernel<2>, dim3((unsigned)tiles), dim3(512), lds_pc, s, p);
     else hipLaunchKernelGGL(conv_mfma_f16x3_pc_kernel<1>, dim3((unsigned)tiles), dim3(512), lds_pc, s, p);
+  } else if (BN == 128 && !FUSE1 && KS == 3 && DIL > 1 && conv_f16x3_group_is_dilated_w4(as, n)) {
+    // the dilated heads on the family's DIL form: single 16-row tiles (halo tiles of (16 + 2 DIL)^2 pixels, two buffer sets)
+    if constexpr (BN == 128 && !FUSE1 && KS == 3 && (DIL == 2 || DIL == 4)) {
+      p.wph = a.wsplit16h;
+      p.wscale_inv = a.wscale_inv;
+      p.tile_base = 0;
+      p.ntile_blocks = (int)(tiles * p.nct);
+      const size_t as_b = 4 * ((size_t)(16 + 2 * DIL) * 24 * 16 + 32);
+      const size_t ldsd = 2 * as_b + 2 * 3 * (size_t)BN * 64 + BN * sizeof(float);
+      const dim3 gd((unsigned)(tiles * p.nct));
+#define SHF_W4D_DIL(SPLIT)                                                                                                    \
+      {                                                                                                                      \
+        if (a.bf16) hipLaunchKernelGGL((conv_mfma_f16x3_w4d_kernel<false, 4, 1, 1, true, DIL>), gd, dim3(256), ldsd, s, p);     \
+        else if (a.nprod >= 3) hipLaunchKernelGGL((conv_mfma_f16x3_w4d_kernel<SPLIT, 4, 1, 3, false, DIL>), gd, dim3(256), ldsd, s, p); \
+        else if (a.nprod == 2) hipLaunchKernelGGL((conv_mfma_f16x3_w4d_kernel<SPLIT, 4, 1, 2, false, DIL>), gd, dim3(256), ldsd, s, p); \
+        else hipLaunchKernelGGL((conv_mfma_f16x3_w4d_kernel<SPLIT, 4, 1, 1, false, DIL>), gd, dim3(256), ldsd, s, p);            \
+      }
+      if (a.in_split) SHF_W4D_DIL(true)
+      else SHF_W4D_DIL(false)
+#undef SHF_W4D_DIL
+    }
   } else if (dual) {
     // dual-tile family (conv_mfma_f16x3_w4d_kernel<.., MT, NTILE, ..>): every variant forms an output with the same
     // operations in the same order, so the choice below -- two tiles per block where that fills whole rounds of one
@@ -428,6 +462,13 @@ int conv_f16x3_init_attributes() {
   SHF_W4D_ATTR(false, 4, 2) SHF_W4D_ATTR(true, 4, 2) SHF_W4D_ATTR(false, 4, 1) SHF_W4D_ATTR(true, 4, 1)
   SHF_W4D_ATTR(false, 2, 2) SHF_W4D_ATTR(true, 2, 2) SHF_W4D_ATTR(false, 2, 1) SHF_W4D_ATTR(true, 2, 1)
 #undef SHF_W4D_ATTR
+#define SHF_W4D_DIL_ATTR(DILV)                                                                                                  \
+  SHF_LDS_ATTR((conv_mfma_f16x3_w4d_kernel<false, 4, 1, 3, false, DILV>)) SHF_LDS_ATTR((conv_mfma_f16x3_w4d_kernel<true, 4, 1, 3, false, DILV>)) \
+  SHF_LDS_ATTR((conv_mfma_f16x3_w4d_kernel<false, 4, 1, 2, false, DILV>)) SHF_LDS_ATTR((conv_mfma_f16x3_w4d_kernel<true, 4, 1, 2, false, DILV>)) \
+  SHF_LDS_ATTR((conv_mfma_f16x3_w4d_kernel<false, 4, 1, 1, false, DILV>)) SHF_LDS_ATTR((conv_mfma_f16x3_w4d_kernel<true, 4, 1, 1, false, DILV>)) \
+  SHF_LDS_ATTR((conv_mfma_f16x3_w4d_kernel<false, 4, 1, 1, true, DILV>))
+  SHF_W4D_DIL_ATTR(2) SHF_W4D_DIL_ATTR(4)
+#undef SHF_W4D_DIL_ATTR
   SHF_LDS_ATTR((conv_mfma_f16x3_w4d_kernel<false, 4, 2, 1, true>)) SHF_LDS_ATTR((conv_mfma_f16x3_w4d_kernel<false, 4, 1, 1, true>))
   SHF_LDS_ATTR((conv_mfma_f16x3_w4d_kernel<false, 2, 2, 1, true>)) SHF_LDS_ATTR((conv_mfma_f16x3_w4d_kernel<false, 2, 1, 1, true>))
 #undef SHF_LDS_ATTR
@@ -445,8 +486,8 @@ int launch_conv_f16x3_group(const ConvArgs* as, int n, hipStream_t s) {
   }
   if (as[0].k == 1)
     return (as[0].out.C % 128 == 0) ? launch_f16x3_t<128, false, 1, 1>(as, n, s) : launch_f16x3_t<64, false, 1, 1>(as, n, s);
-  if (as[0].dil == 2) return launch_f16x3_t<64, false, 2>(as, n, s);
-  if (as[0].dil == 4) return launch_f16x3_t<64, false, 4>(as, n, s);
+  if (as[0].dil == 2) return conv_f16x3_group_is_dilated_w4(as, n) ? launch_f16x3_t<128, false, 2>(as, n, s) : launch_f16x3_t<64, false, 2>(as, n, s);
+  if (as[0].dil == 4) return conv_f16x3_group_is_dilated_w4(as, n) ? launch_f16x3_t<128, false, 4>(as, n, s) : launch_f16x3_t<64, false, 4>(as, n, s);
   return (as[0].out.C % 128 == 0) ? launch_f16x3_t<128, false>(as, n, s) : launch_f16x3_t<64, false>(as, n, s);
 }
 

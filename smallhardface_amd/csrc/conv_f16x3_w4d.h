@@ -31,11 +31,17 @@ namespace shf {
 // rows a ds_read_b128 lane group touches land on complementary halves of the 256-B bank row), planes 32 B apart
 // mod 128 (the 8-lane groups of the parking ds_write_b128 -- 2 pixels x 4 planes -- cover all 32 banks).  Every
 // fragment address is lane offset + immediate: tap kx = +16 B, kernel row = +384 B, lo = +2 planes.
-template <bool IN_SPLIT, int MT_, int NTILE, int NP = 3, bool BF = false>
+// DIL (round 4): the dilated shared-weight heads (dilation 2 / 4, Cin = Cout = 128) run here too, as single 16-row tiles:
+// the halo tile is (16 + 2 DIL)^2 pixels -- 20 or 24 per row, inside the 24-pixel plane rows --, a tap is DIL pixels / DIL
+// plane rows further, nothing else changes (111 / 123 KB of LDS).  They used to take the 8-wave kernel's 64-cout form (a
+// fragment read per MFMA: 0.29 issued).
+template <bool IN_SPLIT, int MT_, int NTILE, int NP = 3, bool BF = false, int DIL = 1>
 __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4d_kernel(ConvK p) {
   static_assert(!BF || (NP == 1 && !IN_SPLIT), "bf16 mode: one product, fp32 activations in HBM");
   static_assert((MT_ == 4 || MT_ == 2) && (NTILE == 1 || NTILE == 2), "16- or 8-row tiles, one or two per block");
-  constexpr int MT = MT_, TH = 4 * MT, TW = 16, HTW = 18, HTH = TH + 2, HP = HTH * HTW;
+  static_assert(DIL == 1 || ((DIL == 2 || DIL == 4) && MT_ == 4 && NTILE == 1), "dilated layers: single 16-row tiles");
+  constexpr int MT = MT_, TH = 4 * MT, TW = 16, HTW = TW + 2 * DIL, HTH = TH + 2 * DIL, HP = HTH * HTW;
+  constexpr int UNUSED = 24 - HTW;                    // plane-row pixels no halo pixel uses (they take the ragged last piece)
   constexpr int KC = 16, BN = 128, NT = 256;
   constexpr int PROW = 24 * 16;                       // 384 B per halo-tile row of a plane (18 pixels used)
   constexpr int PLANE = HTH * PROW + 32;              // 6 944 B (16-row tiles) / 3 872 B (8-row tiles)
@@ -129,7 +135,7 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4d_kernel(ConvK p) {
       const int idx = tid + NT * j;
       const int hp = idx >> 2, q = idx & 3;
       const int hy = hp / HTW, hx = hp - hy * HTW;
-      const int gy = g.ty0 - 1 + hy, gx = g.tx0 - 1 + hx;
+      const int gy = g.ty0 - DIL + hy, gx = g.tx0 - DIL + hx;
       const bool in = exists && (idx < HP * 4) && ((unsigned)gy < (unsigned)g.H) && ((unsigned)gx < (unsigned)g.W);
       const unsigned pix = (unsigned)(((g.b * g.H + gy) * g.W + gx) * in_stride_v) * 4u;
       a_goff[t][j] = in ? pix + (IN_SPLIT ? (unsigned)((q >> 1) * 64 + (q & 1) * 16) : (unsigned)(q * 16)) : 0u;
@@ -199,13 +205,18 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4d_kernel(ConvK p) {
     const int idx = tid + NT * j;
     const int hp = idx >> 2, q = idx & 3;
     int hy = hp / HTW, hx = hp - hy * HTW;
-    if (NT * (j + 1) > HP * 4) {
-      // the ragged last piece: threads past the tile's end store theirs in the unused columns 18..23 of the first rows
-      // (no branch inside the stage -- it would split the scheduling region)
-      const int hpd = hp - HP, ry = hpd / 6;
-      const bool past = idx >= HP * 4;
-      hy = past ? ry : hy;
-      hx = past ? HTW + hpd - ry * 6 : hx;
+    if constexpr (UNUSED > 0) {
+      if (NT * (j + 1) > HP * 4) {
+        // the ragged last piece: threads past the tile's end store theirs in the unused columns (18..23 at dilation 1) of
+        // the first rows (no branch inside the stage -- it would split the scheduling region)
+        static_assert((ALD * NT - HP * 4 + 3) / 4 <= (UNUSED > 0 ? UNUSED : 1) * HTH, "the ragged piece's parking columns");
+        const int hpd = hp - HP, ry = hpd / (UNUSED > 0 ? UNUSED : 1);
+        const bool past = idx >= HP * 4;
+        hy = past ? ry : hy;
+        hx = past ? HTW + hpd - ry * UNUSED : hx;
+      }
+    } else {
+      static_assert(UNUSED > 0 || (HP * 4) % NT == 0, "a full 24-pixel halo row leaves no parking column: no ragged piece allowed");
     }
     unsigned char* pix = As + set_off + t * AS_B + hy * PROW + hx * 16;
     if constexpr (IN_SPLIT) {
@@ -275,7 +286,7 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4d_kernel(ConvK p) {
     const unsigned char* Bst = Bs + (st & 1) * (3 * SLAB_B);
     half8 fa[2][2 * MT], fb[2][4];
     auto load_a = [&](int h, half8* a) {              // half-step h = NTILE kx + tile
-      const unsigned char* Ap = As + (h % NTILE) * AS_B + ky * PROW + (h / NTILE) * 16;
+      const unsigned char* Ap = As + (h % NTILE) * AS_B + ky * DIL * PROW + (h / NTILE) * DIL * 16;
 #pragma unroll
       for (int t = 0; t < MT; ++t) {
         a[2 * t] = *(const half8*)(Ap + a_off[t]);

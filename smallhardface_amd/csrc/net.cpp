@@ -171,11 +171,11 @@ static const char* kProfNames[PC_COUNT] = {"conv_mfma_f32_kernel<3, 1, 128, 8, 1
                                            "conv_mfma_f16x3_kernel<64, true, 1, 3, 3, false>", "conv_mfma_f16x3_kernel<64, false, 2, 3, 3, false>",
                                            "conv_mfma_f16x3_kernel<64, false, 4, 3, 3, false>", "conv_mfma_f16x3_kernel<128, false, 1, 1, 3, false>",
                                            "conv_mfma_f16x3_kernel<64, false, 1, 1, 3, false>", "conv_mfma_f16x3_pc_kernel<3, false, false>",
-                                           // dual-tile family <IN_SPLIT, rows / 4, tiles per block, products>: index = in_split * 4 + (rows == 8) * 2 + (tiles == 1)
-                                           "conv_mfma_f16x3_w4d_kernel<false, 4, 2, 3, false>", "conv_mfma_f16x3_w4d_kernel<false, 4, 1, 3, false>",
-                                           "conv_mfma_f16x3_w4d_kernel<false, 2, 2, 3, false>", "conv_mfma_f16x3_w4d_kernel<false, 2, 1, 3, false>",
-                                           "conv_mfma_f16x3_w4d_kernel<true, 4, 2, 3, false>", "conv_mfma_f16x3_w4d_kernel<true, 4, 1, 3, false>",
-                                           "conv_mfma_f16x3_w4d_kernel<true, 2, 2, 3, false>", "conv_mfma_f16x3_w4d_kernel<true, 2, 1, 3, false>",
+                                           // dual-tile family <IN_SPLIT, rows / 4, tiles per block, products, bf16, dilation>: index = in_split * 4 + (rows == 8) * 2 + (tiles == 1)
+                                           "conv_mfma_f16x3_w4d_kernel<false, 4, 2, 3, false, 1>", "conv_mfma_f16x3_w4d_kernel<false, 4, 1, 3, false, 1>",
+                                           "conv_mfma_f16x3_w4d_kernel<false, 2, 2, 3, false, 1>", "conv_mfma_f16x3_w4d_kernel<false, 2, 1, 3, false, 1>",
+                                           "conv_mfma_f16x3_w4d_kernel<true, 4, 2, 3, false, 1>", "conv_mfma_f16x3_w4d_kernel<true, 4, 1, 3, false, 1>",
+                                           "conv_mfma_f16x3_w4d_kernel<true, 2, 2, 3, false, 1>", "conv_mfma_f16x3_w4d_kernel<true, 2, 1, 3, false, 1>",
                                            "conv_first_kernel", "conv_direct_kernel", "maxpool_kernel",
                                            "deconv_depthwise", "detect_tail", "box_merge", "layout"};
 
@@ -897,7 +897,8 @@ void shf_net::build(const std::string& text, const char* caffemodel) {
   {
     static const bool split_act = !(getenv("SHF_F16X3_SPLIT_ACT") && atoi(getenv("SHF_F16X3_SPLIT_ACT")) == 0);
     auto w4_reader = [&](const Layer& Q, int cin) {
-      return Q.op == OP_CONV && Q.kclass == 0 && Q.k == 3 && Q.dil == 1 && Q.pad == 1 && cin % 32 == 0 && Q.nout % 128 == 0 &&
+      const bool dil_ok = Q.dil == 1 || ((Q.dil == 2 || Q.dil == 4) && conv_f16x3_dilated_uses_w4());   // (the heads: family's DIL form)
+      return Q.op == OP_CONV && Q.kclass == 0 && Q.k == 3 && dil_ok && Q.pad == Q.dil && cin % 32 == 0 && Q.nout % 128 == 0 &&
              Q.first_src < 0 && conv_f16x3_uses_w4(cin) && conv_f16x3_eligible(cin, Q.nout, Q.k, Q.pad, Q.dil);
     };
     for (size_t bi = 0; bi < blobs.size() && split_act; ++bi) {
@@ -1117,7 +1118,7 @@ void shf_net::commit_params(int li) {
         pack_conv_weights_split16(p.host.data(), p.shape[0], p.shape[1], p.shape[2], sp.data(), true);
         p.packed16b.ensure(sp.size() * 2);
         HIP_THROW(hipMemcpy(p.packed16b.p, sp.data(), sp.size() * 2, hipMemcpyHostToDevice));
-        if (L.k == 3 && L.dil == 1 && conv_f16x3_uses_w4(p.shape[1]) && p.shape[0] % 128 == 0 && p.shape[1] % 32 == 0) {
+        if (L.k == 3 && (L.dil == 1 || ((L.dil == 2 || L.dil == 4) && conv_f16x3_dilated_uses_w4())) && conv_f16x3_uses_w4(p.shape[1]) && p.shape[0] % 128 == 0 && p.shape[1] % 32 == 0) {
           std::vector<uint16_t> sh(split16h_conv_weight_halfs(p.shape[0], p.shape[1], p.shape[2]));
           pack_conv_weights_split16h(p.host.data(), p.shape[0], p.shape[1], p.shape[2], sh.data(), true);
           p.packed16hb.ensure(sh.size() * 2);
@@ -1137,7 +1138,7 @@ void shf_net::commit_params(int li) {
         p.packed16.ensure(sp.size() * 2);
         HIP_THROW(hipMemcpy(p.packed16.p, sp.data(), sp.size() * 2, hipMemcpyHostToDevice));
         p.split_stale = false;
-        if (L.k == 3 && L.dil == 1 && conv_f16x3_uses_w4(p.shape[1]) && p.shape[0] % 128 == 0 &&
+        if (L.k == 3 && (L.dil == 1 || ((L.dil == 2 || L.dil == 4) && conv_f16x3_dilated_uses_w4())) && conv_f16x3_uses_w4(p.shape[1]) && p.shape[0] % 128 == 0 &&
             p.shape[1] % 32 == 0) {
           std::vector<uint16_t> sh(split16h_conv_weight_halfs(p.shape[0], p.shape[1], p.shape[2]));
           p.wscale_inv = pack_conv_weights_split16h(p.host.data(), p.shape[0], p.shape[1], p.shape[2], sh.data());
@@ -2282,6 +2283,8 @@ int shf_prof_only(shf_net* net, int cls) {
 int shf_prof_num_classes(shf_net*) { return PC_COUNT; }
 const char* shf_prof_class_name(shf_net*, int cls) {
   if (cls == PC_CONV_F16X3_PC && shf::conv_f16x3_pc_persistent()) return "conv_mfma_f16x3_pc_kernel<3, false, true>";
+  if (cls == PC_CONV_F16X3_64_D2 && shf::conv_f16x3_dilated_uses_w4()) return "conv_mfma_f16x3_w4d_kernel<true, 4, 1, 3, false, 2>";
+  if (cls == PC_CONV_F16X3_64_D4 && shf::conv_f16x3_dilated_uses_w4()) return "conv_mfma_f16x3_w4d_kernel<true, 4, 1, 3, false, 4>";
   return (cls >= 0 && cls < PC_COUNT) ? kProfNames[cls] : nullptr;
 }
 int shf_prof_read(shf_net* net, int cls, int64_t* launches, double* total_ms, double* flops, double* bytes) {

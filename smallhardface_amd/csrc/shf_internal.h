@@ -82,6 +82,8 @@ size_t split16_conv_weight_halfs(int Cout, int Cin, int k);
 size_t split16h_conv_weight_halfs(int Cout, int Cin, int k);
 float pack_conv_weights_split16h(const float* w, int Cout, int Cin, int k, void* dst, bool bf = false);  // returns 1 / scale
 bool conv_f16x3_group_is_dual(const ConvArgs* as, int n);
+bool conv_f16x3_dilated_uses_w4();   // the dilated heads (dilation 2 / 4) run on the dual-tile family's DIL form (SHF_F16X3_DIL_W4)
+bool conv_f16x3_group_is_dilated_w4(const ConvArgs* as, int n);
 void pack_conv_weights_split16(const float* w, int Cout, int Cin, int k, void* dst, bool bf = false);
 // first layer (64, 27) as the B operand of v_mfma_f32_32x32x16_f16: [n 2][kk 2][hi/lo 2][lane 64][8 halfs], K padded 27 -> 32
 constexpr size_t kFirstConvFragHalfs = 2 * 2 * 2 * 64 * 8;

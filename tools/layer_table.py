@@ -184,8 +184,9 @@ def main():
     # single tiles for the rest (same <IN_SPLIT, rows>).  Merge such pairs while there are more dispatches than layers.
     import re
     def w4d(n):
-        m = re.search(r"w4d_kernel<(\w+), (\d), (\d), (\d)(?:, \w+)?>", n)
-        return None if m is None else (m.group(1), m.group(2), int(m.group(3)))
+        m = re.search(r"w4d_kernel<(\w+), (\d), (\d), (\d)(?:, \w+)?(?:, (\d))?>", n)
+        # (the dilated heads -- last template argument 2 / 4 -- are layers of their own, never the second half of a pair)
+        return None if m is None or (m.group(5) or "1") != "1" else (m.group(1), m.group(2), int(m.group(3)))
     groups, j = [], 0
     while j < len(conv_idx) and len(groups) < len(layers):
         i = conv_idx[j]
