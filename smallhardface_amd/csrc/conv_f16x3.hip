@@ -118,6 +118,8 @@ struct Knobs {
   int w4_mode;         // SHF_F16X3_W4: -1 auto (Cin >= 64), 0 never, 1 always -- which layers take the 4-wave dual-tile family
   int w4_mt;           // SHF_F16X3_W4_MT: 0 auto, 2 / 4 force 8- / 16-row tiles
   int w4d_ntile;       // SHF_F16X3_W4D_NTILE: 0 auto (hybrid launches), 1 / 2 force single- / two-tile blocks
+  int pc_tab;          // SHF_F16X3_PC_TAB: 0 = the persistent first pair decodes its tiles one by one (the path launches with more than
+                       // 300 tiles per block take anyway); bit-identical
   int dil_w4;          // SHF_F16X3_DIL_W4: 1 (default) = the dilated heads on the dual-tile family's DIL form, 0 = the 8-wave kernel
   bool pc, dilated, k1, scalar_epilogue;   // SHF_F16X3_PC, SHF_F16X3_DILATED, SHF_F16X3_1X1 (default on), SHF_CONV_SCALAR_EPILOGUE (off)
   bool pc_persist;     // SHF_F16X3_PC_PERSIST (default on): the fused first pair as one block per CU walking the tiles
@@ -131,6 +133,7 @@ const Knobs& knobs() {
     q.w4_mt = env_int("SHF_F16X3_W4_MT", 0);
     q.w4d_ntile = env_int("SHF_F16X3_W4D_NTILE", 0);
     q.dil_w4 = env_int("SHF_F16X3_DIL_W4", 1);
+    q.pc_tab = env_int("SHF_F16X3_PC_TAB", 1);
     q.pc = env_int("SHF_F16X3_PC", 1) != 0;
     q.pc_persist = env_int("SHF_F16X3_PC_PERSIST", 1) != 0;
     q.dilated = env_int("SHF_F16X3_DILATED", 1) != 0;
@@ -319,7 +322,7 @@ if (lds_pc > 160 * 1024) { set_error("conv f16x3: the fused first pair does not 
       p.ntile_blocks = (int)tiles;
       const dim3 gp((unsigned)std::min<long long>(tiles, knobs().cus));
       {   // the per-block tile table: fits (300 tiles per block) and packs (image < 256, tile row / column < 1024)?
-        bool ok = (tiles + gp.x - 1) / gp.x <= 300;
+        bool ok = knobs().pc_tab != 0 && (tiles + gp.x - 1) / gp.x <= 300;
         for (int i = 0; i < n; ++i)
           ok = ok && as[i].in.B <= 255 && p.m[i].tiles_x <= 1023 && p.m[i].tiles_per_img / std::max(1, p.m[i].tiles_x) <= 1023;
         p.pc_tab = ok ? 1 : 0;

@@ -279,9 +279,9 @@ def test_c4_wider_shaped_pyramid_vs_oracle():
     assert a[:, [0, 2]].max() <= 1024 and a[:, [1, 3]].max() <= 768 and a[:, :4].min() >= -1e-3
 
 
-def _run_bench(tmp_path, world, extra, tag):
+def _run_bench(tmp_path, world, extra, tag, more_env=None):
     out = str(tmp_path / ("dets_%s.npy" % tag))
-    env = dict(os.environ, PYTHONPATH=ROOT, SHF_BENCH_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, PYTHONPATH=ROOT, SHF_BENCH_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0", **(more_env or {}))
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
         env.pop(k, None)
     base = [os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "0", "--no-cpu-baseline",
@@ -343,6 +343,10 @@ def test_rccl_one_rank_group_runs_the_collective_path(tmp_path):
     assert jr["rccl_ranks"] == 1 and jr["collective_backend"] == "nccl" and jr["collectives_issued_rank0"] >= 2
     assert len(d1) > 0
     np.testing.assert_array_equal(d1, dr)
+    # the persistent first pair's walk without its per-block tile table (the path launches with more than 300 tiles per
+    # block take): ~106 tiles per block here, each decoded a tile ahead on a producer wave -- the same bits
+    dt, _ = _run_bench(tmp_path, 1, [], "c5_n1_no_tile_table", more_env={"SHF_F16X3_PC_TAB": "0"})
+    np.testing.assert_array_equal(d1, dt)
 
 
 # ------------------------------------------------------------------------------------------------------------

@@ -575,7 +575,7 @@ np.savez(sys.argv[1], voted=voted, raw=buf[:n].cpu().numpy())
                       ("scalar_epilogue", {"SHF_CONV_SCALAR_EPILOGUE": "1", "SHF_F16X3_SPLIT_ACT": "0"}),
                       ("single_tile", {"SHF_F16X3_W4D_NTILE": "1"}), ("dual_tile", {"SHF_F16X3_W4D_NTILE": "2"}),
                       ("rows8", {"SHF_F16X3_W4_MT": "2"}), ("rows16", {"SHF_F16X3_W4_MT": "4"}), ("no_pc", {"SHF_F16X3_PC": "0"}),
-                      ("no_dil_w4", {"SHF_F16X3_DIL_W4": "0"}),
+                      ("no_dil_w4", {"SHF_F16X3_DIL_W4": "0"}), ("pc_no_tile_table", {"SHF_F16X3_PC_TAB": "0"}),
                       ("pc_block_per_tile", {"SHF_F16X3_PC_PERSIST": "0"})):
         out = str(tmp_path / (name + ".npz"))
         e = dict(os.environ, PYTHONPATH=root, **env)
@@ -584,7 +584,7 @@ np.savez(sys.argv[1], voted=voted, raw=buf[:n].cpu().numpy())
         outs[name] = np.load(out)
     assert len(outs["default"]["voted"]) > 0 and len(outs["default"]["raw"]) > len(outs["default"]["voted"])
     # same arithmetic, different data path: bit-identical, merged and un-merged
-    for name in ("no_split_act", "single_tile", "dual_tile", "rows8", "rows16", "pc_block_per_tile"):
+    for name in ("no_split_act", "single_tile", "dual_tile", "rows8", "rows16", "pc_block_per_tile", "pc_no_tile_table"):
         for key in ("voted", "raw"):
             assert outs[name][key].shape == outs["default"][key].shape and np.array_equal(outs[name][key], outs["default"][key]), (name, key)
     # other kernels for the same layers: fp32-class agreement of the rows that go into the merge (a row may cross the
