@@ -7,22 +7,29 @@
 
 namespace shf {
 
-// Producer / consumer variant of the fused first pair (conv1_1 -> conv1_2, Cin = Cout = 64).  With only
-// 64 couts a wave of the 8-wave kernel owns ONE 32-pixel MFMA row tile (MT = 1) and needs a ds_read_b128 per
-// MFMA -- LDS-bound at ~40 % matrix-pipe use -- and its conv1_1 (lane = halo pixel, 27 taps x 32 channels
-// with one weight fetch per packed FMA) is latency-bound: ~12 k cycles per 32-channel pass, two passes.
-// Here:
-//  * conv1_1 runs ONCE, in the prologue, on all eight waves with lane = output channel: the lane keeps
-//    its 27 weights in registers, the pixel values are wave-uniform LDS broadcasts of the image patch, and
-//    one v_pk_fma_f32 advances two neighbouring pixels.  Both 32-channel chunks of the 18x18 halo tile are
-//    written to LDS (two tiles: the first-layer weights no longer live there, so both fit) -- no second
-//    pass, no hand-over barrier in the K loop.
-//  * waves 0-3 are CONSUMERS (one per SIMD): 64 px x 64 couts = 4 accumulator tiles each, 8 fragment reads
-//    per 12 MFMAs, the six k-steps of a stage software-pipelined like the 4-wave kernel (~2.6 k cycles per
-//    stage against 2.3 k of pure MFMA issue).  Waves 4-7 are PRODUCERS: they issue every weight DMA.
-//  * PERSIST (round 3): one block per CU WALKS the tiles (tile = block, block + grid, ...).  The producers fetch the
-//    next tile's image patch, its validity flags and its first weight stage under the current K loop, so a tile no
-//    longer pays the block turnaround, the tile decode and the patch's round trip (≈6 k of ≈37 k cycles).
+// Producer / consumer kernel of the fused first pair (conv1_1 -> conv1_2, Cin = Cout = 64): conv1_1's 64-channel output
+// (1.8 GB per image on the bench pyramid) never touches HBM.  With only 64 couts a wave of the 8-wave kernel owns ONE
+// 32-pixel MFMA row tile (MT = 1) and needs a ds_read_b128 per MFMA -- LDS-bound at ~40 % matrix-pipe use.  Here:
+//  * conv1_1 runs ON THE MATRIX CORES as D[cout][pixel]: [324 halo px x 27 taps (padded to 32)] x [32 x 64 couts] =
+//    11 row tiles of 32 halo pixels, 12 split-fp16 MFMAs each.  The 20x20x3 image patch is parked in LDS ALREADY SPLIT
+//    (fp16 hi | fp16 lo << 16 per dword), the K slots are ordered (first_conv_slot_tap) so that a lane's sixteen patch reads
+//    are base(kk, kh) + immediate, and a fragment register is one byte permute of two patch words.  Weights fragments and
+//    biases live in LDS; a row tile = all operand reads, then the twelve MFMAs, then two epilogues (bias, ReLU, zero
+//    outside the image, split, four 8-byte stores of hi and of lo per chunk into the halo tiles As0 / As1).
+//  * waves 0-3 are CONSUMERS (one per SIMD): 64 px x 64 couts = 4 accumulator tiles each, 8 fragment reads per 12 MFMAs,
+//    the six k-steps of a stage software-pipelined (~2.65 k cycles per stage against 2.3 k of pure MFMA issue); their
+//    epilogue stores from registers (conv_common.h conv_epilogue_pool_only when only the pooled map is kept).  Waves 4-7
+//    are PRODUCERS: every weight DMA, and the walk's bookkeeping.
+//  * PERSIST: one block per CU WALKS the tiles (tile = block, block + grid, ...), decoded once per block into a packed
+//    LDS table.  Under tile t's K loop the producers read tile t + 2's record (stage 4), request tile t + 1's patch
+//    (stage 1, IN FRONT of that stage's weight pieces) and park it with its validity flags (stage 2), hand tile t + 1's
+//    geometry to all waves through LDS (stage 3) and request its first weight stage (stage 5).
+//  * A matrix stream and a vector stream do not overlap on a SIMD (tools/scratch/coissue.hip: a partner wave gets ~3 vector
+//    issues per MFMA), so conv1_1 of tile t + 1 does NOT run under the K loop (measured: the K loop grows by what the
+//    producers run) but BESIDE THE OTHER VECTOR PHASE: behind a post-K barrier its 11 row tiles are claimed one at a time
+//    (an LDS counter) by whichever wave is free -- the producers at once, the consumers when their epilogue is out.
+//    Per tile: K loop 6 x ~2.7 k cycles (stages 0 / 1 stretched to ~3.2 / 3.7 k by the producers' chores), epilogue +
+//    conv1_1 phase 7.5-8.5 k, hand-over to stage 0 1.3-1.9 k: 1.84 -> 1.50 ms per image against round 3.
 template <int NP, bool BF = false, bool PERSIST = false>
 __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
   using namespace f16x3;
