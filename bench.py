@@ -19,6 +19,12 @@ Rank 0 prints ONE JSON line (contract in the task description) with two extra ob
   cpu_baseline  the numpy/OpenBLAS oracle (Caffe's im2col+SGEMM algorithm) timed on the
                 host cores on the five levels of one image (flips counted twice) + bbox_vote
   reduced_precision  (N=1) a short second run in bf16 / f16 after the timed region: value + measured drift
+  sustained     (N=1) back-to-back steps for --sustain-seconds after the timed region (the timed region is a fraction of a second)
+  mixed_shapes  (N=1) 32 uint8 images of 8 WIDER-like shapes through upload + device pyramid + re-plan + two images in flight
+                (test.inference_worker's loop), with the runtime's allocation counts after the first pass
+HIP events: an untimed survey pass brackets every launch (per-class table); the timed region brackets only the dominant
+kernel's launches (an event pair costs the stream a few microseconds; --events-all restores full bracketing).
+--force-dist runs the N>1 schedule on a ONE-rank process group (with --backend nccl: a 1-rank RCCL communicator).
 """
 import argparse
 import json
