@@ -103,3 +103,16 @@ def test_generated_template_equals_the_reference_template(key, dd):
     assert len(canon) == want["n_chars"]
     assert hashlib.sha256(canon.encode()).hexdigest() == want["sha256"]
     assert P.parse(canon) == msg                       # printer/parser round trip
+
+
+def test_c_abi_exports_every_declared_symbol_and_the_allocation_counters_answer_without_a_gpu():
+    """include/shf_hip.h vs the built library (no compute call: CPU containers have no GPU), and the round-4 measurement
+    entry point shf_alloc_counts, which only reads two process-wide counters."""
+    from smallhardface_amd import _lib, caffe
+    lib = _lib.load(require_gpu=False)
+    names = _lib.declared_symbols()
+    assert len(names) > 50 and "shf_alloc_counts" in names and "shf_prof_only" in names
+    missing = [s for s in names if not hasattr(lib, s)]
+    assert not missing, missing
+    d, h = caffe.alloc_counts()
+    assert isinstance(d, int) and isinstance(h, int) and d >= 0 and h >= 0
