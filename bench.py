@@ -275,20 +275,29 @@ def main():
     state = {"k": 0, "pending": None, "collectives": 0}
     host_trace = [] if os.environ.get("SHF_BENCH_HOST_TRACE") == "1" else None   # diagnostics: where the host waits
 
+    dist_t = {"enqueue": 0.0, "export": 0.0, "gather": 0.0, "merge": 0.0}   # (SHF_BENCH_HOST_TRACE=1: where the host's time goes)
+
     def finish_window(w):
         ls, ex = lane_sets[w], export_sets[w]
+        t_a = time.perf_counter()
         counts = ls[0].detect_export_many(ls, [e.data_ptr() for e in ex], cfg.TEST.N_DETS_PER_MODULE) if ls else []
+        t_b = time.perf_counter()
         local = {i: [] for i in range(world)}   # per image: the units' export buffers as they are (no concatenation)
         for m, (i, u) in enumerate(mine):
             if counts[m]:
                 local[i].append(ex[m][:min(counts[m], cfg.TEST.N_DETS_PER_MODULE)])
         got = pyramid.gather_window(local, world, rank, world, device=dev, force_collective=args.force_dist)
         state["collectives"] += 1
+        t_c = time.perf_counter()
         for i, t in got.items():            # (gather_window has synchronised on the received header rows)
             net.detect_begin()
             t = t.contiguous()
             net.detect_import(t.data_ptr(), int(t.shape[0]))
             last[i] = net.detect_finish(cfg.TEST.NMS_METHOD, cfg.TEST.NMS_THRESH)
+        t_d = time.perf_counter()
+        dist_t["export"] += t_b - t_a
+        dist_t["gather"] += t_c - t_b
+        dist_t["merge"] += t_d - t_c
 
     def step():
         if not dist_path and args.mode == "streams":  # the older per-unit-streams schedule: one image at a time
@@ -317,7 +326,9 @@ def main():
         state["k"] += 1
         ls = lane_sets[w]
         if ls:
+            t_e = time.perf_counter()
             ls[0].detect_add_levels(ls, mine_units, thresh, on_device=True, per_member_lists=True)
+            dist_t["enqueue"] += time.perf_counter() - t_e
         if state["pending"] is not None:
             finish_window(state["pending"])
         state["pending"] = w
@@ -382,6 +393,8 @@ def main():
         step()
     fence()
     elapsed = time.perf_counter() - t0
+    if host_trace is not None and dist_path:
+        print("host time per window (ms): " + ", ".join("%s %.2f" % (k, 1e3 * v / max(1, state["k"])) for k, v in dist_t.items()), file=sys.stderr)
     if host_trace:
         base = [t for k, t in host_trace if t >= t0][0]
         print(" ".join("%s%.2f" % (k, 1000 * (t - base)) for k, t in host_trace if t >= t0)[:4000], file=sys.stderr)

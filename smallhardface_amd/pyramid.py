@@ -138,7 +138,9 @@ def gather_window(local, n_images, rank, world, device=None, group=None, force_c
                 at += take
         send[:, :, 0, :].copy_(hdr, non_blocking=True)   # every header row of the window in one copy
         if to_host:
-            torch.cuda.synchronize()                     # (validation path: the rows came down from the GPU)
+            # (validation path: the rows came down from the GPU on torch's current stream -- wait for THAT stream, not for the
+            # device: the next window's convolutions are already running on the runtime's own streams)
+            torch.cuda.current_stream().synchronize()
         dist.all_to_all_single(recv.view(world, -1), send.view(world, -1), group=group)
         buf["head"].copy_(recv[:, :, 0, :2])             # the one host synchronisation: [sender][slot] -> (rows, sender's max)
         if torch.device(dev).type == "cuda":
