@@ -196,8 +196,11 @@ def main():
     if dist_path:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if world == 1:
-            os.environ.setdefault("MASTER_PORT", "29533")
+        if world == 1 and "MASTER_PORT" not in os.environ:   # (--force-dist without a launcher: any free port will do)
+            import socket
+            with socket.socket() as s_:
+                s_.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(s_.getsockname()[1])
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
