@@ -16,7 +16,8 @@
 // Kernels, one header each (this file is the host side: weight packs, knobs, launchers):
 //   conv_f16x3_w4d.h   conv_mfma_f16x3_w4d_kernel -- the dual-tile 4-wave family: Cin >= 64, Cout % 128 == 0 (80 % of the time)
 //   conv_f16x3_pc.h    conv_mfma_f16x3_pc_kernel  -- the fused first pair conv1_1 -> conv1_2, producer / consumer waves
-//   conv_f16x3_8w.h    conv_mfma_f16x3_kernel     -- 8 waves: the dilated heads, the 1x1s, Cout 64, unaligned views
+//   conv_f16x3_k1.h    conv_mfma_f16x3_k1_kernel  -- the 1x1 layers with Cout % 256 == 0 as a plain GEMM over flat pixels
+//   conv_f16x3_8w.h    conv_mfma_f16x3_kernel     -- 8 waves: what the others cannot take (Cout 64, other 1x1s, unaligned views)
 //   conv_f16x3_types.h vector types, the hi / lo split, the MFMA wrapper, conv1_1's K-slot map
 // Common structure: tile 256 px (16x16) x BN couts; a STAGE is one kernel row (3 taps) of one channel chunk: its weight
 // slabs are double-buffered in LDS and arrive by LDS DMA; the halo tile is staged once per chunk and reused by all 9 taps.
@@ -39,6 +40,7 @@
 #include "conv_f16x3_8w.h"
 #include "conv_f16x3_w4d.h"
 #include "conv_f16x3_pc.h"
+#include "conv_f16x3_k1.h"
 
 namespace shf {
 
@@ -121,6 +123,8 @@ struct Knobs {
   int pc_tab;          // SHF_F16X3_PC_TAB: 0 = the persistent first pair decodes its tiles one by one (the path launches with more than
                        // 300 tiles per block take anyway); bit-identical
   int dil_w4;          // SHF_F16X3_DIL_W4: 1 (default) = the dilated heads on the dual-tile family's DIL form, 0 = the 8-wave kernel
+  int k1_gemm;         // SHF_F16X3_K1_GEMM: 1 (default) = 1x1 layers with Cout % 256 == 0 on the GEMM kernel (conv_f16x3_k1.h), 0 = the
+                       // 8-wave kernel's KS = 1 form
   bool pc, dilated, k1, scalar_epilogue;   // SHF_F16X3_PC, SHF_F16X3_DILATED, SHF_F16X3_1X1 (default on), SHF_CONV_SCALAR_EPILOGUE (off)
   bool pc_persist;     // SHF_F16X3_PC_PERSIST (default on): the fused first pair as one block per CU walking the tiles
   int cus;
@@ -133,6 +137,7 @@ const Knobs& knobs() {
     q.w4_mt = env_int("SHF_F16X3_W4_MT", 0);
     q.w4d_ntile = env_int("SHF_F16X3_W4D_NTILE", 0);
     q.dil_w4 = env_int("SHF_F16X3_DIL_W4", 1);
+    q.k1_gemm = env_int("SHF_F16X3_K1_GEMM", 1);
     q.pc_tab = env_int("SHF_F16X3_PC_TAB", 1);
     q.pc = env_int("SHF_F16X3_PC", 1) != 0;
     q.pc_persist = env_int("SHF_F16X3_PC_PERSIST", 1) != 0;
@@ -175,6 +180,20 @@ bool conv_f16x3_group_is_dilated_w4(const ConvArgs* as, int n) {
   if (!conv_f16x3_dilated_uses_w4() || !as[0].wsplit16h || as[0].img || as[0].k != 3 || (as[0].dil != 2 && as[0].dil != 4) || as[0].out.C % 128)
     return false;
   if (!conv_f16x3_uses_w4(as[0].in.C) || knobs().scalar_epilogue || !views_aligned(as, n)) return false;
+  for (int i = 0; i < n; ++i)
+    if ((unsigned long long)as[i].in.B * as[i].in.H * as[i].in.W * as[i].in.cstride * 4ull >= (1ull << 32)) return false;
+  return true;
+}
+
+// 1x1 layers on the GEMM kernel (conv_f16x3_k1.h): all 256 couts of a pixel in one block, the family's weight pack with
+// k = 1, activations in the split format (net.cpp counts such a layer as a split-format reader) or fp32
+bool conv_f16x3_k1_gemm_shape(int Cin, int Cout) {
+  return knobs().k1_gemm != 0 && knobs().k1 && conv_f16x3_uses_w4(Cin) && Cin % 32 == 0 && Cout % 256 == 0;
+}
+bool conv_f16x3_group_is_k1_gemm(const ConvArgs* as, int n) {
+  if (!as[0].wsplit16h || as[0].img || as[0].k != 1 || as[0].bf16 || as[0].pool.p || !conv_f16x3_k1_gemm_shape(as[0].in.C, as[0].out.C))
+    return false;
+  if (knobs().scalar_epilogue || !views_aligned(as, n)) return false;
   for (int i = 0; i < n; ++i)
     if ((unsigned long long)as[i].in.B * as[i].in.H * as[i].in.W * as[i].in.cstride * 4ull >= (1ull << 32)) return false;
   return true;
@@ -439,6 +458,67 @@ if (lds_pc > 160 * 1024) { set_error("conv f16x3: the fused first pair does not 
   return 0;
 }
 
+// 1x1 GEMM kernel: blocks of 256 pixels of each member's flat pixel list x 256 couts
+static int launch_f16x3_k1(const ConvArgs* as, int n, hipStream_t s) {
+  const ConvArgs& a = as[0];
+  ConvK p;
+  p.wp = (const float*)a.wsplit16;
+  p.wph = a.wsplit16h;
+  p.wscale_inv = a.wscale_inv;
+  p.tile_base = 0;
+  p.ntile_blocks = 0;
+  p.pc_tab = 0;
+  p.bias = a.bias;
+  p.Cin = a.in.C; p.Cout = a.out.C;
+  p.in_stride = a.in.cstride; p.out_stride = a.out.cstride;
+  p.dil = 1; p.relu = a.relu | 16 | (a.out_split ? 32 : 0);
+  p.pool_stride = 0;
+  p.nct = p.Cout / 256;
+  p.nmem = n;
+  for (int i = 0; i < MAX_GROUP; ++i) p.tile_starts[i] = 0x7fffffff;
+  p.dbg = nullptr;
+  p.range_flag = a.range_flag;
+  p.w1t = nullptr; p.w1f = nullptr; p.b1 = nullptr;
+  long long tiles = 0;
+  for (int i = 0; i < n; ++i) {
+    const ConvArgs& q = as[i];
+    if (q.in.C != p.Cin || q.out.C != p.Cout || q.in.cstride != p.in_stride || q.out.cstride != p.out_stride ||
+        q.wsplit16h != a.wsplit16h || q.in_split != a.in_split || q.out_split != a.out_split || q.k != 1) {
+      set_error("conv group: members must share the layer");
+      return -1;
+    }
+    ConvMember& m = p.m[i];
+    m.in = q.in.p + q.in.coff;
+    m.out = q.out.p + q.out.coff;
+    m.pool = nullptr;
+    m.img = nullptr;
+    m.in_amax = q.in_amax; m.out_amax = q.out_amax; m.pool_amax = nullptr;
+    m.B = q.in.B; m.H = q.in.H; m.W = q.in.W;
+    const long long npix = (long long)m.B * m.H * m.W;
+    if (npix >= (1ll << 31)) { set_error("conv f16x3: 2^31 pixels or more in one member"); return -1; }
+    m.tiles_x = 1;
+    m.tiles_per_img = (int)((npix + 255) / 256);
+    m.inv_tiles_x = 0; m.inv_tiles_per_img = 0;
+    m.tile_start = (int)tiles;
+    p.tile_starts[i] = (int)tiles;
+    tiles += m.tiles_per_img;
+  }
+  if (tiles * p.nct >= (1ll << 31)) { set_error("conv f16x3: grid too large"); return -1; }
+  const size_t lds = 3 * 256 * 128 + 2 * 2 * 256 * 64;   // three activation chunks + two weight chunks: all 160 KiB
+  const dim3 g((unsigned)(tiles * p.nct));
+#define SHF_K1_LAUNCH(SPLIT)                                                                                         \
+  {                                                                                                                 \
+    if (a.nprod >= 3) hipLaunchKernelGGL((conv_mfma_f16x3_k1_kernel<SPLIT, 3>), g, dim3(256), lds, s, p);            \
+    else if (a.nprod == 2) hipLaunchKernelGGL((conv_mfma_f16x3_k1_kernel<SPLIT, 2>), g, dim3(256), lds, s, p);       \
+    else hipLaunchKernelGGL((conv_mfma_f16x3_k1_kernel<SPLIT, 1>), g, dim3(256), lds, s, p);                         \
+  }
+  if (a.in_split) SHF_K1_LAUNCH(true)
+  else SHF_K1_LAUNCH(false)
+#undef SHF_K1_LAUNCH
+  SHF_HIP_OK(hipGetLastError());
+  return 0;
+}
+
 int conv_f16x3_init_attributes() {
   (void)knobs();
 #define SHF_LDS_ATTR(K) SHF_HIP_OK(hipFuncSetAttribute((const void*)(K), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -474,6 +554,8 @@ int conv_f16x3_init_attributes() {
 #undef SHF_W4D_DIL_ATTR
   SHF_LDS_ATTR((conv_mfma_f16x3_w4d_kernel<false, 4, 2, 1, true>)) SHF_LDS_ATTR((conv_mfma_f16x3_w4d_kernel<false, 4, 1, 1, true>))
   SHF_LDS_ATTR((conv_mfma_f16x3_w4d_kernel<false, 2, 2, 1, true>)) SHF_LDS_ATTR((conv_mfma_f16x3_w4d_kernel<false, 2, 1, 1, true>))
+  SHF_LDS_ATTR((conv_mfma_f16x3_k1_kernel<true, 3>)) SHF_LDS_ATTR((conv_mfma_f16x3_k1_kernel<true, 2>)) SHF_LDS_ATTR((conv_mfma_f16x3_k1_kernel<true, 1>))
+  SHF_LDS_ATTR((conv_mfma_f16x3_k1_kernel<false, 3>)) SHF_LDS_ATTR((conv_mfma_f16x3_k1_kernel<false, 2>)) SHF_LDS_ATTR((conv_mfma_f16x3_k1_kernel<false, 1>))
 #undef SHF_LDS_ATTR
   return 0;
 }
@@ -487,6 +569,7 @@ int launch_conv_f16x3_group(const ConvArgs* as, int n, hipStream_t s) {
     if (as[0].in.C != 64 || !as[0].w1t) { set_error("conv f16x3: fused first layer needs 64 channels + transposed weights"); return -1; }
     return launch_f16x3_t<64, true>(as, n, s);  // conv1_1 computed in place (BN=64 tile: Cout 64 or any multiple of 64)
   }
+  if (as[0].k == 1 && conv_f16x3_group_is_k1_gemm(as, n)) return launch_f16x3_k1(as, n, s);
   if (as[0].k == 1)
     return (as[0].out.C % 128 == 0) ? launch_f16x3_t<128, false, 1, 1>(as, n, s) : launch_f16x3_t<64, false, 1, 1>(as, n, s);
   if (as[0].dil == 2) return conv_f16x3_group_is_dilated_w4(as, n) ? launch_f16x3_t<128, false, 2>(as, n, s) : launch_f16x3_t<64, false, 2>(as, n, s);

@@ -898,6 +898,8 @@ void shf_net::build(const std::string& text, const char* caffemodel) {
     static const bool split_act = !(getenv("SHF_F16X3_SPLIT_ACT") && atoi(getenv("SHF_F16X3_SPLIT_ACT")) == 0);
     auto w4_reader = [&](const Layer& Q, int cin) {
       const bool dil_ok = Q.dil == 1 || ((Q.dil == 2 || Q.dil == 4) && conv_f16x3_dilated_uses_w4());   // (the heads: family's DIL form)
+      if (Q.op == OP_CONV && Q.kclass == 0 && Q.k == 1 && Q.pad == 0 && Q.first_src < 0)   // 1x1 layers on the GEMM kernel
+        return conv_f16x3_k1_gemm_shape(cin, Q.nout) && conv_f16x3_eligible(cin, Q.nout, Q.k, Q.pad, Q.dil);
       return Q.op == OP_CONV && Q.kclass == 0 && Q.k == 3 && dil_ok && Q.pad == Q.dil && cin % 32 == 0 && Q.nout % 128 == 0 &&
              Q.first_src < 0 && conv_f16x3_uses_w4(cin) && conv_f16x3_eligible(cin, Q.nout, Q.k, Q.pad, Q.dil);
     };
@@ -1074,6 +1076,12 @@ void shf_net::build_tail_weights() {
 void shf_net::commit_params(int li) {
   Layer& L = layers[li];
   if (L.params.empty()) return;
+  // the dual-tile family's weight pack (16-channel slabs, unscaled low parts): its 3x3 layers, and the 1x1 GEMM kernel's
+  auto wants_family_pack = [](const Layer& Q, const ParamBlob& w) {
+    if (Q.k == 1) return Q.pad == 0 && conv_f16x3_k1_gemm_shape(w.shape[1], w.shape[0]);
+    return Q.k == 3 && (Q.dil == 1 || ((Q.dil == 2 || Q.dil == 4) && conv_f16x3_dilated_uses_w4())) && conv_f16x3_uses_w4(w.shape[1]) &&
+           w.shape[0] % 128 == 0 && w.shape[1] % 32 == 0;
+  };
   // the raw / packed tensors are shared by every lane cloned from this net: nothing may be in flight on any stream
   HIP_THROW(hipDeviceSynchronize());
   const bool in_tail = std::count(tail_cls_layers.begin(), tail_cls_layers.end(), li) ||
@@ -1118,7 +1126,7 @@ void shf_net::commit_params(int li) {
         pack_conv_weights_split16(p.host.data(), p.shape[0], p.shape[1], p.shape[2], sp.data(), true);
         p.packed16b.ensure(sp.size() * 2);
         HIP_THROW(hipMemcpy(p.packed16b.p, sp.data(), sp.size() * 2, hipMemcpyHostToDevice));
-        if (L.k == 3 && (L.dil == 1 || ((L.dil == 2 || L.dil == 4) && conv_f16x3_dilated_uses_w4())) && conv_f16x3_uses_w4(p.shape[1]) && p.shape[0] % 128 == 0 && p.shape[1] % 32 == 0) {
+        if (wants_family_pack(L, p)) {
           std::vector<uint16_t> sh(split16h_conv_weight_halfs(p.shape[0], p.shape[1], p.shape[2]));
           pack_conv_weights_split16h(p.host.data(), p.shape[0], p.shape[1], p.shape[2], sh.data(), true);
           p.packed16hb.ensure(sh.size() * 2);
@@ -1138,8 +1146,7 @@ void shf_net::commit_params(int li) {
         p.packed16.ensure(sp.size() * 2);
         HIP_THROW(hipMemcpy(p.packed16.p, sp.data(), sp.size() * 2, hipMemcpyHostToDevice));
         p.split_stale = false;
-        if (L.k == 3 && (L.dil == 1 || ((L.dil == 2 || L.dil == 4) && conv_f16x3_dilated_uses_w4())) && conv_f16x3_uses_w4(p.shape[1]) && p.shape[0] % 128 == 0 &&
-            p.shape[1] % 32 == 0) {
+        if (wants_family_pack(L, p)) {
           std::vector<uint16_t> sh(split16h_conv_weight_halfs(p.shape[0], p.shape[1], p.shape[2]));
           p.wscale_inv = pack_conv_weights_split16h(p.host.data(), p.shape[0], p.shape[1], p.shape[2], sh.data());
           p.packed16h.ensure(sh.size() * 2);
@@ -2283,6 +2290,7 @@ int shf_prof_only(shf_net* net, int cls) {
 int shf_prof_num_classes(shf_net*) { return PC_COUNT; }
 const char* shf_prof_class_name(shf_net*, int cls) {
   if (cls == PC_CONV_F16X3_PC && shf::conv_f16x3_pc_persistent()) return "conv_mfma_f16x3_pc_kernel<3, false, true>";
+  if (cls == PC_CONV_F16X3_128_K1 && shf::conv_f16x3_k1_gemm_shape(512, 256)) return "conv_mfma_f16x3_k1_kernel<true, 3>";
   if (cls == PC_CONV_F16X3_64_D2 && shf::conv_f16x3_dilated_uses_w4()) return "conv_mfma_f16x3_w4d_kernel<true, 4, 1, 3, false, 2>";
   if (cls == PC_CONV_F16X3_64_D4 && shf::conv_f16x3_dilated_uses_w4()) return "conv_mfma_f16x3_w4d_kernel<true, 4, 1, 3, false, 4>";
   return (cls >= 0 && cls < PC_COUNT) ? kProfNames[cls] : nullptr;

@@ -84,6 +84,8 @@ float pack_conv_weights_split16h(const float* w, int Cout, int Cin, int k, void*
 bool conv_f16x3_group_is_dual(const ConvArgs* as, int n);
 bool conv_f16x3_dilated_uses_w4();   // the dilated heads (dilation 2 / 4) run on the dual-tile family's DIL form (SHF_F16X3_DIL_W4)
 bool conv_f16x3_group_is_dilated_w4(const ConvArgs* as, int n);
+bool conv_f16x3_k1_gemm_shape(int Cin, int Cout);   // a 1x1 layer of this shape runs on the GEMM kernel (SHF_F16X3_K1_GEMM): the family's pack, split-format input
+bool conv_f16x3_group_is_k1_gemm(const ConvArgs* as, int n);
 void pack_conv_weights_split16(const float* w, int Cout, int Cin, int k, void* dst, bool bf = false);
 // first layer (64, 27) as the B operand of v_mfma_f32_32x32x16_f16: [n 2][kk 2][hi/lo 2][lane 64][8 halfs], K padded 27 -> 32
 constexpr size_t kFirstConvFragHalfs = 2 * 2 * 2 * 64 * 8;

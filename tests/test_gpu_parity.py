@@ -62,6 +62,8 @@ def conv_layer(name, bottom, nout, k, pad, dil=1, relu=True):
     (128, 384, 3, 1, 45, 83, True),    # three cout tiles, an odd number of 16-row tiles (dual-tile family: dummy second tile)
     (160, 128, 3, 1, 23, 17, True),    # Cin = 10 x 16: an odd number of 32-channel chunks' worth
     (512, 256, 1, 1, 9, 13, True),     # 1x1 (conv5_256 / conv4_256)
+    (512, 256, 1, 1, 23, 29, True),    # 1x1 GEMM kernel: three 256-pixel blocks, the last one ragged
+    (96, 512, 1, 1, 20, 20, False),    # ... an odd number of 32-channel chunks, two cout tiles, no ReLU
     (128, 128, 3, 2, 22, 26, True),    # head_2
     (128, 128, 3, 4, 22, 26, True),    # head_4
     (128, 128, 3, 4, 5, 6, True),      # map smaller than the dilation halo
@@ -576,6 +578,7 @@ np.savez(sys.argv[1], voted=voted, raw=buf[:n].cpu().numpy())
                       ("single_tile", {"SHF_F16X3_W4D_NTILE": "1"}), ("dual_tile", {"SHF_F16X3_W4D_NTILE": "2"}),
                       ("rows8", {"SHF_F16X3_W4_MT": "2"}), ("rows16", {"SHF_F16X3_W4_MT": "4"}), ("no_pc", {"SHF_F16X3_PC": "0"}),
                       ("no_dil_w4", {"SHF_F16X3_DIL_W4": "0"}), ("pc_no_tile_table", {"SHF_F16X3_PC_TAB": "0"}),
+                      ("no_k1_gemm", {"SHF_F16X3_K1_GEMM": "0"}),
                       ("pc_block_per_tile", {"SHF_F16X3_PC_PERSIST": "0"})):
         out = str(tmp_path / (name + ".npz"))
         e = dict(os.environ, PYTHONPATH=root, **env)
@@ -589,7 +592,7 @@ np.savez(sys.argv[1], voted=voted, raw=buf[:n].cpu().numpy())
             assert outs[name][key].shape == outs["default"][key].shape and np.array_equal(outs[name][key], outs["default"][key]), (name, key)
     # other kernels for the same layers: fp32-class agreement of the rows that go into the merge (a row may cross the
     # > 0.05 cut on one side only)
-    for name in ("no_w4", "scalar_epilogue", "no_pc", "no_dil_w4"):
+    for name in ("no_w4", "scalar_epilogue", "no_pc", "no_dil_w4", "no_k1_gemm"):
         a, b = outs["default"]["raw"], outs[name]["raw"]
         slack = max(2, len(a) // 500)
         assert abs(len(a) - len(b)) <= slack, (name, len(a), len(b))
