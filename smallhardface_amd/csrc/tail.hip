@@ -98,10 +98,18 @@ __global__ __launch_bounds__(256) void tail_logits_kernel(TailGK g) {
           }
         }
       }
+      // the xor butterfly 16, 8, 4, 2, 1 over the 32 lanes of a pixel -- only the first step through the LDS crossbar: after
+      // step m the lanes i and i ^ m hold the same bits (a + b == b + a), so the partner of step 8 / 4 may as well be the
+      // lane 8 / 4 places round the 16-lane row (DPP row_ror), and steps 2 / 1 are quad permutes: the same tree, the same bits
 #pragma unroll
       for (int o = 0; o < 6; ++o) {
-#pragma unroll
-        for (int m = 16; m >= 1; m >>= 1) part[o] += __shfl_xor(part[o], m, 64);
+        float v = part[o];
+        v += __shfl_xor(v, 16, 64);
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));   // row_ror:8
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));   // row_ror:4
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));    // quad_perm [2,3,0,1]
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));    // quad_perm [1,0,3,2]
+        part[o] = v;
       }
       if (q == 0 && k < p.K) {
         float* L = p.logits + ((size_t)k * g.A + a) * 6;
