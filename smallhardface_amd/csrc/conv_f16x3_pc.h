@@ -143,6 +143,8 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
   const size_t slab = (size_t)p.Cout * 72;
   const _Float16* wbase = (const _Float16*)p.wp;
   auto dma_w = [&](int stage, int buf) {     // producer waves only: 7 rounds of 4 pieces (the last one ragged)
+    unsigned dma_l16 = (unsigned)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) * 16u;   // (formed here: not kept across the stages)
+    asm volatile("" : "+v"(dma_l16));
     // (opaque base: the 42 source addresses of a tile are formed where they are used, on the scalar unit -- as loop
     // invariants of the persistent walk they would occupy 84 scalar registers, i.e. be spilled)
     const _Float16* wb = wbase;
@@ -154,9 +156,20 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
       int pc = (wave_u - 4) + 4 * j;
       pc = pc < PCS ? pc : PCS - 1;
       const int sl = pc / PCS_SLAB, within = pc - sl * PCS_SLAB;
+#ifdef SHF_PC_BUILTIN_DMA
       const unsigned char* src = ws_ + (size_t)sl * slab * 2 + within * 1024 + lane * 16;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(bd_ + pc * 1024), 16, 0, 0);
+#else
+      // (inline asm, like the family's dma_w: behind the BUILTIN the compiler -- which cannot tell the DMA's LDS destination
+      // from any other LDS address -- drained vmcnt before the producers' next LDS access, so their chores of a stage (patch
+      // parking, validity flags, the walk's bookkeeping, and after stage 5 the first conv1_1 row tile) started only when
+      // the seven pieces just issued had landed, instead of running under their flight.  Completion is waited for by
+      // hand at the top of the next stage.)
+      const unsigned char* ub = ws_ + (size_t)sl * slab * 2 + within * 1024;
+      const unsigned lds = (unsigned)(__SIZE_TYPE__)(__attribute__((address_space(3))) unsigned char*)(bd_ + pc * 1024);
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds), "v"(dma_l16), "s"(ub));
+#endif
     }
   };
   if (!consumer) dma_w(0, 0);
@@ -444,7 +457,14 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
 #ifdef SHF_CONV_TIMING
     if (st > 0) { asm volatile("s_nop 0" ::: "memory"); ts_own[st - 1] += __builtin_amdgcn_s_memtime() - tt[2 + st]; }
 #endif
+#ifdef SHF_PC_BUILTIN_DMA
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
+    // (the builtin: the compiler's own count of the loads in flight must see this wait -- the patch registers requested in
+    // stage 1 are parked in stage 2 BEHIND that stage's DMA issues, which it cannot see)
+    __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0), expcnt / lgkmcnt untouched
+    asm volatile("" ::: "memory");
+#endif
     __syncthreads();
     PC_T();
     if (consumer) {

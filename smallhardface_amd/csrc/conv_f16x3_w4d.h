@@ -278,7 +278,18 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4d_kernel(ConvK p) {
     constexpr int MODE = decltype(MODE_)::value;
     const int st = c * 3 + ky;
     // this wave's share of W(st) (and, MODE 2, its halo pieces) has landed; its parked pieces are in LDS
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    // (the BUILTIN, not an asm string: hipcc keeps its own count of the loads in flight and cannot see a wait inside an asm
+    // statement, nor the DMA issues inside dma_w's.  With an invisible wait it guarded every halo piece of the MODE 2 stage
+    // -- requested a whole stage earlier, long landed -- with a vmcnt(11 - j) by ITS count, and since the counter really
+    // holds this stage's DMA pieces as well, the later of those waited for weight pieces issued moments before: 1-2 % of
+    // every two-tile and 16-row layer, same-box A/B.  The single 8-row tile form -- three pieces per thread, two blocks
+    // per CU -- measured 3 % FASTER on conv2_1 with the asm form (699 / 713 against 734 / 725 us) and keeps it.)
+    if constexpr (MT == 2 && NTILE == 1) {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    } else {
+      __builtin_amdgcn_s_waitcnt(0x0070);             // vmcnt(0) lgkmcnt(0), expcnt untouched
+      asm volatile("" ::: "memory");
+    }
     __syncthreads();
     const int st_next = st + 1 < NST ? st + 1 : st;   // the last stage re-fetches itself (unused) instead of branching
     const int buf_next = (st + 1) & 1;
