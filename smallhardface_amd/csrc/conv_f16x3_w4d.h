@@ -321,7 +321,10 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4d_kernel(ConvK p) {
     constexpr int PARK_VALU = IN_SPLIT ? 4 : 7;       // vector instructions the scheduler may put beside one MFMA
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
-      constexpr int DMA_N2[6] = {1, 1, 1, 1, 1, 1}, DMA_J2[6] = {0, 1, 2, 3, 4, 5};
+      // (two-tile blocks of 8-row tiles -- conv5_x -- issue the stage's six weight pieces a half-step earlier: their half-steps
+      // are half as long, and a piece issued in the last one had ~400 cycles to land before the next stage's wait; same-box
+      // 3 x 300 vs 3 x 312 us.  For 16-row tiles the even spread stays: 2-2-2-0-0-0 measured 2 % slower there.)
+      constexpr int DMA_N2[6] = {MT == 2 ? 2 : 1, 1, 1, 1, 1, MT == 2 ? 0 : 1}, DMA_J2[6] = {0, MT == 2 ? 2 : 1, MT == 2 ? 3 : 2, MT == 2 ? 4 : 3, MT == 2 ? 5 : 4, MT == 2 ? 6 : 5};
       constexpr int DMA_N1[3] = {2, 2, 2}, DMA_J1[3] = {0, 2, 4};
       const int dma_n = NTILE == 2 ? DMA_N2[h] : DMA_N1[h], dma_j = NTILE == 2 ? DMA_J2[h] : DMA_J1[h];
       const int kx = h / NTILE, tl = h % NTILE;
