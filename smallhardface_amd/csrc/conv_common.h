@@ -235,12 +235,27 @@ __device__ __forceinline__ void conv_publish_amax(unsigned* slot, unsigned* slot
 // two fp16 holds, so the lift is ONE exact multiplication: a unit whose max is below 0.25 lands lower than [2^13, 2^14),
 // at worst (max 2^-16 x a few) around 1, where the low parts still carry 2^-23 of the top (a bound 2^12 too large
 // passes every magnitude test: tools/experiments/exponent_bias_run.sh).
-__device__ __forceinline__ int conv_act_exponent(const unsigned* slot) {
-  if (!slot) return 0;
-  const unsigned b = *slot;
+__device__ __forceinline__ int conv_act_exponent_of_bits(unsigned b) {
   if (b == 0u || b >= 0x7f800000u) return 0;
   const int e = 13 - ((int)(b >> 23) - 127);
   return e < 0 ? 0 : (e > 15 ? 15 : e);
+}
+__device__ __forceinline__ int conv_act_exponent(const unsigned* slot) {
+  if (!slot) return 0;
+  return conv_act_exponent_of_bits(*slot);
+}
+// The same read through the SCALAR cache, in two halves: the slot pointer is wave-uniform and nothing in this launch
+// writes the slot (its producers ran in earlier launches; the scalar cache starts a kernel empty).  As a vector load the
+// read sat in vmcnt next to the kernels' first weight DMA: the compiler's wait for it drained those pieces too, and -- in
+// front of the halo requests, once per tile -- put two or three serial memory round trips into every block's prologue.
+// conv_act_slot_request early, conv_act_slot_bits (one lgkmcnt(0) wait for all requests) where the exponent is needed.
+__device__ __forceinline__ unsigned conv_act_slot_request(const unsigned* slot) {
+  unsigned b = 0u;   // (a null slot: "unknown", exponent 0)
+  if (slot) asm volatile("s_load_dword %0, %1, 0x0" : "=s"(b) : "s"(slot) : "memory");
+  return b;
+}
+__device__ __forceinline__ void conv_act_slot_wait(unsigned& b0, unsigned& b1) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(b0), "+s"(b1)::"memory");
 }
 // 2^k as an fp16 bit pattern, twice (v_pk_mul_f16 operand); k in [-14, 15]
 __device__ __forceinline__ unsigned conv_pk_pow2_f16(int k) {

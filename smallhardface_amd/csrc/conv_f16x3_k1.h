@@ -101,7 +101,9 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_k1_kernel(ConvK p) {
 #pragma unroll
   for (int r = 0; r < 8; ++r) dma_a(nchunks > 1 ? 1 : 0, 1, r);
   // activation exponent (conv_common.h): the unit's max |input| -> hi * 2^e, lo * 2^(e - 11), exact in fp16
-  const int e_act = __builtin_amdgcn_readfirstlane(conv_act_exponent(mem.in_amax));
+  unsigned slot_bits = conv_act_slot_request(mem.in_amax), slot_none = 0u;   // (through the scalar cache: conv_common.h)
+  conv_act_slot_wait(slot_bits, slot_none);
+  const int e_act = conv_act_exponent_of_bits(slot_bits);
   typedef _Float16 h2 __attribute__((ext_vector_type(2)));
   const h2 f_hi = __builtin_bit_cast(h2, conv_pk_pow2_f16(e_act)), f_lo = __builtin_bit_cast(h2, conv_pk_pow2_f16(e_act - 11));
   // the two 16-byte pieces a lane reads per (pixel tile, k-step) -> its hi and lo fragments

@@ -97,6 +97,9 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4d_kernel(ConvK p) {
   // the first stage's weights only depend on the cout tile: requested BEFORE the tile decode (dozens of dependent scalar
   // loads through the member table), so that their round trip runs under it
   dma_w(0, 0, 0, W_ROUNDS);
+  // (the block's biases: requested here, parked behind the halo pieces at the end of the prologue -- parked right behind
+  // the halo requests, the compiler's wait for this one load was a wait for all of them)
+  const float bias_v = (tid < BN && p.bias) ? p.bias[ct * BN + tid] : 0.f;
 
   struct Geo { int ty0, tx0, H, W, b; const float* in; float* out; float* pool; const unsigned* in_amax; unsigned* out_amax; unsigned* pool_amax; };
   auto geometry = [&](int t) {
@@ -117,6 +120,7 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4d_kernel(ConvK p) {
   const int t0 = p.tile_base + NTILE * pp;
   const bool has1 = NTILE == 2 && t0 + 1 < ntiles;    // (an odd tile count: the last block's second tile is a dummy)
   const Geo g0 = geometry(t0), g1 = geometry(has1 ? t0 + 1 : t0);
+  unsigned slot_bits0 = conv_act_slot_request(g0.in_amax), slot_bits1 = NTILE == 2 ? conv_act_slot_request(g1.in_amax) : 0u;
 
 
   // halo piece j of this thread (per tile): 16-byte piece q = idx & 3 of halo pixel idx >> 2, idx = tid + 256 j.
@@ -155,8 +159,10 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4d_kernel(ConvK p) {
   // epilogue multiplies 2^-e back together with the weights' scale.  e <= 15, so 2^e and 2^(e - 11) are fp16 numbers and
   // the lift is one exact multiplication per value.
   // e is a function of the unit alone, so every grouping of tiles into launches / blocks forms the same bits.
-  const int e_t0 = __builtin_amdgcn_readfirstlane(conv_act_exponent(g0.in_amax));
-  const int e_t1 = NTILE == 2 ? __builtin_amdgcn_readfirstlane(conv_act_exponent(g1.in_amax)) : 0;
+  // (read through the scalar cache, requested with the geometry: conv_act_slot_request)
+  conv_act_slot_wait(slot_bits0, slot_bits1);
+  const int e_t0 = conv_act_exponent_of_bits(slot_bits0);
+  const int e_t1 = NTILE == 2 ? conv_act_exponent_of_bits(slot_bits1) : 0;
   typedef _Float16 h2 __attribute__((ext_vector_type(2)));
   // pk_f1 = this thread's factor for a split-format piece (its pieces are all hi or all lo: q = tid & 3), hi1 / lo1 = the
   // two factors of an fp32 piece -- plain registers, no struct (hipcc parks a struct that is indexed by a lane-dependent
@@ -235,7 +241,6 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4d_kernel(ConvK p) {
     areg0[j] = *(const float4*)((const char*)g0.in + a_goff[0][j]);
     if constexpr (NTILE == 2) areg1[j] = *(const float4*)((const char*)g1.in + a_goff[1][j]);
   }
-  if (tid < BN) biasL[tid] = p.bias ? p.bias[ct * BN + tid] : 0.f;
 
   const int i = lane & 31, kh = lane >> 5;
   int dy, px;
@@ -268,6 +273,7 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4d_kernel(ConvK p) {
       store_piece(areg1[j], 1, j, 0u);
     }
   }
+  if (tid < BN) biasL[tid] = bias_v;
 
   unsigned seen0 = 0xffffffffu, seen0p = 0xffffffffu, seen1 = 0xffffffffu, seen1p = 0xffffffffu;
   // one stage = kernel row KY of the 16-channel chunk c.  MODE 1 (kernel row 1 of a chunk that has a successor):
