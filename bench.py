@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Headline benchmark: images/sec over the full multi-scale test pyramid.
 
-    python bench.py --gpus 1 --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus N --steps K --warmup W        (N > 1: starts its N ranks itself through torch.distributed.run)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...      (the same, pre-launched)
 
 One "step" = one window of N images (N = number of GPUs, weak scaling), each image being
 the reference's whole test pyramid (configs/smallhardface.toml: scales
@@ -22,6 +22,7 @@ Rank 0 prints ONE JSON line (contract in the task description) with two extra ob
   sustained     (N=1) back-to-back steps for --sustain-seconds after the timed region (the timed region is a fraction of a second)
   mixed_shapes  (N=1) 32 uint8 images of 8 WIDER-like shapes through upload + device pyramid + re-plan + two images in flight
                 (test.inference_worker's loop), with the runtime's allocation counts after the first pass
+  from_files    (N=1) the same shapes as JPEG FILES: decode (reader threads) -> the loop above -> WIDER detection files
 HIP events: an untimed survey pass brackets every launch (per-class table); the timed region brackets only the dominant
 kernel's launches (an event pair costs the stream a few microseconds; --events-all restores full bracketing).
 --force-dist runs the N>1 schedule on a ONE-rank process group (with --backend nccl: a 1-rank RCCL communicator).
@@ -129,6 +130,31 @@ def cpu_baseline(msg, params, seconds_budget=45.0):
             "sample_seconds": tot_dt + vote_dt, "sample_gflops_per_s": tot_fl / tot_dt / 1e9}
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` (N > 1) without a launcher: start the N ranks as children of ONE fresh
+    `python -m torch.distributed.run` (the reference starts its N workers from one command as well,
+    lib/test.py:327-344) and return its exit code.  The parent counts the devices (which does not initialise the
+    GPU on this image) and otherwise never touches it; no exec.  `--standalone` keeps the rendezvous on a TCPStore
+    the agent binds itself (port 0) and hands to the workers: no bind-close-reuse of a port."""
+    import subprocess
+    if os.environ.get("SHF_BENCH_ONE_GPU") != "1":
+        import torch
+        n_dev = torch.cuda.device_count()
+        if n_dev < n:
+            raise SystemExit("bench.py --gpus %d needs %d visible MI355X, found %d (SHF_BENCH_ONE_GPU=1 --backend gloo runs "
+                             "all ranks on one GPU for validation)" % (n, n, n_dev))
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # the host driver only supports dmabuf IPC (RCCL among processes)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    for k in ("RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           "--nproc-per-node", str(n), os.path.abspath(__file__)] + sys.argv[1:]
+    print("bench.py: starting %d ranks: %s" % (n, " ".join(cmd)), file=sys.stderr, flush=True)
+    # the children inherit stdout / stderr: rank 0's JSON line and every rank's diagnostics appear as they are written
+    return subprocess.call(cmd, env=env, cwd=ROOT)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -174,13 +200,19 @@ def main():
                     help="N=1: after the timed region, back-to-back steps for this long in the headline mode -> 'sustained' "
                          "(0 to skip); --steps still defines 'value'")
     ap.add_argument("--no-mixed", action="store_true", help="skip the mixed-shape image stream leg ('mixed_shapes', N=1)")
+    ap.add_argument("--no-files", action="store_true", help="skip the file-to-detections leg ('from_files', N=1; part of the "
+                    "mixed-shape leg: the same shapes as JPEG files through test.fused_image_loop into the WIDER writer)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # bare `python bench.py --gpus N`: start the N ranks ourselves (the reference starts its N workers from one
+        # command too, lib/test.py:327-344).  This parent never initialises the GPU.
+        raise SystemExit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world))
+        raise SystemExit("bench.py --gpus %d was started inside a launcher with WORLD_SIZE=%d" % (args.gpus, world))
 
     import torch
     one_gpu = os.environ.get("SHF_BENCH_ONE_GPU") == "1"
@@ -194,18 +226,28 @@ def main():
     dist = None
     dist_path = world > 1 or args.force_dist      # the N>1 schedule (lane sets, export, gather, import); N=1 only with --force-dist
     if dist_path:
+        import datetime
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if world == 1 and "MASTER_PORT" not in os.environ:   # (--force-dist without a launcher: any free port will do)
-            import socket
-            with socket.socket() as s_:
-                s_.bind(("127.0.0.1", 0))
-                os.environ["MASTER_PORT"] = str(s_.getsockname()[1])
+        pg = dict(rank=rank, world_size=world,
+                  timeout=datetime.timedelta(seconds=float(os.environ.get("SHF_BENCH_DIST_TIMEOUT", "600"))))
+        if world == 1 and "MASTER_PORT" not in os.environ:   # (--force-dist without a launcher: a file store, no port at all)
+            import tempfile
+            store_dir = tempfile.mkdtemp(prefix="shf_bench_store_")
+            pg["init_method"] = "file://" + os.path.join(store_dir, "store")
         if args.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), **pg)
         else:
-            dist.init_process_group(args.backend, rank=rank, world_size=world)
+            dist.init_process_group(args.backend, **pg)
     dev = torch.device("cuda", local_rank)
+    ranks_seen = None
+    if dist is not None:
+        # a 1-element all_reduce of ones: its sum is the number of ranks the collective backend really connected
+        one = torch.ones(1, dtype=torch.float32, device=dev)
+        dist.all_reduce(one)
+        ranks_seen = int(round(float(one.item())))
+        if ranks_seen != world:
+            raise SystemExit("the %s group connected %d ranks, expected %d" % (args.backend, ranks_seen, world))
 
     from smallhardface_amd import caffe, prototxt as P, pyramid, weights
     from smallhardface_amd.config import cfg, cfg_from_file
@@ -233,8 +275,8 @@ def main():
     n_flip = 2 if cfg.TEST.FLIP else 1
     n_units = len(cfg.TEST.SCALES) * n_flip
     mine = pyramid.my_units(rank, world, world, n_units, shard=args.shard, units_per_level=n_flip)
-    if len(mine) > 16:
-        raise SystemExit("a rank's share of the window is %d units; one grouped pass holds 16" % len(mine))
+    GROUP = 16     # units per grouped pass (one kernel-argument member table); a larger share runs as several passes
+    chunks = [(a, min(a + GROUP, len(mine))) for a in range(0, len(mine), GROUP)]
     units = {}
     cache = {}
     for (i, u) in mine:
@@ -271,7 +313,7 @@ def main():
         # both windows' convolutions on ONE in-order stream, the tails / exports on the set heads' own high-priority
         # streams, the merges on the root net's (shf_net_set_pipeline): no dependence on how the runtime maps streams
         # to hardware queues
-        for h in [ls[0] for ls in lane_sets if ls] + [net]:
+        for h in [ls[a] for ls in lane_sets for (a, _) in chunks] + [net]:
             h.set_pipeline(True)
         export_sets = [export, [torch.empty_like(e) for e in export]]
         mine_units = [(units[k][0].data_ptr(),) + units[k][1:] for k in mine]
@@ -283,7 +325,9 @@ def main():
     def finish_window(w):
         ls, ex = lane_sets[w], export_sets[w]
         t_a = time.perf_counter()
-        counts = ls[0].detect_export_many(ls, [e.data_ptr() for e in ex], cfg.TEST.N_DETS_PER_MODULE) if ls else []
+        counts = []
+        for (a, b) in chunks:     # (each pass was enqueued on its own head lane ls[a])
+            counts += ls[a].detect_export_many(ls[a:b], [e.data_ptr() for e in ex[a:b]], cfg.TEST.N_DETS_PER_MODULE)
         t_b = time.perf_counter()
         local = {i: [] for i in range(world)}   # per image: the units' export buffers as they are (no concatenation)
         for m, (i, u) in enumerate(mine):
@@ -328,10 +372,10 @@ def main():
         w = state["k"] & 1
         state["k"] += 1
         ls = lane_sets[w]
-        if ls:
-            t_e = time.perf_counter()
-            ls[0].detect_add_levels(ls, mine_units, thresh, on_device=True, per_member_lists=True)
-            dist_t["enqueue"] += time.perf_counter() - t_e
+        t_e = time.perf_counter()
+        for (a, b) in chunks:
+            ls[a].detect_add_levels(ls[a:b], mine_units[a:b], thresh, on_device=True, per_member_lists=True)
+        dist_t["enqueue"] += time.perf_counter() - t_e
         if state["pending"] is not None:
             finish_window(state["pending"])
         state["pending"] = w
@@ -507,6 +551,52 @@ def main():
                  "pinned_host_allocs_after_first_pass": a2[1] - a1[1], "voted_boxes": int(n_boxes),
                  "path": "host uint8 image -> upload (pageable, 2-3 MB) -> shf_make_pyramid_level x 10 -> grouped pass, two images "
                          "in flight (test.inference_worker's loop); consecutive images always differ in shape"}
+        # ---- the same stream from image FILES (the reference's hot loop starts at cv2.imread, lib/test.py:113,239-244):
+        #      JPEGs of the same 8 shapes in a temp dir -> test.fused_image_loop (decode on reader threads, upload, device
+        #      pyramid, grouped pass, two images in flight -- what test.inference_worker runs) -> the WIDER writer
+        if not args.no_files:
+            import shutil
+            import tempfile
+            from PIL import Image
+            from smallhardface_amd.datasets import write_detections_wider
+            from smallhardface_amd.test import fused_image_loop
+            tdir = tempfile.mkdtemp(prefix="shf_bench_files_")
+            try:
+                os.makedirs(os.path.join(tdir, "images", "0--Bench"))
+                rel, nbytes = [], 0
+                for k in range(len(stream)):
+                    h_, w_ = shapes[k % len(shapes)]
+                    # photo-like content (a smooth random field + mild noise): uniform noise would make JPEGs of 1-2 MB that
+                    # decode 3x slower than a WIDER photograph of the same size
+                    low = rngm.integers(0, 256, (h_ // 16 + 2, w_ // 16 + 2, 3)).astype(np.uint8)
+                    im_ = np.asarray(Image.fromarray(low).resize((w_, h_), Image.BICUBIC)).astype(np.int16)
+                    im_ = np.clip(im_ + rngm.integers(-12, 13, im_.shape), 0, 255).astype(np.uint8)
+                    rel.append("images/0--Bench/img%03d.jpg" % k)
+                    Image.fromarray(im_).save(os.path.join(tdir, rel[-1]), quality=90)
+                    nbytes += os.path.getsize(os.path.join(tdir, rel[-1]))
+                paths = [os.path.join(tdir, r) for r in rel]
+                fused_image_loop(net, paths, thresh, fd=fd, dp=dpm)        # untimed: page cache, buffers at these shapes
+                fence()
+                st_ = {}
+                t1 = time.perf_counter()
+                dets_f = fused_image_loop(net, paths, thresh, fd=fd, dp=dpm, stats=st_)
+                fence()
+                t2 = time.perf_counter()
+                write_detections_wider(rel, [[], dets_f], os.path.join(tdir, "detections"))
+                t3 = time.perf_counter()
+                files = {"value": len(paths) / (t3 - t1), "unit": "images/s", "images": len(paths),
+                         "value_without_write": len(paths) / (t2 - t1), "vs_mixed_shapes": (len(paths) / (t3 - t1)) / mixed["value"],
+                         "mean_jpeg_kb": nbytes / len(paths) / 1024.0,
+                         "decode_ms": st_["decode_ms"], "decode_wait_ms": st_["decode_wait_ms"], "submit_ms": st_["submit_ms"],
+                         "collect_wait_ms": st_["collect_wait_ms"], "write_ms": 1000.0 * (t3 - t2) / len(paths),
+                         "decode_threads": st_["decode_threads"], "voted_boxes": int(sum(len(d) for d in dets_f)),
+                         "path": "JPEG files (the mixed_shapes stream's 8 shapes, photo-like content, quality 90) -> PIL decode on "
+                                 "reader threads -> test.fused_image_loop (what test.inference_worker runs) -> "
+                                 "datasets.write_detections_wider; per-image means in ms: decode on the reader threads, and on "
+                                 "the submitting thread decode_wait / submit / collect_wait / write"}
+                mixed["from_files"] = files
+            finally:
+                shutil.rmtree(tdir, ignore_errors=True)
         del dpm
 
     # ---- reduced-precision leg (BASELINE configs C3 / C5 name bf16; the headline above stays the fp32-class mode): after
@@ -601,7 +691,8 @@ def main():
             },
         }
         if dist_path:
-            out["rccl_ranks"] = int(dist.get_world_size()) if args.backend == "nccl" else 0
+            out["rccl_ranks"] = int(ranks_seen) if args.backend == "nccl" else 0   # (sum of a 1-element all_reduce of ones)
+            out["collective_ranks"] = int(ranks_seen)
             out["collective_backend"] = str(dist.get_backend())
             out["collectives_issued_rank0"] = int(state["collectives"])
             out["all_ranks_on_one_gpu"] = bool(one_gpu)
@@ -674,7 +765,10 @@ def main():
         if sustained is not None:
             out["sustained"] = sustained
         if mixed is not None:
+            from_files = mixed.pop("from_files", None)
             out["mixed_shapes"] = mixed
+            if from_files is not None:
+                out["from_files"] = from_files
         if reduced is not None:
             out["reduced_precision"] = reduced
         if world == 1 and not args.no_cpu_baseline:

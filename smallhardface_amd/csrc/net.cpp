@@ -1820,7 +1820,7 @@ int shf_detect_add_levels(shf_net* net, int n, shf_net** members, const float* c
                           const int* H, const int* W, const int* im_h, const int* im_w, const float* im_scale,
                           const int* flip, float thresh, int per_member_lists) {
   API_BEGIN
-  if (n < 1 || n > 16) throw std::runtime_error("detect_add_levels: 1..16 units per group");
+  if (n < 1 || n > kMaxGroup) throw std::runtime_error("detect_add_levels: 1..16 units per group");
   for (int m = 0; m < n; ++m) {
     for (int q = 0; q < m; ++q)
       if (members[q] == members[m]) throw std::runtime_error("detect_add_levels: members must be distinct nets");
@@ -1850,7 +1850,9 @@ int shf_detect_add_levels(shf_net* net, int n, shf_net** members, const float* c
       HIP_THROW(hipStreamWaitEvent(net->stream, members[m]->logits_done, 0));
     members[m]->prepare_unit(data[m], data_on_device, H[m], W[m], cs);
   }
-  if (shared && !per_member_lists) HIP_THROW(hipMemsetAsync(net->range_flag.p, 0, 4, cs));  // (detect_begin zeroes it on the head's stream)
+  // (detect_begin zeroes it on the head's stream; a pipelined head: on the conv stream, by the image's FIRST pass -- a
+  // longer unit list comes as several passes into the same list and a later one must not clear an earlier one's flag)
+  if (shared && !per_member_lists && net->img_units == 0) HIP_THROW(hipMemsetAsync(net->range_flag.p, 0, 4, cs));
   if (per_member_lists) HIP_THROW(hipMemsetAsync(net->range_flag.p, 0, 4, cs));  // no detect_begin on this path
   struct FlagScope {  // one range flag per pass: the head's
     shf_net** mb; int n;

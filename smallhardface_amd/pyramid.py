@@ -89,6 +89,15 @@ def gather_window(local, n_images, rank, world, device=None, group=None, force_c
     Host side (round 4): the send / receive blocks are allocated once and reused; all header rows of a window go up
     as ONE host-built tensor copy (they were ~3 scalar device writes per image), rows beyond a block's count are never
     read, so nothing is cleared; the header rows come back through one pinned copy.
+
+    LIFETIME of the result: an image that exactly one sender contributed to is returned as a VIEW into the cached
+    receive block (no copy); two buffer sets alternate, so a returned tensor stays valid through the NEXT call and is
+    overwritten by the one after it.  A caller that keeps results longer must ``.clone()`` them (bench.py imports them
+    into the owner's image list before its next-but-one window).  With world == 1 and no collective the inputs
+    themselves are returned.
+
+    ``device``: where the exchange's blocks live; when None it is taken from the first non-empty part of ``local`` --
+    a rank whose parts are ALL empty lists must therefore pass it (ValueError otherwise).
     """
     import torch
 
@@ -100,17 +109,32 @@ def gather_window(local, n_images, rank, world, device=None, group=None, force_c
         out = {}
         for i in range(n_images):
             ps = parts_of(i)
-            first = local[i][0] if isinstance(local[i], (list, tuple)) and len(local[i]) else local[i]
-            out[i] = ps[0] if len(ps) == 1 else (torch.cat(ps, 0) if ps else
-                                                  torch.zeros((0, 5), dtype=torch.float32,
-                                                              device=device if device is not None else getattr(first, "device", "cpu")))
+            if len(ps) == 1:
+                out[i] = ps[0]
+                continue
+            if device is not None:
+                d0 = device
+            else:
+                seen = [p for j in range(n_images)
+                        for p in (local[j] if isinstance(local[j], (list, tuple)) else [local[j]])]
+                d0 = seen[0].device if seen else "cpu"
+            out[i] = torch.cat(ps, 0) if ps else torch.zeros((0, 5), dtype=torch.float32, device=d0)
         return out
     import torch.distributed as dist
+    def first_tensor():
+        for i in range(n_images):
+            t = local[i]
+            for p in (t if isinstance(t, (list, tuple)) else [t]):
+                return p
+        return None
+
     if device is not None:
         dev = device
     else:
-        t0 = local[0]
-        dev = (t0[0] if isinstance(t0, (list, tuple)) else t0).device
+        t0 = first_tensor()
+        if t0 is None:
+            raise ValueError("gather_window: every local part is an empty list; pass device=")
+        dev = t0.device
     out_dev = dev
     to_host = dist.get_backend(group) == "gloo" and torch.device(dev).type != "cpu"
     if to_host:

@@ -222,6 +222,9 @@ def lane_ranges(costs, n_lanes):
     return ranges
 
 
+GROUP_UNITS = 16   # units per grouped pass (csrc/conv_common.h MAX_GROUP = csrc/tail.hip TG)
+
+
 class FusedDetector(object):
     """detect() with every per-unit step on the device (C ABI shf_detect_*), the units of an
     image spread over execution lanes (own HIP stream + activations, shared weights) so the
@@ -278,15 +281,20 @@ class FusedDetector(object):
 
     def submit(self, units, thresh=0.05, on_device=False):
         units = list(units)
-        assert self.mode == "group" and len(units) <= 16
+        assert self.mode == "group"
         head = self.next_head()
         lanes = self.lanes
         while len(lanes) < len(units):
             lanes.append(self.net.clone())
         head.detect_begin()
         # no wait here: add_levels starts as soon as the previous image's logits kernels have consumed
-        # the member lanes' feature maps and only awaits its appends before this image's own tails
-        head.detect_add_levels(lanes[:len(units)], units, thresh, on_device=on_device)
+        # the member lanes' feature maps and only awaits its appends before this image's own tails.
+        # One grouped pass holds GROUP_UNITS units (one kernel-argument member table); a longer unit list runs as
+        # several passes into the same image list, each on lanes of its own (a pass's tails run on the head's
+        # stream beside the next pass's convolutions: they must not share tail workspaces).
+        for a in range(0, len(units), GROUP_UNITS):
+            b = min(a + GROUP_UNITS, len(units))
+            head.detect_add_levels(lanes[a:b], units[a:b], thresh, on_device=on_device)
         head.record_event()
         self._inflight.append((head, units, thresh, on_device))
         self._turn = 1 - self._turn
@@ -323,12 +331,12 @@ class FusedDetector(object):
         """``units``: list of (data, H, W, im_h, im_w, scale, flip); data = host array or device pointer."""
         units = list(units)
         if self.mode == "group":
-            while len(self.lanes) < min(len(units), 16):
+            while len(self.lanes) < min(len(units), GROUP_UNITS):
                 self.lanes.append(self.net.clone())
             head = self.lanes[0]
             head.detect_begin()
-            for a in range(0, len(units), 16):
-                chunk = units[a:a + 16]
+            for a in range(0, len(units), GROUP_UNITS):
+                chunk = units[a:a + GROUP_UNITS]
                 head.detect_add_levels(self.lanes[:len(chunk)], chunk, thresh, on_device=on_device)
             try:
                 return [head.detect_finish(cfg.TEST.NMS_METHOD, cfg.TEST.NMS_THRESH)]
@@ -367,6 +375,83 @@ def detect_fused(net, units, thresh=0.05, on_device=False):
     return [net.detect_finish(cfg.TEST.NMS_METHOD, cfg.TEST.NMS_THRESH)]
 
 
+def fused_image_loop(net, paths, thresh=0.05, timers=None, progress=None, prefetch=None, stats=None, fd=None, dp=None):
+    """The hot loop of inference_worker (lib/test.py:239-244: imread -> detect, image after image) on the device-resident
+    path: image FILE -> decode -> upload -> pyramid on the device (DevicePyramid) -> grouped pass -> merge, two images in
+    flight on the GPU (FusedDetector.submit / collect).  The decodes of the next ``prefetch`` images (default 2; env
+    SHF_DECODE_PREFETCH, 0 = decode synchronously like the reference) run on reader threads while image i is being
+    submitted and image i - 1 collected: a JPEG decode is 5-15 ms, the GPU's share of an image 11-15 ms, so a
+    synchronous decode on the submitting thread would be exposed.  Returns the per-image (n, 5) detection arrays in order.  ``stats`` (a dict) receives per-image
+    mean milliseconds: decode (on the reader thread), decode_wait / submit / collect_wait (on this thread)."""
+    import time
+    from concurrent.futures import ThreadPoolExecutor
+    if timers is None:
+        timers = {'detect': Timer(), 'misc': Timer()}
+    if prefetch is None:
+        prefetch = int(os.environ.get("SHF_DECODE_PREFETCH", "2"))
+    prefetch = max(0, int(prefetch))
+    n_units = len(cfg.TEST.SCALES) * (2 if cfg.TEST.FLIP else 1)
+    fd = fd or FusedDetector(net, n_lanes=n_units, mode="group")
+    dp = dp or DevicePyramid(net, n_slots=2)
+    acc = {"decode": 0.0, "decode_wait": 0.0, "submit": 0.0, "collect_wait": 0.0}
+
+    import threading
+    acc_lock = threading.Lock()
+
+    def read(path):
+        t0 = time.perf_counter()
+        im = _imread(path)
+        with acc_lock:
+            acc["decode"] += time.perf_counter() - t0
+        if im is None:
+            raise IOError("cannot read image %s" % path)
+        return im
+
+    out = [None] * len(paths)
+    queued = []
+    pool = ThreadPoolExecutor(max_workers=prefetch) if prefetch and len(paths) > 1 else None
+    ahead, nxt_i = [], 0     # futures of the images after the current one, in order
+    try:
+        for i in list(range(len(paths))) + [None]:
+            if i is not None:
+                timers['misc'].tic()
+                t0 = time.perf_counter()
+                if pool:
+                    while nxt_i < len(paths) and nxt_i <= i + prefetch:
+                        ahead.append(pool.submit(read, paths[nxt_i]))
+                        nxt_i += 1
+                    im = ahead.pop(0).result()
+                else:
+                    im = read(paths[i])
+                t1 = time.perf_counter()
+                acc["decode_wait"] += t1 - t0
+                timers['misc'].toc()
+                timers['detect'].tic()
+                fd.submit(dp.units(im, net=fd.next_head()), thresh, on_device=True)
+                acc["submit"] += time.perf_counter() - t1
+                queued.append(i)
+            if queued and (i is None or fd.pending() > 1):
+                j = queued.pop(0)
+                t0 = time.perf_counter()
+                out[j] = fd.collect()[0]
+                acc["collect_wait"] += time.perf_counter() - t0
+                timers['detect'].toc()
+                if progress:
+                    progress(j)
+        while queued:
+            j = queued.pop(0)
+            out[j] = fd.collect()[0]
+            if progress:
+                progress(j)
+    finally:
+        if pool:
+            pool.shutdown(wait=True)
+    if stats is not None and paths:
+        stats.update({k + "_ms": 1000.0 * v / len(paths) for k, v in acc.items()})
+        stats["decode_threads"] = prefetch if pool else 0
+    return out
+
+
 def inference_worker(rank, imdb, target_test, start, end, thresh, result_queue=None, fused=None):
     """lib/test.py:220-253.  ``fused`` (default: env SHF_FUSED_DETECT, on): pyramid images go through
     the device-resident path (DevicePyramid -> FusedDetector.submit/collect, two images in flight)
@@ -389,8 +474,7 @@ def inference_worker(rank, imdb, target_test, start, end, thresh, result_queue=N
     dets = [[[] for _ in range(start, end)] for _ in range(imdb.num_classes)]
     if fused is None:
         fused = os.environ.get("SHF_FUSED_DETECT", "1") != "0"
-    n_units = len(cfg.TEST.SCALES) * (2 if cfg.TEST.FLIP else 1)
-    fused = fused and pyramid and n_units <= 16 and len(cfg.TEST.LEVEL) == 0
+    fused = fused and pyramid and len(cfg.TEST.LEVEL) == 0
 
     def progress(i):
         if rank == 0:
@@ -400,26 +484,8 @@ def inference_worker(rank, imdb, target_test, start, end, thresh, result_queue=N
                 (end - i - 1) * (timers['detect'].average_time + timers['misc'].average_time)), end='')
 
     if fused:
-        fd = FusedDetector(net, n_lanes=n_units, mode="group")
-        dp = DevicePyramid(net, n_slots=2)
-        queued = []
-        for i in list(range(start, end)) + [None]:
-            if i is not None:
-                timers['misc'].tic()
-                im = _imread(imdb.image_path_at(i))
-                timers['misc'].toc()
-                timers['detect'].tic()
-                fd.submit(dp.units(im, net=fd.next_head()), thresh, on_device=True)
-                queued.append(i)
-            if queued and (i is None or fd.pending() > 1):
-                j = queued.pop(0)
-                dets[1][j - start] = fd.collect()[0]
-                timers['detect'].toc()
-                progress(j)
-        while queued:
-            j = queued.pop(0)
-            dets[1][j - start] = fd.collect()[0]
-            progress(j)
+        paths = [imdb.image_path_at(i) for i in range(start, end)]
+        dets[1] = fused_image_loop(net, paths, thresh, timers=timers, progress=lambda j: progress(start + j))
     else:
         for i in range(start, end):
             im_path = imdb.image_path_at(i)
@@ -437,6 +503,33 @@ def _worker_entry(cfg_state, rank, imdb, target_test, start, end, thresh, result
     cfg.clear()
     cfg.update(cfg_state)
     inference_worker(rank, imdb, target_test, start, end, thresh, result_queue)
+
+
+def _gather_results(result_queue, procs, poll_seconds=0.5, grace_polls=20):
+    """One (rank, dets) per worker from the queue -- lib/test.py:339 is a bare ``result_queue.get()`` per worker and
+    waits forever for a worker that died (out of memory, unreadable image); here a worker that has exited without
+    delivering ends the run with an exception naming its rank, and the surviving workers are stopped."""
+    import queue as _queue
+    got, quiet = {}, {}
+    while len(got) < len(procs):
+        try:
+            rank, d = result_queue.get(timeout=poll_seconds)
+            got[rank] = (rank, d)
+            continue
+        except _queue.Empty:
+            pass
+        for rank, p in enumerate(procs):
+            if rank in got or p.exitcode is None:
+                continue
+            # (an exit code 0 with the result still in the pipe is possible for a moment: allow a few more polls)
+            quiet[rank] = quiet.get(rank, 0) + 1
+            if p.exitcode != 0 or quiet[rank] > grace_polls:
+                for q in procs:
+                    if q.exitcode is None:
+                        q.terminate()
+                raise RuntimeError("inference worker %d (GPU %s) exited with code %s before delivering its detections"
+                                   % (rank, cfg.TEST.GPU_ID[rank] if rank < len(cfg.TEST.GPU_ID) else "?", p.exitcode))
+    return [got[r] for r in sorted(got)]
 
 
 def test_net(imdb, output_dir, target_test, thresh=0.05, no_cache=False, step=0):
@@ -474,7 +567,7 @@ def test_net(imdb, output_dir, target_test, thresh=0.05, no_cache=False, step=0)
                 p.daemon = True
                 p.start()
                 procs.append(p)
-            dets = [result_queue.get() for _ in procs]
+            dets = _gather_results(result_queue, procs)
             for p in procs:
                 p.join()
             dets = [det[1] for det in sorted(dets, key=lambda x: x[0])]

@@ -83,11 +83,11 @@ def written(d):
     return np.stack([x1, y1, x2 - x1, y2 - y1], 1)
 
 
-def compare_detection_lists(key, got, want, max_unmatched=2, max_pixel_rows=2):
-    """Absolute bars set from what is measured (round 3: 0 unmatched boxes at every config, 0 written-pixel rows at C4 / C5,
-    1 of 1107 at C3 -- a box coordinate within float noise of an integer): a handful of boxes crossing the > 0.05 cut or an
-    integer boundary on one side only is legitimate, twenty are a regression.  The north star's bar is 0-pixel index
-    difference (lib/datasets/wider.py:160-167 writes the truncated integers); callers that measured 0 / 0 assert 0 / 0."""
+def compare_detection_lists(key, got, want, max_unmatched=0, max_pixel_rows=0):
+    """The north star's bar: every box matched, 0-pixel index difference (lib/datasets/wider.py:160-167 writes the
+    truncated integers).  Round 4 measured 0 unmatched / 0 written-pixel rows at EVERY config (C3, C4, C5, the afw /
+    fddb / pascal scale sets; gpurun_out/fullsize_parity.json), and the inputs are seeded, so 0 / 0 is the default;
+    a caller may only pass a looser bar together with the measured non-zero it documents (none does today)."""
     pairs, miss, extra = match_detections(got, want)
     assert len(pairs) > 0
     gi = np.array([p[0] for p in pairs])
@@ -149,7 +149,7 @@ def test_c2_1024_level_vs_oracle(c2, mode):
     assert err < SCORE_TOL, (mode, err)
     assert derr < 1e-3
     assert e53 < 5e-5 and e12 < 5e-5 and eff < 5e-5
-    assert abs(len(go["boxes"]) - len(ref["boxes"])) <= max(2, 0.01 * len(ref["boxes"]))
+    assert len(go["boxes"]) == len(ref["boxes"])         # (both sides: the 10 000 best of 49 152)
     assert srt < SCORE_TOL
     # the proposal stage on IDENTICAL inputs: order / indices exact at 49 152 anchors
     pb, pp = O.proposal_forward(gp, gnet.blobs["bbox_pred_output"].data, info)
@@ -279,7 +279,7 @@ def test_c4_wider_shaped_pyramid_vs_oracle():
     assert a[:, [0, 2]].max() <= 1024 and a[:, [1, 3]].max() <= 768 and a[:, :4].min() >= -1e-3
 
 
-def _run_bench(tmp_path, world, extra, tag, more_env=None):
+def _run_bench(tmp_path, world, extra, tag, more_env=None, bare=False):
     out = str(tmp_path / ("dets_%s.npy" % tag))
     env = dict(os.environ, PYTHONPATH=ROOT, SHF_BENCH_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0", **(more_env or {}))
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
@@ -288,6 +288,9 @@ def _run_bench(tmp_path, world, extra, tag, more_env=None):
             "--no-latency", "--no-calib", "--no-reduced", "--no-mixed", "--sustain-seconds", "0", "--dump-dets", out] + extra
     if world == 1:
         cmd = [sys.executable] + base
+    elif bare:
+        # the way the driver starts every run: ONE bare command, bench.py starts its ranks itself
+        cmd = [sys.executable] + base + ["--backend", "gloo"]
     else:
         import socket
         s = socket.socket()
@@ -328,6 +331,25 @@ def test_c5_two_and_four_ranks_equal_one_rank(tmp_path):
     d4, j4 = _run_bench(tmp_path, 4, ["--shard", "strict"], "c5_n4_strict")
     np.testing.assert_array_equal(d1, d4)
     assert j4["config"]["shard"] == "strict"
+    # the bare command (no launcher around it: bench.py starts torch.distributed.run itself) is the same run
+    db, jb = _run_bench(tmp_path, 2, ["--shard", "window"], "c5_n2_bare", bare=True)
+    np.testing.assert_array_equal(d1, db)
+    assert jb["n_gpus"] == 2 and jb["collective_ranks"] == 2 and jb["collectives_issued_rank0"] > 0
+
+
+@pytest.mark.timeout(1800)
+def test_more_than_sixteen_units_per_share(tmp_path):
+    """A share larger than one grouped pass (16 units: one kernel-argument member table): 9 scales x flip = 18 units per
+    image on one rank (FusedDetector.submit splits the image into two passes into the same list), and strict level->rank
+    sharding on 2 ranks (rank 0: 5 levels x 2 flips x 2 images = 20 units per window = two passes on two head lanes)
+    -- the same detections bit for bit.  (the north star's strict mode at 8 ranks sits exactly AT 16.)"""
+    many = ["--source", "240x320", "--scales", "100,150,200,250,300,350,400,450,500"]
+    d1, j1 = _run_bench(tmp_path, 1, many, "u18_n1")
+    assert j1["config"]["units_per_image"] == 18 and len(d1) > 0
+    d2, j2 = _run_bench(tmp_path, 2, many + ["--shard", "strict"], "u18_n2_strict")
+    np.testing.assert_array_equal(d1, d2)
+    d1s, _ = _run_bench(tmp_path, 1, many + ["--mode", "streams", "--lanes", "3"], "u18_n1_streams")
+    np.testing.assert_array_equal(d1, d1s)
 
 
 @pytest.mark.timeout(1800)

@@ -32,9 +32,15 @@ def unmatched(a, b, score_tol, box_tol):
 def test_reduced_mode_drift_and_coverage(mode):
     from smallhardface_amd import test as T
     cfg.MODEL.DIFFERENT_DILATION.ENABLE = True
-    gnet, _ = H.make_pair(H.detector_msg(True), cls_bias=1.0)
+    gnet, onet = H.make_pair(H.detector_msg(True), cls_bias=1.0)
     data = H.synth_image_blob(160, 224, seed=8)
     info = np.array([[160, 224, 1.0]], np.float32)
+    # the CPU oracle (Caffe's algorithm in fp32) on the same level: the drift bands below are held against IT as well
+    # as against the library's own exact-fp32 mode
+    onet.blobs['data'].reshape(*data.shape)
+    onet.blobs['im_info'].reshape(1, 3)
+    onet.forward(data=data, im_info=info)
+    ora_s = onet.blobs["cls_prob_reshape_output"].data.copy()
 
     def run(m):
         gnet.set_conv_mode(m)
@@ -54,6 +60,9 @@ def test_reduced_mode_drift_and_coverage(mode):
     lo, hi = BANDS[mode]
     assert lo < drift < hi, (mode, drift)
     assert float(np.abs(x3_s - ref_s).max()) < 1e-4
+    drift_oracle = float(np.abs(red_s - ora_s).max())
+    assert lo < drift_oracle < hi, (mode, drift_oracle)
+    assert float(np.abs(x3_s - ora_s).max()) < 1e-4 and float(np.abs(ref_s - ora_s).max()) < 1e-4
     # every kernel family runs reduced: each of these layers (fused first pair in the fused path / 8-wave conv1_2 here,
     # 8-wave conv2_1, 4-wave conv3_3 / fuse_final / head_1, 1x1 conv4_256, dilated head_4) moves away from fp32 by more
     # than the parity mode does, and not by much
