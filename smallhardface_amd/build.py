@@ -27,7 +27,7 @@ SOURCES = [
     ("calib.hip", []),
     ("net.cpp", []),
 ]
-HEADERS = ["shf_internal.h", "conv_common.h", "conv_f16x3_types.h", "conv_f16x3_8w.h", "conv_f16x3_w4d.h", "conv_f16x3_pc.h", "conv_f16x3_k1.h",
+HEADERS = ["shf_internal.h", "conv_common.h", "conv_f16x3_types.h", "conv_f16x3_8w.h", "conv_f16x3_w4d.h", "conv_f16x3_pc.h", "conv_f16x3_k1.h", "conv_f16x3_h3.h",
            "proto_text.h", os.path.join("..", "..", "include", "shf_hip.h")]
 
 

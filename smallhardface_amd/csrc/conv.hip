@@ -386,7 +386,7 @@ static size_t mfma_lds_bytes(int k, int dil, int BN, int TH, int TW) {
 template <int KS, int DIL, int BN, int TH, int TW>
 static int launch_mfma_t(const ConvArgs* as, int n, hipStream_t s) {
   const ConvArgs& a = as[0];
-  ConvK p;
+  ConvK p = {};
   p.wp = a.wpacked;
   p.bias = a.bias;
   p.Cin = a.in.C; p.Cout = a.out.C;

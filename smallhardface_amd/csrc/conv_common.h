@@ -24,6 +24,12 @@ struct ConvMember {
   const unsigned* in_amax;
   unsigned* out_amax;
   unsigned* pool_amax;
+  // the three shared-weight dilated heads in one launch (conv_f16x3_h3.h): `out` is dilation 1's output, these are
+  // dilation 2's and dilation 4's (null for every other kernel)
+  float* out2;
+  float* out3;
+  unsigned* out2_amax;
+  unsigned* out3_amax;
 };
 
 struct ConvK {

@@ -17,6 +17,7 @@
 //   conv_f16x3_w4d.h   conv_mfma_f16x3_w4d_kernel -- the dual-tile 4-wave family: Cin >= 64, Cout % 128 == 0 (80 % of the time)
 //   conv_f16x3_pc.h    conv_mfma_f16x3_pc_kernel  -- the fused first pair conv1_1 -> conv1_2, producer / consumer waves
 //   conv_f16x3_k1.h    conv_mfma_f16x3_k1_kernel  -- the 1x1 layers with Cout % 256 == 0 as a plain GEMM over flat pixels
+//   conv_f16x3_h3.h    conv_mfma_f16x3_heads3_kernel -- the three shared-weight dilated heads (dilation 1 / 2 / 4) in ONE launch
 //   conv_f16x3_8w.h    conv_mfma_f16x3_kernel     -- 8 waves: what the others cannot take (Cout 64, other 1x1s, unaligned views)
 //   conv_f16x3_types.h vector types, the hi / lo split, the MFMA wrapper, conv1_1's K-slot map
 // Common structure: tile 256 px (16x16) x BN couts; a STAGE is one kernel row (3 taps) of one channel chunk: its weight
@@ -41,6 +42,7 @@
 #include "conv_f16x3_w4d.h"
 #include "conv_f16x3_pc.h"
 #include "conv_f16x3_k1.h"
+#include "conv_f16x3_h3.h"
 
 namespace shf {
 
@@ -123,6 +125,8 @@ struct Knobs {
   int pc_tab;          // SHF_F16X3_PC_TAB: 0 = the persistent first pair decodes its tiles one by one (the path launches with more than
                        // 300 tiles per block take anyway); bit-identical
   int dil_w4;          // SHF_F16X3_DIL_W4: 1 (default) = the dilated heads on the dual-tile family's DIL form, 0 = the 8-wave kernel
+  int heads3;          // SHF_F16X3_HEADS3: 1 (default) = the three shared-weight dilated heads as ONE launch (conv_f16x3_h3.h), 0 = one
+                       // launch per head; bit-identical
   int k1_gemm;         // SHF_F16X3_K1_GEMM: 1 (default) = 1x1 layers with Cout % 256 == 0 on the GEMM kernel (conv_f16x3_k1.h), 0 = the
                        // 8-wave kernel's KS = 1 form
   bool pc, dilated, k1, scalar_epilogue;   // SHF_F16X3_PC, SHF_F16X3_DILATED, SHF_F16X3_1X1 (default on), SHF_CONV_SCALAR_EPILOGUE (off)
@@ -138,6 +142,7 @@ const Knobs& knobs() {
     q.w4d_ntile = env_int("SHF_F16X3_W4D_NTILE", 0);
     q.dil_w4 = env_int("SHF_F16X3_DIL_W4", 1);
     q.k1_gemm = env_int("SHF_F16X3_K1_GEMM", 1);
+    q.heads3 = env_int("SHF_F16X3_HEADS3", 1);
     q.pc_tab = env_int("SHF_F16X3_PC_TAB", 1);
     q.pc = env_int("SHF_F16X3_PC", 1) != 0;
     q.pc_persist = env_int("SHF_F16X3_PC_PERSIST", 1) != 0;
@@ -259,7 +264,7 @@ static int launch_f16x3_t(const ConvArgs* as, int n, hipStream_t s) {
   constexpr int PADH = KS == 3 ? DIL : 0;
   constexpr int HP = (TH + 2 * PADH) * (TW + 2 * PADH);
   const ConvArgs& a = as[0];
-  ConvK p;
+  ConvK p = {};
   p.wp = (const float*)a.wsplit16;
   p.wph = nullptr;
   p.wscale_inv = 1.f;
@@ -461,7 +466,7 @@ if (lds_pc > 160 * 1024) { set_error("conv f16x3: the fused first pair does not 
 // 1x1 GEMM kernel: blocks of 256 pixels of each member's flat pixel list x 256 couts
 static int launch_f16x3_k1(const ConvArgs* as, int n, hipStream_t s) {
   const ConvArgs& a = as[0];
-  ConvK p;
+  ConvK p = {};
   p.wp = (const float*)a.wsplit16;
   p.wph = a.wsplit16h;
   p.wscale_inv = a.wscale_inv;
@@ -519,6 +524,85 @@ static int launch_f16x3_k1(const ConvArgs* as, int n, hipStream_t s) {
   return 0;
 }
 
+// The three shared-weight dilated heads as ONE launch (conv_f16x3_h3.h): a1 / a2 / a4 = the dilation-1 / 2 / 4 layers'
+// arguments, member by member.  They must read the same input with the same weights and differ in dilation and output only.
+bool conv_f16x3_group_is_heads3(const ConvArgs* a1, const ConvArgs* a2, const ConvArgs* a4, int n) {
+  if (!knobs().heads3 || n < 1 || n > MAX_GROUP) return false;
+  const ConvArgs& a = a1[0];
+  if (!a.wsplit16h || a.bf16 || a.img || a.k != 3 || a.dil != 1 || a.out.C != 128 || a.in.C % 16 || !conv_f16x3_uses_w4(a.in.C)) return false;
+  if (knobs().scalar_epilogue || !conv_f16x3_dilated_uses_w4()) return false;
+  for (int i = 0; i < n; ++i) {
+    const ConvArgs* q[3] = {&a1[i], &a2[i], &a4[i]};
+    if (q[1]->dil != 2 || q[2]->dil != 4) return false;
+    for (int d = 0; d < 3; ++d) {
+      const ConvArgs& b = *q[d];
+      if (b.k != 3 || b.pad != b.dil || b.wsplit16h != a.wsplit16h || b.bias != a.bias || b.nprod != a.nprod || b.bf16 || b.pool.p ||
+          b.relu != a.relu || b.in_split != a.in_split || b.out_split != a.out_split || b.out.C != 128 || b.out.cstride != a.out.cstride ||
+          b.in.p != q[0]->in.p || b.in.coff != q[0]->in.coff || b.in.cstride != a.in.cstride || b.in.C != a.in.C ||
+          b.in.B != q[0]->in.B || b.in.H != q[0]->in.H || b.in.W != q[0]->in.W || b.range_flag != a.range_flag)
+        return false;
+    }
+    if (!views_aligned(q[0], 1) || !views_aligned(q[1], 1) || !views_aligned(q[2], 1)) return false;
+    if ((unsigned long long)a1[i].in.B * a1[i].in.H * a1[i].in.W * a1[i].in.cstride * 4ull >= (1ull << 32)) return false;
+  }
+  return true;
+}
+
+int launch_conv_f16x3_heads3(const ConvArgs* a1, const ConvArgs* a2, const ConvArgs* a4, int n, hipStream_t s) {
+  if (!conv_f16x3_group_is_heads3(a1, a2, a4, n)) { set_error("conv f16x3: not a shared-weight dilation-1/2/4 triple"); return -1; }
+  const ConvArgs& a = a1[0];
+  ConvK p = {};
+  p.wp = (const float*)a.wsplit16;
+  p.wph = a.wsplit16h;
+  p.wscale_inv = a.wscale_inv;
+  p.bias = a.bias;
+  p.Cin = a.in.C; p.Cout = a.out.C;
+  p.in_stride = a.in.cstride; p.out_stride = a.out.cstride;
+  p.dil = 1; p.relu = a.relu | 16 | (a.out_split ? 32 : 0);
+  p.nct = 1;
+  p.nmem = n;
+  for (int i = 0; i < MAX_GROUP; ++i) p.tile_starts[i] = 0x7fffffff;
+  p.range_flag = a.range_flag;
+  long long tiles = 0;
+  for (int i = 0; i < n; ++i) {
+    ConvMember& m = p.m[i];
+    m.in = a1[i].in.p + a1[i].in.coff;
+    m.out = a1[i].out.p + a1[i].out.coff;
+    m.out2 = a2[i].out.p + a2[i].out.coff;
+    m.out3 = a4[i].out.p + a4[i].out.coff;
+    m.in_amax = a1[i].in_amax;
+    m.out_amax = a1[i].out_amax; m.out2_amax = a2[i].out_amax; m.out3_amax = a4[i].out_amax;
+    m.B = a1[i].in.B; m.H = a1[i].in.H; m.W = a1[i].in.W;
+    m.tiles_x = (m.W + 15) / 16;
+    m.tiles_per_img = m.tiles_x * ((m.H + 7) / 8);
+    m.inv_tiles_x = conv_inv32(m.tiles_x);
+    m.inv_tiles_per_img = conv_inv32(m.tiles_per_img);
+    m.tile_start = (int)tiles;
+    p.tile_starts[i] = (int)tiles;
+    tiles += (long long)m.tiles_per_img * m.B;
+    if ((unsigned long long)m.tiles_per_img * m.B * (unsigned long long)m.tiles_per_img >= (1ull << 32)) {
+      set_error("conv f16x3: more than 2^32 / tiles-per-image pixel tiles in one member");
+      return -1;
+    }
+  }
+  if (tiles >= (1ll << 31)) { set_error("conv f16x3: grid too large"); return -1; }
+  p.ntile_blocks = (int)tiles;
+  const size_t as_b = 4 * ((size_t)16 * 24 * 16 + 32);
+  const size_t lds = 2 * as_b + 2 * 3 * (size_t)128 * 64 + 128 * sizeof(float);
+  const dim3 g((unsigned)tiles);
+#define SHF_H3_LAUNCH(SPLIT)                                                                                        \
+  {                                                                                                                \
+    if (a.nprod >= 3) hipLaunchKernelGGL((conv_mfma_f16x3_heads3_kernel<SPLIT, 3>), g, dim3(256), lds, s, p);       \
+    else if (a.nprod == 2) hipLaunchKernelGGL((conv_mfma_f16x3_heads3_kernel<SPLIT, 2>), g, dim3(256), lds, s, p);  \
+    else hipLaunchKernelGGL((conv_mfma_f16x3_heads3_kernel<SPLIT, 1>), g, dim3(256), lds, s, p);                    \
+  }
+  if (a.in_split) SHF_H3_LAUNCH(true)
+  else SHF_H3_LAUNCH(false)
+#undef SHF_H3_LAUNCH
+  SHF_HIP_OK(hipGetLastError());
+  return 0;
+}
+
 int conv_f16x3_init_attributes() {
   (void)knobs();
 #define SHF_LDS_ATTR(K) SHF_HIP_OK(hipFuncSetAttribute((const void*)(K), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -555,6 +639,8 @@ int conv_f16x3_init_attributes() {
   SHF_LDS_ATTR((conv_mfma_f16x3_w4d_kernel<false, 4, 2, 1, true>)) SHF_LDS_ATTR((conv_mfma_f16x3_w4d_kernel<false, 4, 1, 1, true>))
   SHF_LDS_ATTR((conv_mfma_f16x3_w4d_kernel<false, 2, 2, 1, true>)) SHF_LDS_ATTR((conv_mfma_f16x3_w4d_kernel<false, 2, 1, 1, true>))
   SHF_LDS_ATTR((conv_mfma_f16x3_k1_kernel<true, 3>)) SHF_LDS_ATTR((conv_mfma_f16x3_k1_kernel<true, 2>)) SHF_LDS_ATTR((conv_mfma_f16x3_k1_kernel<true, 1>))
+  SHF_LDS_ATTR((conv_mfma_f16x3_heads3_kernel<true, 3>)) SHF_LDS_ATTR((conv_mfma_f16x3_heads3_kernel<true, 2>)) SHF_LDS_ATTR((conv_mfma_f16x3_heads3_kernel<true, 1>))
+  SHF_LDS_ATTR((conv_mfma_f16x3_heads3_kernel<false, 3>)) SHF_LDS_ATTR((conv_mfma_f16x3_heads3_kernel<false, 2>)) SHF_LDS_ATTR((conv_mfma_f16x3_heads3_kernel<false, 1>))
   SHF_LDS_ATTR((conv_mfma_f16x3_k1_kernel<false, 3>)) SHF_LDS_ATTR((conv_mfma_f16x3_k1_kernel<false, 2>)) SHF_LDS_ATTR((conv_mfma_f16x3_k1_kernel<false, 1>))
 #undef SHF_LDS_ATTR
   return 0;

@@ -157,10 +157,14 @@ struct Layer {
   int fused_into = -1;     // pool: index of the conv that produces it in the fused path
   int first_src = -1;      // conv: index of the first-layer conv computed inside this conv's halo staging (f16x3)
   int first_dst = -1;      // first-layer conv: index of the conv that absorbs it
+  // the three shared-weight dilated heads (prototxt :480-552): on the dilation-1 layer, the indices of its dilation-2 / -4
+  // siblings (same bottom, same parameter blobs); on those, the index of the dilation-1 layer.  One launch covers the three
+  // when the shapes and the mode allow (conv_f16x3_group_is_heads3).
+  int heads3_d2 = -1, heads3_d4 = -1, heads3_lead = -1;
 };
 
 // the first 8 classes are the instantiations of conv_mfma_f32_kernel, named like rocprofv3 prints them
-enum ProfClass { PC_CONV_MFMA, PC_CONV_MFMA_1 = 1, PC_CONV_MFMA_7 = 7, PC_CONV_F16X3_128, PC_CONV_F16X3_W4, PC_CONV_F16X3_W4_SPLIT, PC_CONV_F16X3_W4_MT2, PC_CONV_F16X3_W4_SPLIT_MT2, PC_CONV_F16X3_64, PC_CONV_F16X3_64_FUSE1, PC_CONV_F16X3_64_D2, PC_CONV_F16X3_64_D4, PC_CONV_F16X3_128_K1, PC_CONV_F16X3_64_K1, PC_CONV_F16X3_PC, PC_CONV_F16X3_W4D_0, PC_CONV_F16X3_W4D_7 = PC_CONV_F16X3_W4D_0 + 7, PC_CONV_FIRST, PC_CONV_DIRECT, PC_POOL, PC_DECONV, PC_TAIL, PC_MERGE, PC_LAYOUT, PC_COUNT };
+enum ProfClass { PC_CONV_MFMA, PC_CONV_MFMA_1 = 1, PC_CONV_MFMA_7 = 7, PC_CONV_F16X3_128, PC_CONV_F16X3_W4, PC_CONV_F16X3_W4_SPLIT, PC_CONV_F16X3_W4_MT2, PC_CONV_F16X3_W4_SPLIT_MT2, PC_CONV_F16X3_64, PC_CONV_F16X3_64_FUSE1, PC_CONV_F16X3_64_D2, PC_CONV_F16X3_64_D4, PC_CONV_F16X3_128_K1, PC_CONV_F16X3_64_K1, PC_CONV_F16X3_PC, PC_CONV_F16X3_W4D_0, PC_CONV_F16X3_W4D_7 = PC_CONV_F16X3_W4D_0 + 7, PC_CONV_F16X3_PCP, PC_CONV_F16X3_K1G, PC_CONV_F16X3_W4D_D2, PC_CONV_F16X3_W4D_D4, PC_CONV_F16X3_H3, PC_CONV_FIRST, PC_CONV_DIRECT, PC_POOL, PC_DECONV, PC_TAIL, PC_MERGE, PC_LAYOUT, PC_COUNT };
 static const char* kProfNames[PC_COUNT] = {"conv_mfma_f32_kernel<3, 1, 128, 8, 16>", "conv_mfma_f32_kernel<3, 2, 128, 8, 16>",
                                            "conv_mfma_f32_kernel<3, 4, 128, 8, 16>", "conv_mfma_f32_kernel<3, 1, 64, 16, 16>",
                                            "conv_mfma_f32_kernel<3, 2, 64, 16, 16>", "conv_mfma_f32_kernel<3, 4, 64, 16, 16>",
@@ -176,6 +180,12 @@ static const char* kProfNames[PC_COUNT] = {"conv_mfma_f32_kernel<3, 1, 128, 8, 1
                                            "conv_mfma_f16x3_w4d_kernel<false, 2, 2, 3, false, 1>", "conv_mfma_f16x3_w4d_kernel<false, 2, 1, 3, false, 1>",
                                            "conv_mfma_f16x3_w4d_kernel<true, 4, 2, 3, false, 1>", "conv_mfma_f16x3_w4d_kernel<true, 4, 1, 3, false, 1>",
                                            "conv_mfma_f16x3_w4d_kernel<true, 2, 2, 3, false, 1>", "conv_mfma_f16x3_w4d_kernel<true, 2, 1, 3, false, 1>",
+                                           // kernels of their own (names: the headline mode's instantiation -- split-format input, three
+                                           // products; the reduced modes run the same templates with other NP / BF arguments): the persistent
+                                           // first pair, the 1x1 GEMM, the family's dilated forms, the three heads in one launch
+                                           "conv_mfma_f16x3_pc_kernel<3, false, true>", "conv_mfma_f16x3_k1_kernel<true, 3>",
+                                           "conv_mfma_f16x3_w4d_kernel<true, 4, 1, 3, false, 2>", "conv_mfma_f16x3_w4d_kernel<true, 4, 1, 3, false, 4>",
+                                           "conv_mfma_f16x3_heads3_kernel<true, 3>",
                                            "conv_first_kernel", "conv_direct_kernel", "maxpool_kernel",
                                            "deconv_depthwise", "detect_tail", "box_merge", "layout"};
 
@@ -218,13 +228,19 @@ struct Prof {
   }
 };
 
-static int f16x3_prof_class(const ConvArgs& a, int nout, const ConvArgs* group = nullptr, int n = 1) {  // which split-fp16 kernel launch_conv_f16x3_group picks
-  if (a.img) return conv_f16x3_uses_pc() && a.in.C == 64 && nout == 64 ? PC_CONV_F16X3_PC : PC_CONV_F16X3_64_FUSE1;
-  if (a.k == 1) return nout % 128 ? PC_CONV_F16X3_64_K1 : PC_CONV_F16X3_128_K1;
-  if (a.dil == 2) return PC_CONV_F16X3_64_D2;
-  if (a.dil == 4) return PC_CONV_F16X3_64_D4;
+// which split-fp16 kernel launch_conv_f16x3_group picks for these arguments -- decided by the launcher's OWN predicates on the
+// actual arguments, so that the 8-wave fallbacks (unaligned views, Cout % 256, bf16 1x1s ...) are not booked under the name of
+// the kernel the knobs would normally select
+static int f16x3_prof_class(const ConvArgs& a, int nout, const ConvArgs* group = nullptr, int n = 1) {
+  const ConvArgs* as = group ? group : &a;
+  if (a.img) {
+    if (!(conv_f16x3_uses_pc() && a.in.C == 64 && nout == 64)) return PC_CONV_F16X3_64_FUSE1;
+    return conv_f16x3_pc_persistent() ? PC_CONV_F16X3_PCP : PC_CONV_F16X3_PC;
+  }
+  if (a.k == 1) return conv_f16x3_group_is_k1_gemm(as, n) ? PC_CONV_F16X3_K1G : (nout % 128 ? PC_CONV_F16X3_64_K1 : PC_CONV_F16X3_128_K1);
+  if (a.dil == 2) return conv_f16x3_group_is_dilated_w4(as, n) ? PC_CONV_F16X3_W4D_D2 : PC_CONV_F16X3_64_D2;
+  if (a.dil == 4) return conv_f16x3_group_is_dilated_w4(as, n) ? PC_CONV_F16X3_W4D_D4 : PC_CONV_F16X3_64_D4;
   if (nout % 128) return PC_CONV_F16X3_64;
-  (void)group; (void)n;
   return PC_CONV_F16X3_128;   // (the dual-tile family reports through SubProf, one record per kernel of the layer)
 }
 
@@ -425,9 +441,6 @@ static int conv_out(int n, int k, int pad, int stride, int dil) {
 
 namespace shf {
 int calib_matrix_pipe(int bf16, int zero_eighths, int constant, int iters, int reps, double* tflops);   // calib.hip
-}
-namespace shf {
-bool conv_f16x3_pc_persistent();   // conv_f16x3.hip (SHF_F16X3_PC_PERSIST)
 }
 using namespace shf;
 
@@ -892,6 +905,29 @@ void shf_net::build(const std::string& text, const char* caffemodel) {
     N.first_src = (int)li;
     F.first_dst = next;
   }
+  // ---- dilation-1 / 2 / 4 convolutions over one bottom with shared parameter blobs: the shared-weight heads
+  for (size_t li = 0; li < layers.size(); ++li) {
+    Layer& A = layers[li];
+    if (A.op != OP_CONV || A.kclass != 0 || A.k != 3 || A.dil != 1 || A.pad != 1 || A.nout != 128 || A.params.empty() ||
+        A.fuse_pool >= 0 || A.first_src >= 0)
+      continue;
+    int d2 = -1, d4 = -1;
+    for (size_t lj = li + 1; lj < layers.size(); ++lj) {
+      Layer& Q = layers[lj];
+      if (Q.op != OP_CONV || Q.kclass != 0 || Q.k != 3 || Q.pad != Q.dil || Q.nout != A.nout || Q.bottoms[0] != A.bottoms[0] ||
+          Q.params.size() != A.params.size() || Q.relu != A.relu || Q.fuse_pool >= 0)
+        continue;
+      bool same = true;
+      for (size_t pi = 0; pi < A.params.size(); ++pi) same = same && Q.params[pi] == A.params[pi];
+      if (!same) continue;
+      if (Q.dil == 2 && d2 < 0) d2 = (int)lj;
+      if (Q.dil == 4 && d4 < 0) d4 = (int)lj;
+    }
+    if (d2 < 0 || d4 < 0) continue;
+    A.heads3_d2 = d2;
+    A.heads3_d4 = d4;
+    layers[d2].heads3_lead = layers[d4].heads3_lead = (int)li;
+  }
   // ---- blobs the fused split-fp16 path keeps in the pre-split activation format: produced by a split-fp16 conv
   //      (or by the pool fused into its epilogue) and read ONLY by convs that run on the 4-wave kernel
   {
@@ -1212,6 +1248,20 @@ void shf_net::forward_ops(bool fused_path, float im_h, float im_w, float im_scal
   if (tail_w_dirty || tail_gen != *wgen) build_tail_weights();
   hipStream_t st = s_override ? s_override : stream;
   Prof& pf = prof_override ? *prof_override : prof;
+  int heads3_done = -1;   // index of a dilation-1 head whose launch also wrote its dilation-2 / -4 siblings
+  // the three shared-weight heads of this unit in one launch (conv_f16x3_h3.h): `a` = the dilation-1 layer's arguments
+  auto try_heads3 = [&](int li, const ConvArgs& a, hipStream_t st_, Prof& pf_) {
+    const Layer& L1 = layers[li];
+    ConvArgs a2, a4;
+    forward_ops(fused_path, im_h, im_w, im_scale, st_, &pf_, L1.heads3_d2, &a2);
+    forward_ops(fused_path, im_h, im_w, im_scale, st_, &pf_, L1.heads3_d4, &a4);
+    if (!conv_f16x3_group_is_heads3(&a, &a2, &a4, 1)) return false;
+    const double fl = 3.0 * conv_flops(L1, blobs[L1.bottoms[0]].shape, blobs[L1.tops[0]].shape);
+    const double by = 4.0 * (blobs[L1.bottoms[0]].count() + 3.0 * blobs[L1.tops[0]].count() + L1.params[0]->count());
+    ProfScope ps(pf_, st_, PC_CONV_F16X3_H3, fl, by);
+    CHECK_RC(launch_conv_f16x3_heads3(&a, &a2, &a4, 1, st_));
+    return true;
+  };
   for (size_t li = 0; li < layers.size(); ++li) {
     if (only_layer >= 0 && (int)li != only_layer) continue;
     Layer& L = layers[li];
@@ -1283,6 +1333,10 @@ void shf_net::forward_ops(bool fused_path, float im_h, float im_w, float im_scal
           a.in = view_of(L.bottoms[0]);
           if (L.kclass == 0 && collect) {
             *collect = a;  // grouped launch: the caller batches this layer over several units
+          } else if (L.kclass == 0 && split16 && L.heads3_lead >= 0 && heads3_done == L.heads3_lead) {
+            // written by the dilation-1 sibling's launch (the three shared-weight heads in one kernel)
+          } else if (L.kclass == 0 && split16 && L.heads3_d2 >= 0 && only_layer < 0 && try_heads3((int)li, a, st, pf)) {
+            heads3_done = (int)li;
           } else if (L.kclass == 0 && split16) {
             if (conv_f16x3_group_is_dual(&a, 1)) {
               SubProf sp{&pf, st, fl, by, {}};
@@ -1893,13 +1947,36 @@ int shf_detect_add_levels(shf_net* net, int n, shf_net** members, const float* c
       CHECK_RC(launch_conv_mfma_group(group.data(), n, st));
     }
   };
+  // the three shared-weight dilated heads of every unit as ONE launch (conv_f16x3_h3.h); false: not that shape / mode
+  int heads3_done = -1;
+  std::vector<ConvArgs> g2(n), g4(n);
+  auto launch_group_heads3 = [&](size_t li, hipStream_t st) {
+    Layer& L = net->layers[li];
+    double fl = 0, by = 4.0 * L.params[0]->count();
+    for (int m = 0; m < n; ++m) {
+      shf_net* mb = members[m];
+      mb->forward_ops(true, (float)im_h[m], (float)im_w[m], im_scale[m], st, &net->prof, (int)li, &group[m]);
+      mb->forward_ops(true, (float)im_h[m], (float)im_w[m], im_scale[m], st, &net->prof, L.heads3_d2, &g2[m]);
+      mb->forward_ops(true, (float)im_h[m], (float)im_w[m], im_scale[m], st, &net->prof, L.heads3_d4, &g4[m]);
+      fl += 3.0 * conv_flops(mb->layers[li], mb->blobs[mb->layers[li].bottoms[0]].shape, mb->blobs[mb->layers[li].tops[0]].shape);
+      by += 4.0 * (mb->blobs[mb->layers[li].bottoms[0]].count() + 3.0 * mb->blobs[mb->layers[li].tops[0]].count());
+    }
+    if (!group[0].wsplit16h || !conv_f16x3_group_is_heads3(group.data(), g2.data(), g4.data(), n)) return false;
+    ProfScope ps(net->prof, st, PC_CONV_F16X3_H3, fl, by);
+    CHECK_RC(launch_conv_f16x3_heads3(group.data(), g2.data(), g4.data(), n, st));
+    return true;
+  };
   for (size_t li = 0; li < net->layers.size(); ++li) {
     Layer& L = net->layers[li];
     if (early_start && (int)li == first_feat_writer)
       for (int m = 0; m < n; ++m)
         if (members[m]->logits_done) HIP_THROW(hipStreamWaitEvent(net->stream, members[m]->logits_done, 0));
     if (L.op == OP_SKIP) continue;
-    if (L.op == OP_CONV && L.kclass == 0) {
+    if (L.op == OP_CONV && L.kclass == 0 && L.heads3_lead >= 0 && heads3_done == L.heads3_lead) {
+      continue;   // written by the dilation-1 sibling's launch
+    } else if (L.op == OP_CONV && L.kclass == 0 && L.heads3_d2 >= 0 && launch_group_heads3(li, cs)) {
+      heads3_done = (int)li;
+    } else if (L.op == OP_CONV && L.kclass == 0) {
       launch_group_conv(li, cs);
     } else if (L.op == OP_DECONV && n > 1) {
       // the units' depthwise up-samplings as one launch (ten serial 5..60-us launches otherwise)
@@ -2291,10 +2368,6 @@ int shf_prof_only(shf_net* net, int cls) {
 }
 int shf_prof_num_classes(shf_net*) { return PC_COUNT; }
 const char* shf_prof_class_name(shf_net*, int cls) {
-  if (cls == PC_CONV_F16X3_PC && shf::conv_f16x3_pc_persistent()) return "conv_mfma_f16x3_pc_kernel<3, false, true>";
-  if (cls == PC_CONV_F16X3_128_K1 && shf::conv_f16x3_k1_gemm_shape(512, 256)) return "conv_mfma_f16x3_k1_kernel<true, 3>";
-  if (cls == PC_CONV_F16X3_64_D2 && shf::conv_f16x3_dilated_uses_w4()) return "conv_mfma_f16x3_w4d_kernel<true, 4, 1, 3, false, 2>";
-  if (cls == PC_CONV_F16X3_64_D4 && shf::conv_f16x3_dilated_uses_w4()) return "conv_mfma_f16x3_w4d_kernel<true, 4, 1, 3, false, 4>";
   return (cls >= 0 && cls < PC_COUNT) ? kProfNames[cls] : nullptr;
 }
 int shf_prof_read(shf_net* net, int cls, int64_t* launches, double* total_ms, double* flops, double* bytes) {

@@ -74,6 +74,7 @@ int conv_init_attributes();
 // split-fp16 (3 x fp16 MFMA, fp32-class accuracy) variant for 3x3 / dilation 1 layers
 bool conv_f16x3_eligible(int Cin, int Cout, int k, int pad, int dil);
 bool conv_f16x3_uses_pc();         // fused first pair: producer/consumer kernel (SHF_F16X3_PC=0 disables)
+bool conv_f16x3_pc_persistent();   // ... as one block per CU walking the tiles (SHF_F16X3_PC_PERSIST)
 bool conv_f16x3_uses_w4(int Cin);  // Cout % 128 == 0, 3x3 / dilation 1 layers: the 4-wave dual-tile family (Cin >= 128) or the 8-wave kernel
 int conv_f16x3_w4_mt(const ConvArgs* as, int n);  // 4-wave family: 16-row (4) or 8-row (2) tiles for this launch
 int conv_f16x3_init_attributes();
@@ -86,6 +87,9 @@ bool conv_f16x3_dilated_uses_w4();   // the dilated heads (dilation 2 / 4) run o
 bool conv_f16x3_group_is_dilated_w4(const ConvArgs* as, int n);
 bool conv_f16x3_k1_gemm_shape(int Cin, int Cout);   // a 1x1 layer of this shape runs on the GEMM kernel (SHF_F16X3_K1_GEMM): the family's pack, split-format input
 bool conv_f16x3_group_is_k1_gemm(const ConvArgs* as, int n);
+// the three shared-weight dilated heads (dilation 1 / 2 / 4, same input, same weights) as ONE launch (conv_f16x3_h3.h; SHF_F16X3_HEADS3)
+bool conv_f16x3_group_is_heads3(const ConvArgs* a1, const ConvArgs* a2, const ConvArgs* a4, int n);
+int launch_conv_f16x3_heads3(const ConvArgs* a1, const ConvArgs* a2, const ConvArgs* a4, int n, hipStream_t s);
 void pack_conv_weights_split16(const float* w, int Cout, int Cin, int k, void* dst, bool bf = false);
 // first layer (64, 27) as the B operand of v_mfma_f32_32x32x16_f16: [n 2][kk 2][hi/lo 2][lane 64][8 halfs], K padded 27 -> 32
 constexpr size_t kFirstConvFragHalfs = 2 * 2 * 2 * 64 * 8;

@@ -89,6 +89,45 @@ def test_conv_mfma(cin, cout, k, dil, h, w, relu):
         assert (go["c1"] < 0).any()
 
 
+def shared_conv_layer(name, bottom, nout, dil):
+    return ('layer { name: "%s" type: "Convolution" bottom: "%s" top: "%s" param { name: "hw" } param { name: "hb" } '
+            'convolution_param { num_output: %d kernel_size: 3 pad: %d dilation: %d } }\n'
+            'layer { name: "%s_relu" type: "ReLU" bottom: "%s" top: "%s" }\n' % (name, bottom, name, nout, dil, dil, name, name, name))
+
+
+@pytest.mark.parametrize("cin,h,w", [
+    (128, 22, 26),      # the detector's shape class, ragged tiles in both directions
+    (128, 5, 6),        # a map smaller than the dilation-4 halo
+    (128, 64, 48),      # whole 8 x 16 tiles only (the `interior` fast path)
+    (160, 17, 33),      # Cin = 10 sixteen-channel chunks
+])
+def test_three_shared_weight_dilated_heads_one_launch(cin, h, w, conv_mode):
+    """head_1 / head_2 / head_4 (models/test_different_dilation_template.prototxt:480-552: same bottom, shared `head_w` /
+    `head_b`, dilation 1 / 2 / 4) run as ONE launch in the split-fp16 modes (conv_f16x3_h3.h): each against the oracle, and
+    through the runtime's profile counters the launch really is the fused kernel."""
+    txt = H.single_layer_net(conv_layer("c0", "data", cin, 3, 1) + shared_conv_layer("h1", "c0", 128, 1) +
+                             shared_conv_layer("h2", "c0", 128, 2) + shared_conv_layer("h4", "c0", 128, 4), 3, h, w)
+    gnet, onet = H.make_pair(P.parse(txt), seed=9)
+    rng = np.random.default_rng(6)
+    for name in ("c0", "h1"):
+        onet.params[name][1][...] = rng.normal(0, 0.5, onet.params[name][1].shape).astype(np.float32)
+    assert onet.params["h4"][1] is onet.params["h1"][1] or np.array_equal(onet.params["h4"][1], onet.params["h1"][1])
+    H.load_params(gnet, onet.params)
+    data = rng.normal(0, 1, (1, 3, h, w)).astype(np.float32)
+    gnet.prof_enable(True)
+    gnet.prof_reset()
+    go, oo = H.run_both(gnet, onet, data, np.array([[h, w, 1]], np.float32))
+    prof = gnet.prof_read()
+    gnet.prof_enable(False)
+    for name in ("h1", "h2", "h4"):
+        a, b = gnet.blobs[name].data, onet.blobs[name].data
+        assert a.shape == b.shape == (1, 128, h, w), name
+        assert H.rel_err(a, b) < ACT_TOL, name
+    assert not np.array_equal(gnet.blobs["h1"].data, gnet.blobs["h2"].data)
+    fused = prof.get("conv_mfma_f16x3_heads3_kernel<true, 3>", {}).get("launches", 0)
+    assert fused == (1 if conv_mode == "f16x3" else 0), prof.keys()
+
+
 def test_conv_identity_is_transpose_detecting():
     """A = I with an ASYMMETRIC weight pattern: catches swapped rows/cols in the MFMA epilogue."""
     h, w, c = 8, 16, 64
@@ -578,7 +617,7 @@ np.savez(sys.argv[1], voted=voted, raw=buf[:n].cpu().numpy())
                       ("single_tile", {"SHF_F16X3_W4D_NTILE": "1"}), ("dual_tile", {"SHF_F16X3_W4D_NTILE": "2"}),
                       ("rows8", {"SHF_F16X3_W4_MT": "2"}), ("rows16", {"SHF_F16X3_W4_MT": "4"}), ("no_pc", {"SHF_F16X3_PC": "0"}),
                       ("no_dil_w4", {"SHF_F16X3_DIL_W4": "0"}), ("pc_no_tile_table", {"SHF_F16X3_PC_TAB": "0"}),
-                      ("no_k1_gemm", {"SHF_F16X3_K1_GEMM": "0"}),
+                      ("no_k1_gemm", {"SHF_F16X3_K1_GEMM": "0"}), ("three_head_launches", {"SHF_F16X3_HEADS3": "0"}),
                       ("pc_block_per_tile", {"SHF_F16X3_PC_PERSIST": "0"})):
         out = str(tmp_path / (name + ".npz"))
         e = dict(os.environ, PYTHONPATH=root, **env)
@@ -587,7 +626,7 @@ np.savez(sys.argv[1], voted=voted, raw=buf[:n].cpu().numpy())
         outs[name] = np.load(out)
     assert len(outs["default"]["voted"]) > 0 and len(outs["default"]["raw"]) > len(outs["default"]["voted"])
     # same arithmetic, different data path: bit-identical, merged and un-merged
-    for name in ("no_split_act", "single_tile", "dual_tile", "rows8", "rows16", "pc_block_per_tile", "pc_no_tile_table"):
+    for name in ("no_split_act", "single_tile", "dual_tile", "rows8", "rows16", "pc_block_per_tile", "pc_no_tile_table", "three_head_launches"):
         for key in ("voted", "raw"):
             assert outs[name][key].shape == outs["default"][key].shape and np.array_equal(outs[name][key], outs["default"][key]), (name, key)
     # other kernels for the same layers: fp32-class agreement of the rows that go into the merge (a row may cross the
