@@ -5,7 +5,7 @@ import os
 import re
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-FILES = ["conv.hip", "conv_f16x3.hip", "conv_f16x3_types.h", "conv_f16x3_8w.h", "conv_f16x3_w4d.h", "conv_f16x3_pc.h", "conv_f16x3_k1.h", "conv_common.h",
+FILES = ["conv.hip", "conv_f16x3.hip", "conv_f16x3_types.h", "conv_f16x3_8w.h", "conv_f16x3_w4d.h", "conv_f16x3_pc.h", "conv_f16x3_k1.h", "conv_f16x3_h3.h", "conv_common.h",
          "misc.hip", "tail.hip", "merge.hip", "pre.hip", "shf_internal.h"]
 
 

@@ -180,6 +180,13 @@ def main():
     a = pcs[-1]
     conv_idx = [i for i in range(a, len(names)) if "conv_mfma" in names[i]]
     layers = conv_layers_of_the_bench_image()
+    if any("heads3_kernel" in names[i] for i in conv_idx):
+        # the three shared-weight dilated heads are ONE launch (conv_f16x3_h3.h): one row, the input counted once
+        hs = [q for q, l in enumerate(layers) if l[0] in ("head_1", "head_2", "head_4")]
+        assert len(hs) == 3 and hs[2] == hs[0] + 2
+        h0 = layers[hs[0]]
+        merged = ["head_1+head_2+head_4", h0[1], h0[2], h0[3], h0[4], sum(layers[q][5] for q in hs), 4.0 * h0[4] * (h0[1] + 3 * h0[2])]
+        layers = layers[:hs[0]] + [merged] + layers[hs[2] + 1:]
     # A layer of the dual-tile family may be TWO consecutive launches: two tiles per block for the whole rounds, then
     # single tiles for the rest (same <IN_SPLIT, rows>).  Merge such pairs while there are more dispatches than layers.
     import re
@@ -202,11 +209,12 @@ def main():
         v = [cval(c, i) for i in g]
         return None if any(x is None for x in v) else sum(v)
     rows = []
-    for (lname, cin, cout, k, px, fl), g in zip(layers, groups):
+    for lrec, g in zip(layers, groups):
+        lname, cin, cout, k, px, fl = lrec[:6]
         i = g[0]
         us = sum(dur[x] for x in g)
         tf = fl / (us * 1e-6) / 1e12
-        alg_bytes = 4.0 * px * (cin + cout)   # input + output once, 4 B per element (weights: < 10 MB, L2-resident)
+        alg_bytes = lrec[6] if len(lrec) > 6 else 4.0 * px * (cin + cout)   # input + output once, 4 B per element (weights: < 10 MB, L2-resident)
         hbm = None
         if gsum("FETCH_SIZE", g) is not None and gsum("WRITE_SIZE", g) is not None:
             hbm = (2.0 * gsum("FETCH_SIZE", g) + gsum("WRITE_SIZE", g)) * 1024.0

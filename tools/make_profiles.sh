@@ -1,6 +1,6 @@
 #!/bin/bash
 # Regenerates the evidence under profiles/ on a GPU box (run from the repo root, e.g. via gpurun):
-#   tools/make_profiles.sh r04
+#   tools/make_profiles.sh r05
 # 1. rocprofv3 --kernel-trace --stats of the default bench command  -> <tag>_bench_kernel_stats.csv
 #    + the JSON line bench.py printed in that run                    -> <tag>_bench_under_rocprof.json
 # 2. counter passes, each its own run with --kernel-trace only (never with --stats / --sys-trace):
@@ -12,7 +12,7 @@
 # Everything is written under gpurun_out/prof_<tag>/ and the summaries copied to gpurun_out/profiles_<tag>/
 # (gpurun merges gpurun_out/ back; copy from there into profiles/ and commit).
 set -u
-tag=${1:-r04}
+tag=${1:-r05}
 root=$(pwd)
 out=$root/gpurun_out/prof_$tag
 dst=$root/gpurun_out/profiles_$tag
