@@ -81,6 +81,28 @@ void pack_conv_weights_split16(const float* w, int Cout, int Cin, int k, void* d
       }
 }
 
+// The fused first pair's pack (conv_f16x3_pc.h): (Cout,Cin,3,3) fp32 -> [Cin/32][ky][kx][Cout][8 x 8 halfs] fp16, 128-byte rows
+// WITHOUT padding; the eight 16-byte pieces of cout row r -- hi k 0-7, 8-15, 16-23, 24-31, then lo (x 2^11) the same -- sit at
+// slot (piece + (r >> 1)) mod 8, so that the 16 lanes of a ds_read_b128 group (16 consecutive rows, one logical piece)
+// cover all 16 bank groups.  The 6 KB of LDS this saves against the 144-byte rows pay for the halo rows' padding there.
+size_t split16r_conv_weight_halfs(int Cout, int Cin, int k) { return (size_t)Cout * (Cin / 32) * k * k * 64; }
+void pack_conv_weights_split16r(const float* w, int Cout, int Cin, int k, void* dst_, bool bf) {
+  _Float16* dst = (_Float16*)dst_;
+  const int taps = k * k;
+  memset(dst_, 0, split16r_conv_weight_halfs(Cout, Cin, k) * 2);
+  for (int co = 0; co < Cout; ++co)
+    for (int ci = 0; ci < Cin; ++ci)
+      for (int t = 0; t < taps; ++t) {
+        const float x = w[((size_t)co * Cin + ci) * taps + t];
+        const _Float16 h = bf ? host_bf16_as_half(x) : (_Float16)x;
+        const _Float16 l = bf ? (_Float16)0 : (_Float16)((x - (float)h) * f16x3::LO_SCALE);
+        const size_t row = (((size_t)(ci / 32) * taps + t) * Cout + co) * 64;
+        const int kk = ci % 32, rot = (co >> 1) & 7;
+        dst[row + (((kk >> 3) + rot) & 7) * 8 + (kk & 7)] = h;
+        dst[row + ((4 + (kk >> 3) + rot) & 7) * 8 + (kk & 7)] = l;
+      }
+}
+
 size_t split16h_conv_weight_halfs(int Cout, int Cin, int k) { return (size_t)Cout * (Cin / 16) * k * k * 32; }
 
 // (Cout,Cin,3,3) fp32 -> [Cin/16][ky][kx][Cout][4 x 8 halfs] fp16: 64-B rows, NO padding (every byte of the pack is
@@ -334,11 +356,13 @@ static int launch_f16x3_t(const ConvArgs* as, int n, hipStream_t s) {
   hipMemset(dbg_dev, 0, 16 * 5 * 8);
   p.dbg = dbg_dev;
 #endif
-  if (FUSE1 && BN == 64 && conv_f16x3_uses_pc() && vec_ok && p.Cin == 64 && p.Cout == 64 && p.w1f) {
-    // two halo tiles (both channel chunks of conv1_1's output) + the weight double buffer + the image patch
+  if (FUSE1 && BN == 64 && conv_f16x3_uses_pc() && vec_ok && p.Cin == 64 && p.Cout == 64 && p.w1f && a.wsplit16r) {
+    p.wp = (const float*)a.wsplit16r;   // its own pack: 128-byte rotated rows (pack_conv_weights_split16r)
+    // two halo tiles (both channel chunks of conv1_1's output; rows of 18 pixels x 144 B + 96 B) + the weight double buffer
+    // (128-byte rows) + the image patch
     constexpr size_t HPP = (HP + 31) / 32 * 32;
-    // (+ conv1_1's weight fragments 8 KiB, its 64 biases, the row-tile counter: 162 512 B of the 160 KiB)
-    const size_t lds_pc = 2 * (size_t)HP * ROWB + 2 * 3 * (size_t)BN * ROWB + (3 * (TH + 4) * (TW + 4) + 8) * sizeof(float) + HPP +
+    // (+ conv1_1's weight fragments 8 KiB, its 64 biases, the row-tile counter)
+    const size_t lds_pc = 2 * (size_t)(TH + 2) * ((TW + 2) * ROWB + 96) + 2 * 3 * (size_t)BN * 128 + (3 * (TH + 4) * (TW + 4) + 8) * sizeof(float) + HPP +
                           BN * sizeof(float) + 8192 + 64 * sizeof(float) + 16 + 64 + 300 * 4;
 if (lds_pc > 160 * 1024) { set_error("conv f16x3: the fused first pair does not fit the LDS"); return -1; }
     if (knobs().pc_persist) {

@@ -45,16 +45,29 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
   PC_T();
   constexpr int BN = 64, MT = 2;
   constexpr int PW = TW + 4, PH = TH + 4;
-  constexpr int HPP = (HP + 31) / 32 * 32;          // 352: tile rows padded to whole 32-row MFMA tiles, so that
-                                                    // conv1_1's epilogue stores need no per-row guard
-  unsigned char* As0 = smem;                        // [HP][ROWB] channels  0..31 of conv1_1's output
-  unsigned char* As1 = smem + HP * ROWB;            // [HP][ROWB] channels 32..63 (the last row tile's stores are guarded)
-  unsigned char* Bs = smem + 2 * HP * ROWB;         // [2][3][BN][ROWB]
+  constexpr int HPP = (HP + 31) / 32 * 32;          // 352: tile rows padded to whole 32-row MFMA tiles
+  // HALO TILES (round 5): a pixel is ROWB = 144 B ([hi 32 | lo 32 | 16 B]: eight consecutive pixels of a row fall on eight
+  // different 16-byte bank groups), a halo ROW is 18 pixels + 96 B = 2 688 B = 128 mod 256: the 16 lanes of a
+  // ds_read_b128 group are 8 pixels of row y and 8 of row y + 1 (row_to_pixel), and with the plain 18 x 144 = 2 592 B rows
+  // (32 mod 256) the second row's groups fell two slots beside the first's -- a 2-way conflict on every A-fragment read
+  // (SQ_LDS_BANK_CONFLICT 0.32 of the kernel's LDS cycles in rounds 3-4, and the consumers' K loop is LDS-bound: 8 KiB of
+  // fragments per 12 MFMAs and wave).  The 3.4 KB the padding costs come from the weight rows (below).
+  constexpr int AROW = HTW * ROWB + 96;             // 2 688 B per halo row
+  constexpr int AT_B = HTH * AROW;                  // 48 384 B per halo tile
+  static_assert(AROW % 256 == 128, "consecutive halo rows on complementary halves of the bank row");
+  // WEIGHT ROWS are 128 B without padding (the 8-wave kernel's pack has 144-byte rows): the eight 16-byte pieces of cout
+  // row r -- hi k 0-7 .. 24-31, lo k 0-7 .. 24-31 -- are rotated by (r >> 1) mod 8 (pack_conv_weights_split16r), so the 16
+  // lanes of a B-fragment read (16 consecutive rows, one logical piece) still cover all 16 bank groups; a tap slab is
+  // 8 KiB = 8 DMA pieces, a stage 24 = six rounds of the four producer waves with no ragged one.
+  constexpr int WROWB = 128;
+  unsigned char* As0 = smem;                        // [HTH][AROW] channels  0..31 of conv1_1's output
+  unsigned char* As1 = smem + AT_B;                 // [HTH][AROW] channels 32..63
+  unsigned char* Bs = smem + 2 * AT_B;              // [2][3][BN][WROWB]
   // [3][PH][PW] image patch, already split: fp16 hi in the low half of a dword, fp16 lo (x 2^11) in the high half (bf16 mode:
   // the bf16 pattern | 0) -- conv1_1's fragments are then gathered with one byte permute per register, no conversion
   // (round 4; the conversions used to be redone for every fragment element: ~200 vector instructions per row tile).
   // (+ 8 dwords: half-wave 1's zero-weight slots read one element past a tap)
-  unsigned* patch = (unsigned*)(Bs + 2 * 3 * BN * ROWB);
+  unsigned* patch = (unsigned*)(Bs + 2 * 3 * BN * WROWB);
   constexpr int PATCH_DW = 3 * PH * PW + 8;
   unsigned char* valid = (unsigned char*)(patch + PATCH_DW);  // [HPP] halo pixel inside the image? (0 in the padding)
   float* bias2L = (float*)(valid + HPP);                          // [BN] conv1_2's biases (read by the register epilogue)
@@ -137,12 +150,12 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
   const unsigned long long t_dec = __builtin_amdgcn_s_memtime();
 #endif
 
-  constexpr int SLAB_B = BN * ROWB;          // 9 KiB
-  constexpr int PCS_SLAB = SLAB_B / 1024;    // 9
-  constexpr int PCS = 3 * PCS_SLAB;          // 27 one-KiB pieces per stage
-  const size_t slab = (size_t)p.Cout * 72;
+  constexpr int SLAB_B = BN * WROWB;         // 8 KiB
+  constexpr int PCS_SLAB = SLAB_B / 1024;    // 8
+  constexpr int PCS = 3 * PCS_SLAB;          // 24 one-KiB pieces per stage
+  const size_t slab = (size_t)p.Cout * (WROWB / 2);
   const _Float16* wbase = (const _Float16*)p.wp;
-  auto dma_w = [&](int stage, int buf) {     // producer waves only: 7 rounds of 4 pieces (the last one ragged)
+  auto dma_w = [&](int stage, int buf) {     // producer waves only: 6 rounds of 4 pieces
     unsigned dma_l16 = (unsigned)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) * 16u;   // (formed here: not kept across the stages)
     asm volatile("" : "+v"(dma_l16));
     // (opaque base: the 42 source addresses of a tile are formed where they are used, on the scalar unit -- as loop
@@ -320,7 +333,7 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) v[r] = ok ? v[r] : 0.f;
         }
-        unsigned char* row = (n ? As1 : As0) + (m * 32 + i1) * ROWB + kh1 * 8;
+        unsigned char* row = (n ? As1 : As0) + hy * AROW + hx * ROWB + kh1 * 8;   // (row_ok lanes: hp is their own pixel)
         float2 sh[4], sl[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -372,11 +385,12 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
   int dy, px;
   row_to_pixel(i, dy, px);
   const int wm = wave_u & 3;
-  int a_off[MT], b_off[2];
+  int a_off[MT], b_off[4];
 #pragma unroll
-  for (int t = 0; t < MT; ++t) a_off[t] = ((wm * 2 * MT + t * 2 + dy) * HTW + px) * ROWB + kh * 16;
+  for (int t = 0; t < MT; ++t) a_off[t] = (wm * 2 * MT + t * 2 + dy) * AROW + px * ROWB + kh * 16;
+  // B fragments: cout row t * 32 + i, logical piece kh + 2 (k half) [+ 4: lo] at slot (piece + (row >> 1)) & 7
 #pragma unroll
-  for (int t = 0; t < 2; ++t) b_off[t] = (t * 32 + i) * ROWB + kh * 16;
+  for (int x = 0; x < 4; ++x) b_off[x] = i * WROWB + ((kh + 2 * x + (i >> 1)) & 7) * 16;
   f32x16 accm[MT][2], accc[MT][2];
 #pragma unroll
   for (int a = 0; a < MT; ++a)
@@ -386,12 +400,12 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
       for (int r = 0; r < 16; ++r) { accm[a][c][r] = 0.f; accc[a][c][r] = 0.f; }
 
   auto mma_stage = [&](const unsigned char* Atile, int ky, int buf) {
-    const unsigned char* Arow = Atile + (ky * HTW) * ROWB;
-    const unsigned char* Bst = Bs + buf * (3 * BN * ROWB);
+    const unsigned char* Arow = Atile + ky * AROW;
+    const unsigned char* Bst = Bs + buf * (3 * SLAB_B);
     half8 fa[2][2 * MT], fb[2][4];
     auto load_frag = [&](int s_, half8* a, half8* bf) {
       const unsigned char* Ap = Arow + (s_ >> 1) * ROWB + (s_ & 1) * 32;
-      const unsigned char* Bp = Bst + (s_ >> 1) * (BN * ROWB) + (s_ & 1) * 32;
+      const unsigned char* Bp = Bst + (s_ >> 1) * SLAB_B;
 #pragma unroll
       for (int t = 0; t < MT; ++t) {
         a[2 * t] = *(const half8*)(Ap + a_off[t]);
@@ -399,8 +413,8 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
       }
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
-        bf[2 * t] = *(const half8*)(Bp + b_off[t]);
-        bf[2 * t + 1] = *(const half8*)(Bp + b_off[t] + 64);
+        bf[2 * t] = *(const half8*)(Bp + t * (32 * WROWB) + b_off[s_ & 1]);
+        bf[2 * t + 1] = *(const half8*)(Bp + t * (32 * WROWB) + b_off[2 + (s_ & 1)]);
       }
     };
     load_frag(0, fa[0], fb[0]);

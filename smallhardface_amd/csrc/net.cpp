@@ -108,8 +108,8 @@ struct HostBuf {
 struct ParamBlob {
   std::vector<int> shape;
   std::vector<float> host;
-  DevBuf raw, packed, packed16, packed16h, first_t, first_frag;
-  DevBuf packed16b, packed16hb, first_frag_b;   // the same three packs for conv mode "bf16" (built on first use of the mode)
+  DevBuf raw, packed, packed16, packed16h, packed16r, first_t, first_frag;   // (packed16r: the fused first pair's rotated-row pack)
+  DevBuf packed16b, packed16hb, packed16rb, first_frag_b;   // the same three packs for conv mode "bf16" (built on first use of the mode)
   bool bf_stale = true;                         // ... and whether they hold the current weights
   float wscale_inv = 1.f;  // packed16h: the power of two its weights were scaled by, inverted
   bool dirty = true;
@@ -1162,6 +1162,12 @@ void shf_net::commit_params(int li) {
         pack_conv_weights_split16(p.host.data(), p.shape[0], p.shape[1], p.shape[2], sp.data(), true);
         p.packed16b.ensure(sp.size() * 2);
         HIP_THROW(hipMemcpy(p.packed16b.p, sp.data(), sp.size() * 2, hipMemcpyHostToDevice));
+        if (L.first_src >= 0 && p.shape[0] == 64 && p.shape[1] == 64) {   // the fused first pair's own pack
+          std::vector<uint16_t> sr(split16r_conv_weight_halfs(p.shape[0], p.shape[1], p.shape[2]));
+          pack_conv_weights_split16r(p.host.data(), p.shape[0], p.shape[1], p.shape[2], sr.data(), true);
+          p.packed16rb.ensure(sr.size() * 2);
+          HIP_THROW(hipMemcpy(p.packed16rb.p, sr.data(), sr.size() * 2, hipMemcpyHostToDevice));
+        }
         if (wants_family_pack(L, p)) {
           std::vector<uint16_t> sh(split16h_conv_weight_halfs(p.shape[0], p.shape[1], p.shape[2]));
           pack_conv_weights_split16h(p.host.data(), p.shape[0], p.shape[1], p.shape[2], sh.data(), true);
@@ -1181,6 +1187,12 @@ void shf_net::commit_params(int li) {
         pack_conv_weights_split16(p.host.data(), p.shape[0], p.shape[1], p.shape[2], sp.data());
         p.packed16.ensure(sp.size() * 2);
         HIP_THROW(hipMemcpy(p.packed16.p, sp.data(), sp.size() * 2, hipMemcpyHostToDevice));
+        if (L.first_src >= 0 && p.shape[0] == 64 && p.shape[1] == 64) {   // the fused first pair's own pack
+          std::vector<uint16_t> sr(split16r_conv_weight_halfs(p.shape[0], p.shape[1], p.shape[2]));
+          pack_conv_weights_split16r(p.host.data(), p.shape[0], p.shape[1], p.shape[2], sr.data());
+          p.packed16r.ensure(sr.size() * 2);
+          HIP_THROW(hipMemcpy(p.packed16r.p, sr.data(), sr.size() * 2, hipMemcpyHostToDevice));
+        }
         p.split_stale = false;
         if (wants_family_pack(L, p)) {
           std::vector<uint16_t> sh(split16h_conv_weight_halfs(p.shape[0], p.shape[1], p.shape[2]));
@@ -1281,6 +1293,7 @@ void shf_net::forward_ops(bool fused_path, float im_h, float im_w, float im_scal
                              conv_f16x3_eligible(ib.shape[1], L.nout, L.k, L.pad, L.dil);
         a.wsplit16 = split16 ? (bf ? L.params[0]->packed16b.p : L.params[0]->packed16.p) : nullptr;
         a.wsplit16h = split16 ? (bf ? L.params[0]->packed16hb.p : L.params[0]->packed16h.p) : nullptr;
+        a.wsplit16r = split16 ? (bf ? L.params[0]->packed16rb.p : L.params[0]->packed16r.p) : nullptr;
         a.wscale_inv = bf ? 1.f : L.params[0]->wscale_inv;
         a.bf16 = bf && split16 ? 1 : 0;
         if (fused_path && L.fuse_pool >= 0) {

@@ -31,6 +31,7 @@ struct ConvArgs {
   const float* wraw = nullptr;     // Caffe layout (Cout,Cin,k,k) for the direct kernels
   const float* wfirst = nullptr;   // first layer: weights transposed to [Cin*k*k][Cout]
   const void* wsplit16 = nullptr;  // split-fp16 pack [Cin/32][tap][Cout][hi32|lo32] (conv_f16x3.hip)
+  const void* wsplit16r = nullptr; // fused first pair (conv_f16x3_pc.h): [Cin/32][tap][Cout][8 rotated 16-byte pieces], 128-byte rows
   const void* wsplit16h = nullptr; // dual-tile 4-wave kernel: [Cin/16][tap][Cout][hi16|lo16], lo UNSCALED, weights x 1/wscale_inv
   float wscale_inv = 1.f;          // ... and the power of two the epilogue multiplies back
   const float* bias = nullptr;     // [Cout] or null
@@ -81,6 +82,8 @@ int conv_f16x3_init_attributes();
 int launch_conv_f16x3_group(const ConvArgs* as, int n, hipStream_t s);
 size_t split16_conv_weight_halfs(int Cout, int Cin, int k);
 size_t split16h_conv_weight_halfs(int Cout, int Cin, int k);
+size_t split16r_conv_weight_halfs(int Cout, int Cin, int k);
+void pack_conv_weights_split16r(const float* w, int Cout, int Cin, int k, void* dst, bool bf = false);
 float pack_conv_weights_split16h(const float* w, int Cout, int Cin, int k, void* dst, bool bf = false);  // returns 1 / scale
 bool conv_f16x3_group_is_dual(const ConvArgs* as, int n);
 bool conv_f16x3_dilated_uses_w4();   // the dilated heads (dilation 2 / 4) run on the dual-tile family's DIL form (SHF_F16X3_DIL_W4)
