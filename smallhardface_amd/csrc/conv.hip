@@ -393,8 +393,6 @@ static int launch_mfma_t(const ConvArgs* as, int n, hipStream_t s) {
   p.in_stride = a.in.cstride; p.out_stride = a.out.cstride;
   p.dil = a.dil; p.relu = a.relu | (a.pool.p && !a.write_main ? 8 : 0);
   p.pool_stride = a.pool.p ? a.pool.cstride : 0;
-  static const int dbg_flags = getenv("SHF_CONV_DBGFLAGS") ? atoi(getenv("SHF_CONV_DBGFLAGS")) : 0;  // experiments only
-  p.relu |= dbg_flags;
   p.nct = p.Cout / BN;
   p.nmem = n;
   for (int i = 0; i < MAX_GROUP; ++i) p.tile_starts[i] = 0x7fffffff;
@@ -444,8 +442,6 @@ static int launch_mfma_t(const ConvArgs* as, int n, hipStream_t s) {
   p.dbg = dbg_dev;
 #endif
   size_t lds = mfma_lds_bytes(KS, DIL, BN, TH, TW);
-  static const int lds_pad = getenv("SHF_CONV_LDS_PAD") ? atoi(getenv("SHF_CONV_LDS_PAD")) : 0;  // tuning knob
-  if (lds + lds_pad <= 160 * 1024) lds += lds_pad;
   const long long blocks = tiles * p.nct;
   hipLaunchKernelGGL((conv_mfma_f32_kernel<KS, DIL, BN, TH, TW>), dim3((unsigned)blocks), dim3(256), lds, s, p);
   SHF_HIP_OK(hipGetLastError());

@@ -146,12 +146,9 @@ struct Knobs {
   int w4d_ntile;       // SHF_F16X3_W4D_NTILE: 0 auto (hybrid launches), 1 / 2 force single- / two-tile blocks
   int pc_tab;          // SHF_F16X3_PC_TAB: 0 = the persistent first pair decodes its tiles one by one (the path launches with more than
                        // 300 tiles per block take anyway); bit-identical
-  int dil_w4;          // SHF_F16X3_DIL_W4: 1 (default) = the dilated heads on the dual-tile family's DIL form, 0 = the 8-wave kernel
   int heads3;          // SHF_F16X3_HEADS3: 1 (default) = the three shared-weight dilated heads as ONE launch (conv_f16x3_h3.h), 0 = one
                        // launch per head; bit-identical
-  int k1_gemm;         // SHF_F16X3_K1_GEMM: 1 (default) = 1x1 layers with Cout % 256 == 0 on the GEMM kernel (conv_f16x3_k1.h), 0 = the
-                       // 8-wave kernel's KS = 1 form
-  bool pc, dilated, k1, scalar_epilogue;   // SHF_F16X3_PC, SHF_F16X3_DILATED, SHF_F16X3_1X1 (default on), SHF_CONV_SCALAR_EPILOGUE (off)
+  bool pc;             // SHF_F16X3_PC (default on): the fused first pair on the producer / consumer kernel
   bool pc_persist;     // SHF_F16X3_PC_PERSIST (default on): the fused first pair as one block per CU walking the tiles
   int cus;
 };
@@ -162,15 +159,10 @@ const Knobs& knobs() {
     q.w4_mode = env_int("SHF_F16X3_W4", -1);
     q.w4_mt = env_int("SHF_F16X3_W4_MT", 0);
     q.w4d_ntile = env_int("SHF_F16X3_W4D_NTILE", 0);
-    q.dil_w4 = env_int("SHF_F16X3_DIL_W4", 1);
-    q.k1_gemm = env_int("SHF_F16X3_K1_GEMM", 1);
     q.heads3 = env_int("SHF_F16X3_HEADS3", 1);
     q.pc_tab = env_int("SHF_F16X3_PC_TAB", 1);
     q.pc = env_int("SHF_F16X3_PC", 1) != 0;
     q.pc_persist = env_int("SHF_F16X3_PC_PERSIST", 1) != 0;
-    q.dilated = env_int("SHF_F16X3_DILATED", 1) != 0;
-    q.k1 = env_int("SHF_F16X3_1X1", 1) != 0;
-    q.scalar_epilogue = env_int("SHF_CONV_SCALAR_EPILOGUE", 0) != 0;
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 4)
       cus = 256;
@@ -195,18 +187,18 @@ bool views_aligned(const ConvArgs* as, int n) {
 // unaligned views (scalar epilogue), take the 8-wave kernel.
 bool conv_f16x3_group_is_dual(const ConvArgs* as, int n) {
   if (!as[0].wsplit16h || as[0].img || as[0].k != 3 || as[0].dil != 1 || as[0].out.C % 128) return false;
-  if (!conv_f16x3_uses_w4(as[0].in.C) || knobs().scalar_epilogue || !views_aligned(as, n)) return false;
+  if (!conv_f16x3_uses_w4(as[0].in.C) || !views_aligned(as, n)) return false;
   for (int i = 0; i < n; ++i)
     if ((unsigned long long)as[i].in.B * as[i].in.H * as[i].in.W * as[i].in.cstride * 4ull >= (1ull << 32)) return false;
   return true;
 }
 
 // the dilated shared-weight heads (dilation 2 / 4) on the family's DIL form: the same conditions but for the dilation
-bool conv_f16x3_dilated_uses_w4() { return knobs().dil_w4 != 0 && knobs().dilated; }
+// (what they exclude -- Cin < 64, Cout % 128, unaligned views -- takes the 8-wave kernel's DIL form)
 bool conv_f16x3_group_is_dilated_w4(const ConvArgs* as, int n) {
-  if (!conv_f16x3_dilated_uses_w4() || !as[0].wsplit16h || as[0].img || as[0].k != 3 || (as[0].dil != 2 && as[0].dil != 4) || as[0].out.C % 128)
+  if (!as[0].wsplit16h || as[0].img || as[0].k != 3 || (as[0].dil != 2 && as[0].dil != 4) || as[0].out.C % 128)
     return false;
-  if (!conv_f16x3_uses_w4(as[0].in.C) || knobs().scalar_epilogue || !views_aligned(as, n)) return false;
+  if (!conv_f16x3_uses_w4(as[0].in.C) || !views_aligned(as, n)) return false;
   for (int i = 0; i < n; ++i)
     if ((unsigned long long)as[i].in.B * as[i].in.H * as[i].in.W * as[i].in.cstride * 4ull >= (1ull << 32)) return false;
   return true;
@@ -215,12 +207,12 @@ bool conv_f16x3_group_is_dilated_w4(const ConvArgs* as, int n) {
 // 1x1 layers on the GEMM kernel (conv_f16x3_k1.h): all 256 couts of a pixel in one block, the family's weight pack with
 // k = 1, activations in the split format (net.cpp counts such a layer as a split-format reader) or fp32
 bool conv_f16x3_k1_gemm_shape(int Cin, int Cout) {
-  return knobs().k1_gemm != 0 && knobs().k1 && conv_f16x3_uses_w4(Cin) && Cin % 32 == 0 && Cout % 256 == 0;
+  return conv_f16x3_uses_w4(Cin) && Cin % 32 == 0 && Cout % 256 == 0;
 }
 bool conv_f16x3_group_is_k1_gemm(const ConvArgs* as, int n) {
   if (!as[0].wsplit16h || as[0].img || as[0].k != 1 || as[0].bf16 || as[0].pool.p || !conv_f16x3_k1_gemm_shape(as[0].in.C, as[0].out.C))
     return false;
-  if (knobs().scalar_epilogue || !views_aligned(as, n)) return false;
+  if (!views_aligned(as, n)) return false;
   for (int i = 0; i < n; ++i)
     if ((unsigned long long)as[i].in.B * as[i].in.H * as[i].in.W * as[i].in.cstride * 4ull >= (1ull << 32)) return false;
   return true;
@@ -248,8 +240,8 @@ bool conv_f16x3_pc_persistent() { return knobs().pc_persist; }
 bool conv_f16x3_uses_w4(int Cin) { return knobs().w4_mode < 0 ? Cin >= 64 : knobs().w4_mode != 0; }
 
 bool conv_f16x3_eligible(int Cin, int Cout, int k, int pad, int dil) {
-  const bool dil_ok = dil == 1 || (knobs().dilated && (dil == 2 || dil == 4));
-  if (k == 1) return knobs().k1 && pad == 0 && Cin % 32 == 0 && Cout % 64 == 0;
+  const bool dil_ok = dil == 1 || dil == 2 || dil == 4;
+  if (k == 1) return pad == 0 && Cin % 32 == 0 && Cout % 64 == 0;
   return k == 3 && dil_ok && pad == dil && Cin % 32 == 0 && Cout % 64 == 0;
 }
 
@@ -307,7 +299,7 @@ static int launch_f16x3_t(const ConvArgs* as, int n, hipStream_t s) {
   p.w1f = a.w1f;
   p.b1 = a.b1;
   long long tiles = 0;
-  const bool vec_ok = !knobs().scalar_epilogue && views_aligned(as, n);
+  const bool vec_ok = views_aligned(as, n);   // (unaligned channel views: the 8-wave kernel's scalar stores)
   // the dual-tile 4-wave family (16- or 8-row tiles, w4_pick_mt) or this template's 8-wave kernel
   const bool dual = BN == 128 && !FUSE1 && DIL == 1 && KS == 3 && conv_f16x3_group_is_dual(as, n);
   const int mt = dual ? w4_pick_mt(as, n, p.nct) : 4;
@@ -554,7 +546,6 @@ bool conv_f16x3_group_is_heads3(const ConvArgs* a1, const ConvArgs* a2, const Co
   if (!knobs().heads3 || n < 1 || n > MAX_GROUP) return false;
   const ConvArgs& a = a1[0];
   if (!a.wsplit16h || a.bf16 || a.img || a.k != 3 || a.dil != 1 || a.out.C != 128 || a.in.C % 16 || !conv_f16x3_uses_w4(a.in.C)) return false;
-  if (knobs().scalar_epilogue || !conv_f16x3_dilated_uses_w4()) return false;
   for (int i = 0; i < n; ++i) {
     const ConvArgs* q[3] = {&a1[i], &a2[i], &a4[i]};
     if (q[1]->dil != 2 || q[2]->dil != 4) return false;

@@ -40,6 +40,11 @@ void set_error(const std::string& msg) { g_err = msg; }
   do {                                                     \
     if ((expr) != 0) throw std::runtime_error(g_err);      \
   } while (0)
+// ... naming the layer (a launcher's message speaks of shapes and kernels, not of the graph)
+#define CHECK_RC_LAYER(expr, lname)                                                           \
+  do {                                                                                        \
+    if ((expr) != 0) throw std::runtime_error("layer '" + std::string(lname) + "': " + g_err); \
+  } while (0)
 
 // hipMemset on the null stream may return before the fill has run, and the null stream is not ordered with the runtime's
 // non-blocking streams: a fill that must be in place before the first kernel touches the buffer is waited for here.  (A
@@ -932,10 +937,20 @@ void shf_net::build(const std::string& text, const char* caffemodel) {
   //      (or by the pool fused into its epilogue) and read ONLY by convs that run on the 4-wave kernel
   {
     static const bool split_act = !(getenv("SHF_F16X3_SPLIT_ACT") && atoi(getenv("SHF_F16X3_SPLIT_ACT")) == 0);
+    // (the static half of the launch-time predicates conv_f16x3_group_is_dual / _dilated_w4 / _k1_gemm: what a reader writes
+    // -- its top and the top of a pool fused into it -- must be a 16-byte aligned channel view, and the GEMM kernel takes no
+    // fused pool; the dynamic half -- an input of 4 GiB or more -- fails the launch with the layer's name)
+    auto aligned_view = [&](int bi_) {
+      const Blob& b_ = blobs[bi_];
+      const Blob& ob_ = blobs[b_.owner >= 0 ? b_.owner : bi_];
+      return ob_.shape.size() == 4 && ob_.shape[1] % 4 == 0 && b_.coff % 4 == 0;
+    };
     auto w4_reader = [&](const Layer& Q, int cin) {
-      const bool dil_ok = Q.dil == 1 || ((Q.dil == 2 || Q.dil == 4) && conv_f16x3_dilated_uses_w4());   // (the heads: family's DIL form)
+      const bool dil_ok = Q.dil == 1 || Q.dil == 2 || Q.dil == 4;   // (the heads: family's DIL form / the three-heads kernel)
+      if (Q.op != OP_CONV || Q.tops.empty() || !aligned_view(Q.tops[0])) return false;
+      if (Q.fuse_pool >= 0 && !aligned_view(layers[Q.fuse_pool].tops[0])) return false;
       if (Q.op == OP_CONV && Q.kclass == 0 && Q.k == 1 && Q.pad == 0 && Q.first_src < 0)   // 1x1 layers on the GEMM kernel
-        return conv_f16x3_k1_gemm_shape(cin, Q.nout) && conv_f16x3_eligible(cin, Q.nout, Q.k, Q.pad, Q.dil);
+        return Q.fuse_pool < 0 && conv_f16x3_k1_gemm_shape(cin, Q.nout) && conv_f16x3_eligible(cin, Q.nout, Q.k, Q.pad, Q.dil);
       return Q.op == OP_CONV && Q.kclass == 0 && Q.k == 3 && dil_ok && Q.pad == Q.dil && cin % 32 == 0 && Q.nout % 128 == 0 &&
              Q.first_src < 0 && conv_f16x3_uses_w4(cin) && conv_f16x3_eligible(cin, Q.nout, Q.k, Q.pad, Q.dil);
     };
@@ -1115,7 +1130,7 @@ void shf_net::commit_params(int li) {
   // the dual-tile family's weight pack (16-channel slabs, unscaled low parts): its 3x3 layers, and the 1x1 GEMM kernel's
   auto wants_family_pack = [](const Layer& Q, const ParamBlob& w) {
     if (Q.k == 1) return Q.pad == 0 && conv_f16x3_k1_gemm_shape(w.shape[1], w.shape[0]);
-    return Q.k == 3 && (Q.dil == 1 || ((Q.dil == 2 || Q.dil == 4) && conv_f16x3_dilated_uses_w4())) && conv_f16x3_uses_w4(w.shape[1]) &&
+    return Q.k == 3 && (Q.dil == 1 || Q.dil == 2 || Q.dil == 4) && conv_f16x3_uses_w4(w.shape[1]) &&
            w.shape[0] % 128 == 0 && w.shape[1] % 32 == 0;
   };
   // the raw / packed tensors are shared by every lane cloned from this net: nothing may be in flight on any stream
@@ -1355,10 +1370,10 @@ void shf_net::forward_ops(bool fused_path, float im_h, float im_w, float im_scal
               SubProf sp{&pf, st, fl, by, {}};
               a.sub_hook = &SubProf::hook;
               a.sub_ctx = &sp;
-              CHECK_RC(launch_conv_f16x3_group(&a, 1, st));
+              CHECK_RC_LAYER(launch_conv_f16x3_group(&a, 1, st), L.name);
             } else {
               ProfScope ps(pf, st, f16x3_prof_class(a, L.nout), fl, by);
-              CHECK_RC(launch_conv_f16x3_group(&a, 1, st));
+              CHECK_RC_LAYER(launch_conv_f16x3_group(&a, 1, st), L.name);
             }
           } else if (L.kclass == 0) {
             const int pc = conv_prof_class(L.k, L.dil, L.nout);
@@ -1949,10 +1964,10 @@ int shf_detect_add_levels(shf_net* net, int n, shf_net** members, const float* c
         SubProf sp{&net->prof, st, fl, by, {}};
         group[0].sub_hook = &SubProf::hook;
         group[0].sub_ctx = &sp;
-        CHECK_RC(launch_conv_f16x3_group(group.data(), n, st));
+        CHECK_RC_LAYER(launch_conv_f16x3_group(group.data(), n, st), L.name);
       } else {
         ProfScope ps(net->prof, st, f16x3_prof_class(group[0], L.nout, group.data(), n), fl, by);
-        CHECK_RC(launch_conv_f16x3_group(group.data(), n, st));
+        CHECK_RC_LAYER(launch_conv_f16x3_group(group.data(), n, st), L.name);
       }
     } else {
       const int pc = conv_prof_class(L.k, L.dil, L.nout);

@@ -86,9 +86,8 @@ size_t split16r_conv_weight_halfs(int Cout, int Cin, int k);
 void pack_conv_weights_split16r(const float* w, int Cout, int Cin, int k, void* dst, bool bf = false);
 float pack_conv_weights_split16h(const float* w, int Cout, int Cin, int k, void* dst, bool bf = false);  // returns 1 / scale
 bool conv_f16x3_group_is_dual(const ConvArgs* as, int n);
-bool conv_f16x3_dilated_uses_w4();   // the dilated heads (dilation 2 / 4) run on the dual-tile family's DIL form (SHF_F16X3_DIL_W4)
 bool conv_f16x3_group_is_dilated_w4(const ConvArgs* as, int n);
-bool conv_f16x3_k1_gemm_shape(int Cin, int Cout);   // a 1x1 layer of this shape runs on the GEMM kernel (SHF_F16X3_K1_GEMM): the family's pack, split-format input
+bool conv_f16x3_k1_gemm_shape(int Cin, int Cout);   // a 1x1 layer of this shape runs on the GEMM kernel: the family's pack, split-format input
 bool conv_f16x3_group_is_k1_gemm(const ConvArgs* as, int n);
 // the three shared-weight dilated heads (dilation 1 / 2 / 4, same input, same weights) as ONE launch (conv_f16x3_h3.h; SHF_F16X3_HEADS3)
 bool conv_f16x3_group_is_heads3(const ConvArgs* a1, const ConvArgs* a2, const ConvArgs* a4, int n);
