@@ -25,10 +25,13 @@ SOURCES = [
     ("merge.hip", ["-ffp-contract=off"]),
     ("pre.hip", ["-ffp-contract=off"]),
     ("calib.hip", []),
-    ("net.cpp", []),
+    ("net_graph.cpp", []),
+    ("net_forward.cpp", []),
+    ("net_detect.cpp", []),
+    ("net_api.cpp", []),
 ]
 HEADERS = ["shf_internal.h", "conv_common.h", "conv_f16x3_types.h", "conv_f16x3_8w.h", "conv_f16x3_w4d.h", "conv_f16x3_pc.h", "conv_f16x3_k1.h", "conv_f16x3_h3.h",
-           "proto_text.h", os.path.join("..", "..", "include", "shf_hip.h")]
+           "proto_text.h", "net_internal.h", os.path.join("..", "..", "include", "shf_hip.h")]
 
 
 def _newer(target, deps):

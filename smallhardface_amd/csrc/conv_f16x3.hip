@@ -182,7 +182,7 @@ bool views_aligned(const ConvArgs* as, int n) {
 }
 }  // namespace
 
-// (net.cpp: will launch_conv_f16x3_group(as, n) take the dual-tile family?  Then the sub-launch hook does the profiling.)
+// (net_forward.cpp / net_detect.cpp: will launch_conv_f16x3_group(as, n) take the dual-tile family?  Then the sub-launch hook does the profiling.)
 // The family addresses its input with 32-bit BYTE offsets from the member's base: inputs of 4 GiB and more, and
 // unaligned views (scalar epilogue), take the 8-wave kernel.
 bool conv_f16x3_group_is_dual(const ConvArgs* as, int n) {
@@ -205,7 +205,7 @@ bool conv_f16x3_group_is_dilated_w4(const ConvArgs* as, int n) {
 }
 
 // 1x1 layers on the GEMM kernel (conv_f16x3_k1.h): all 256 couts of a pixel in one block, the family's weight pack with
-// k = 1, activations in the split format (net.cpp counts such a layer as a split-format reader) or fp32
+// k = 1, activations in the split format (net_graph.cpp counts such a layer as a split-format reader) or fp32
 bool conv_f16x3_k1_gemm_shape(int Cin, int Cout) {
   return conv_f16x3_uses_w4(Cin) && Cin % 32 == 0 && Cout % 256 == 0;
 }

@@ -450,7 +450,7 @@ __global__ __launch_bounds__(1024) void compact_rows_kernel(const double* __rest
 
 int launch_vote_accumulate(const float* sorted5, const u64* mask, const int* cluster, int n, const int* heads,
                            const int* counters, double* out5, int* n_out, hipStream_t s) {
-  // rows/emit scratch live behind the compacted output: out5 has room for 2n rows (see net.cpp)
+  // rows/emit scratch live behind the compacted output: out5 has room for 2n rows (see net_internal.h: MergeCtx)
   double* rows = out5 + (size_t)n * 5;
   int* emit = (int*)(rows + (size_t)n * 5);
   // (one wave per cluster head, grid-stride: the head count is only known on the device)

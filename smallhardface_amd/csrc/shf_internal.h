@@ -51,7 +51,7 @@ struct ConvArgs {
                   // activations in HBM, no fp16 range guard and no activation exponent (bf16 has fp32's range)
   int nprod = 3;  // split-fp16 kernels: fp16 products formed per fp32 product -- 3 (hi*hi + hi*lo + lo*hi: fp32-class),
                   // 2 (drops a_lo*b_hi: activations effectively fp16) or 1 (hi*hi only: plain fp16 operands)
-  int* range_flag = nullptr;  // split-fp16 kernels raise it when an output leaves the fp16 range (net.cpp: fp32 re-run)
+  int* range_flag = nullptr;  // split-fp16 kernels raise it when an output leaves the fp16 range (net_forward.cpp: fp32 re-run)
   // activation-exponent slots (conv_common.h ConvMember): max |value| of the input blob as left by its producers, and
   // where this launch raises the max of what it writes (main output / fused pool output); null = not tracked
   const unsigned* in_amax = nullptr;

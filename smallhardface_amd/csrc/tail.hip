@@ -443,7 +443,7 @@ int launch_sort_desc_u64(unsigned long long* keys, const int* n_dev, size_t n_ma
 
 // ---------------------------------------------------------------------------
 static void fill_logits_shared(const TailArgs& a, TailGK& lk) {
-  lk.Wt = a.wcls[0];  // combined [A][6][Cf] matrix prepared by the net (see net.cpp: build_tail_weights)
+  lk.Wt = a.wcls[0];  // combined [A][6][Cf] matrix prepared by the net (see net_graph.cpp: build_tail_weights)
   lk.bt = a.bcls[0];
   lk.A = a.A; lk.Cf = a.Cf;
   for (int i = 0; i < a.A; ++i) {
