@@ -465,7 +465,15 @@ if (lds_pc > 160 * 1024) { set_error("conv f16x3: the fused first pair does not 
   }
   SHF_HIP_OK(hipGetLastError());
 #ifdef SHF_CONV_TIMING
-  {
+  if (dual) {   // the family's per-block phase sums (conv_f16x3_w4d.h): wave 0 of every block of the layer's launch(es)
+    unsigned long long h[4];
+    hipStreamSynchronize(s);
+    hipMemcpy(h, dbg_dev, sizeof(h), hipMemcpyDeviceToHost);
+    if (h[3])
+      fprintf(stderr, "[w4d timing] Cin %d Cout %d rows %d: %llu blocks, per block cycles: prologue %.0f, K loop %.0f (%d stages: %.0f each), epilogue %.0f\n",
+              p.Cin, p.Cout, 4 * mt, h[3], (double)h[0] / h[3], (double)h[1] / h[3], p.Cin / 16 * 3, (double)h[1] / h[3] / (p.Cin / 16 * 3),
+              (double)h[2] / h[3]);
+  } else {
     unsigned long long h[80];
     hipStreamSynchronize(s);
     hipMemcpy(h, dbg_dev, sizeof(h), hipMemcpyDeviceToHost);

@@ -59,6 +59,9 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4d_kernel(ConvK p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wn = wave & 1, wm = wave >> 1;
   const int bid = blockIdx.x;
+#ifdef SHF_CONV_TIMING
+  const unsigned long long tt_entry = __builtin_amdgcn_s_memtime();
+#endif
   const int ct = bid % p.nct;
   const int pp = bid / p.nct;
   const int ntiles = p.ntile_blocks / p.nct;          // the launch covers pixel tiles [tile_base, ntiles) of the group
@@ -274,6 +277,9 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4d_kernel(ConvK p) {
     }
   }
   if (tid < BN) biasL[tid] = bias_v;
+#ifdef SHF_CONV_TIMING
+  const unsigned long long tt_pro = __builtin_amdgcn_s_memtime();
+#endif
 
   unsigned seen0 = 0xffffffffu, seen0p = 0xffffffffu, seen1 = 0xffffffffu, seen1p = 0xffffffffu;
   // one stage = kernel row KY of the 16-channel chunk c.  MODE 1 (kernel row 1 of a chunk that has a successor):
@@ -443,6 +449,9 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4d_kernel(ConvK p) {
   stage(nchunks - 1, integral_constant<int, 0>{}, integral_constant<int, 0>{});
   stage(nchunks - 1, integral_constant<int, 1>{}, integral_constant<int, 0>{});
   stage(nchunks - 1, integral_constant<int, 2>{}, integral_constant<int, 3>{});
+#ifdef SHF_CONV_TIMING
+  const unsigned long long tt_k = __builtin_amdgcn_s_memtime();
+#endif
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last stage's (unused) self re-fetch, the slot peeks
   asm volatile("" : "+v"(seen0), "+v"(seen0p), "+v"(seen1), "+v"(seen1p));   // (the compiler's own wait for them goes HERE)
   // (wave-uniform: parked in scalar registers until the end of the epilogue -- a vector register would be spilled)
@@ -533,6 +542,17 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4d_kernel(ConvK p) {
       if constexpr (NTILE == 2) tile_out(acc1, g1, has1, e_t1, amax1);
     }
   }
+#ifdef SHF_CONV_TIMING
+  // per-block phase cycles of wave 0 (summed over all blocks of the launch): prologue (entry .. first stage), K loop, epilogue
+  if (p.dbg && tid == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long tt_end = __builtin_amdgcn_s_memtime();
+    atomicAdd(p.dbg + 0, tt_pro - tt_entry);
+    atomicAdd(p.dbg + 1, tt_k - tt_pro);
+    atomicAdd(p.dbg + 2, tt_end - tt_k);
+    atomicAdd(p.dbg + 3, 1ull);
+  }
+#endif
   conv_raise_range_flag(p.range_flag, conv_absmax_bits(amax0, amax1));
   conv_amax_commit(g0.out_amax, seen0, g0.pool ? g0.pool_amax : nullptr, seen0p, amax0);
   if constexpr (NTILE == 2) {
