@@ -8,7 +8,10 @@
 //   REFRESH 1: every fragment gets new mantissa / sign bits every 24 MFMAs (a half-step of the conv)
 //   ZERO8   eighths of the ACTIVATION dwords (second MFMA source) that are zero (post-ReLU maps); 16 + n: n eighths of the
 //           WEIGHT dwords (first MFMA source) instead
-//   ORDER   0: the conv kernel's order (tm outer, tn inner)   1: snake (one operand changes per MFMA)
+//   ORDER   0: the conv kernel's order (product outer, tm, tn inner)   1: snake (one operand changes per MFMA)
+//           2: product INNERMOST -- the three products of an accumulator tile back to back (dependent on SrcC: does the pipe
+//              forward the accumulator, and does that save register-file energy?)   3: the same over pairs of tiles (two chains
+//              interleaved)   4: over quads of tiles
 //   TRUNC   low mantissa bits forced to zero in the lo fragments (a[odd], b[odd])
 // hipcc --offload-arch=gfx950 -O3 tools/mfma_power.hip -o tools/bin/mfma_power && ./tools/bin/mfma_power
 #include <hip/hip_runtime.h>
@@ -72,9 +75,11 @@ __global__ __launch_bounds__(256) void k(float* out, int iters) {
           B[i][j] ^= ((ts >> ((i + 2 * j + 5) & 15)) * 0x00010001u) & MANT & ((i & 1) ? TMASK : 0xFFFFFFFFu);
     }
 #pragma unroll
-    for (int prod = 0; prod < 3; ++prod)
-#pragma unroll
-      for (int s = 0; s < 8; ++s) {
+    for (int idx = 0; idx < 24; ++idx) {
+        // (ORDER >= 2: groups of G = 1 / 2 / 4 accumulator tiles, the three products innermost over the group)
+        constexpr int G = ORDER == 2 ? 1 : ORDER == 3 ? 2 : 4;
+        const int prod = ORDER < 2 ? idx / 8 : (idx / G) % 3;
+        const int s = ORDER < 2 ? idx % 8 : (idx / (3 * G)) * G + idx % G;
         const int tm = s >> 1, tn = ORDER == 1 ? ((s & 1) ^ (tm & 1)) : (s & 1);
         const u4 a = A[2 * tm + (prod == 2)], b = B[2 * tn + (prod == 1)];
         if constexpr (TYPE == 0)
@@ -139,6 +144,11 @@ int main() {
   run<0, 1, 0, 20, 0, 0>("f16 random, WEIGHTS half zero");
   run<0, 1, 0, 0, 1, 0>("f16 random, snake order");
   run<0, 1, 0, 4, 1, 0>("f16 random, half zero, snake");
+  run<0, 1, 0, 4, 2, 0>("f16 random, half zero, acc chained");
+  run<0, 1, 0, 4, 3, 0>("f16 random, half zero, 2 chains");
+  run<0, 1, 0, 4, 4, 0>("f16 random, half zero, 4 chains");
+  run<0, 1, 0, 4, 0, 0>("f16 random, act half zero (again)");
+  run<0, 1, 0, 0, 2, 0>("f16 random dense, acc chained");
   run<0, 1, 0, 4, 0, 3>("f16 random, half zero, lo 8 bits");
   run<0, 1, 0, 4, 0, 5>("f16 random, half zero, lo 6 bits");
   run<0, 1, 1, 4, 0, 0>("f16 refresh, half zero");
