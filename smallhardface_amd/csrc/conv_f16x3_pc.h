@@ -21,9 +21,10 @@ namespace shf {
 //    epilogue stores from registers (conv_common.h conv_epilogue_pool_only when only the pooled map is kept).  Waves 4-7
 //    are PRODUCERS: every weight DMA, and the walk's bookkeeping.
 //  * PERSIST: one block per CU WALKS the tiles (tile = block, block + grid, ...), decoded once per block into a packed
-//    LDS table.  Under tile t's K loop the producers read tile t + 2's record (stage 4), request tile t + 1's patch
-//    (stage 1, IN FRONT of that stage's weight pieces) and park it with its validity flags (stage 2), hand tile t + 1's
-//    geometry to all waves through LDS (stage 3) and request its first weight stage (stage 5).
+//    LDS table.  Under tile t's K loop the producers read tile t + 2's record (stage 4), request tile t + 1's patch (a pair per
+//    thread in each of stages 1-3, IN FRONT of that stage's weight pieces) and park it a stage later (stages 2-4), write its
+//    validity flags (stage 5), hand tile t + 1's geometry to all waves through LDS (stage 3) and request its first weight
+//    stage (stage 5): 2.0-2.7 k cycles of own work in every stage (round 5; stages 1 / 2 carried 2.9 k / 3.4 k before).
 //  * A matrix stream and a vector stream do not overlap on a SIMD (tools/scratch/coissue.hip: a partner wave gets ~3 vector
 //    issues per MFMA), so conv1_1 of tile t + 1 does NOT run under the K loop (measured: the K loop grows by what the
 //    producers run) but BESIDE THE OTHER VECTOR PHASE: behind a post-K barrier its 11 row tiles are claimed one at a time
@@ -488,7 +489,7 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
       }
       mma_stage(st < 3 ? As0 : As1, st % 3, st & 1);
     } else {
-      if (!(PERSIST && st == 1) && st + 1 < 6) dma_w(st + 1, (st + 1) & 1);   // (stage 1: behind the patch requests, below)
+      if (!(PERSIST && st >= 1 && st <= 3) && st + 1 < 6) dma_w(st + 1, (st + 1) & 1);   // (stages 1-3: behind the patch requests, below)
       if constexpr (PERSIST) {
         // (measured, not kept: s_setprio 3 around these chores -- no change: what made a producer's stage-1 work 4.3 k cycles
         // was not issue arbitration but the patch loads queueing behind the stage's seven 1-KiB weight pieces)
@@ -496,12 +497,19 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
         asm volatile("" : "+v"(lane_p));
         const int ptid = (wave_u - 4) * 64 + lane_p;
         if (st == 4 && tile + 2 * gstride < ntiles) nxt_pre = p.pc_tab ? decode_tab(k_walk + 2) : decode(tile + 2 * gstride);
-        if (st == 1 && has_next) {   // (stage 1: the producers' lightest -- stage 0 carries the walk's bookkeeping)
+        // THE PRODUCERS' CHORES ARE SPREAD OVER THE STAGES (round 5; per-role cycle counters, -DSHF_CONV_TIMING): with the patch
+        // requested in stage 1 and parked -- with the validity flags -- in stage 2, the producers' own work was 2.9 k / 3.4 k
+        // cycles in those stages against the consumers' 2.5-2.6 k, and 1.7 k / 1.7 k / 1.1 k in stages 3-5: stages 1 and 2 waited
+        // for the producers (3.0 k / 3.4 k per stage instead of 2.6 k).  Now a thread's three patch pairs are requested one per
+        // stage in stages 1-3, each is parked a stage later (stages 2-4: its load was waited for at that stage's top), and the
+        // validity flags are written in stage 5: ~2.0-2.5 k of own work in every stage.
+        static_assert(NPF2 == 3, "one patch pair per producer thread and stage in stages 1-3");
+        if (st >= 1 && st <= 3 && has_next) {
           // x-PAIRS of patch elements, one 8-byte load each (a load instruction costs a producer wave 100-200 cycles beside
           // the consumers' stream: 12 wave-level loads instead of 20).  With an even level width a pair is inside or outside
           // the image as a whole and 8-byte aligned: the patch starts at column tx0 - 2 (even).
 #pragma unroll
-          for (int k = 0; k < NPF2; ++k) {
+          for (int k = st - 1; k < st; ++k) {
             const int pi = ptid + 256 * k;                       // pair index: row (ci, py) = pi / 10, column pair pi % 10
             const int row = (pi * 6554) >> 16, c2 = pi - row * (PW / 2);
             const int ci = (row * 3277) >> 16, py = row - ci * PH;
@@ -522,7 +530,7 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
         }
         // (the patch requests go out FIRST in their stage: issued behind the stage's seven 1-KiB weight pieces they queued for
         // 2-3 k cycles with the wave stuck at the issue -- a stage 1 of 4.3 k cycles instead of 3.7; 2.7 is the consumers')
-        if (st == 1) dma_w(2, 0);
+        if (st >= 1 && st <= 3) dma_w(st + 1, (st + 1) & 1);
         if (st == 3 && has_next && ptid == 0) {   // (the previous tile's claims ended before stage 0; read behind the post-K barrier)
           ctrL[0] = 0u;
           ctrL[1] = (nxt.ty0 >= 1 && nxt.tx0 >= 1 && nxt.ty0 + TH < nxt.H && nxt.tx0 + TW < nxt.W) ? 1u : 0u;
@@ -536,13 +544,15 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
           geoL[10] = (unsigned)q2; geoL[11] = (unsigned)(q2 >> 32); geoL[12] = (unsigned)q3; geoL[13] = (unsigned)(q3 >> 32);
           geoL[14] = (unsigned)q4; geoL[15] = (unsigned)(q4 >> 32);
         }
-        if (st == 2 && has_next) {   // (stage 2: the producers' lightest; the loads were waited for at its top)
+        if (st >= 2 && st <= 4 && has_next) {   // (pair st - 2: requested a stage ago, waited for at this stage's top)
 #pragma unroll
-          for (int k = 0; k < NPF2; ++k) {
+          for (int k = st - 2; k < st - 1; ++k) {
             const int pi = ptid + 256 * k;
             if (pi < 3 * PH * (PW / 2)) *(uint2*)(patch + 2 * pi) = make_uint2(patch_word(pvn[2 * k]), patch_word(pvn[2 * k + 1]));
             amax1 = conv_absmax_bits(conv_absmax_bits(amax1, pvn[2 * k]), pvn[2 * k + 1]);
           }
+        }
+        if (st == 5 && has_next) {
 #pragma unroll
           for (int k = 0; k < (HPP + 255) / 256; ++k) {
             const int hp = ptid + 256 * k;
