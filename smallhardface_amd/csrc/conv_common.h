@@ -273,6 +273,22 @@ __device__ __forceinline__ unsigned conv_pk_pow2_f16(int k) {
 // A block-wide store covers PPI = NT / (BN/4) pixels; the walk over the 256 pixels is fully unrolled
 // with compile-time (row, column) steps so that an iteration is one LDS read, one predicate and one
 // float4 store off a running pointer.
+// The low halves of a split pair from the packed hi halves: lo = fp16((x - f32(hi)) * 2048) formed as
+// fma(f32(hi), -2048, x * 2048) with ONE rounding to fp16 -- v_fma_mixlo / mixhi_f16 read the fp16 source straight out of the
+// packed register, so the two conversions back to fp32, the subtraction and the second pack of the plain form become two
+// instructions (3 instead of 5 per pair after the hi pack).  Bit for bit the plain form: x - hi is exact in fp32, so are both
+// products, and the fma's exact result is rounded once like the conversion's (tools/scratch/mix_split.hip: 0 mismatches over
+// 8.4 M pairs from 2^-30 to the fp16 ceiling, zeros and subnormal results included).
+typedef _Float16 cs_h2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ cs_h2 conv_split_lo(const cs_f32x2 x, const cs_h2 hi) {
+  const cs_f32x2 x2 = x * 2048.0f;
+  const float k = -2048.0f;
+  unsigned d;
+  asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(__builtin_bit_cast(unsigned, hi)), "s"(k), "v"(x2[0]));
+  asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(d) : "v"(__builtin_bit_cast(unsigned, hi)), "s"(k), "v"(x2[1]));
+  return __builtin_bit_cast(cs_h2, d);
+}
+
 // four consecutive channels (c % 4 == 0) of one pixel in the split-fp16 activation format:
 // [chunk c/32][hi 32 halfs | lo 32 halfs], x = hi + lo / 2048
 __device__ __forceinline__ void conv_store_split4(float* __restrict__ pixel, int c, const float4 v) {
@@ -280,8 +296,7 @@ __device__ __forceinline__ void conv_store_split4(float* __restrict__ pixel, int
   typedef float f2 __attribute__((ext_vector_type(2)));
   const f2 x01 = {v.x, v.y}, x23 = {v.z, v.w};
   const h2 h01 = __builtin_convertvector(x01, h2), h23 = __builtin_convertvector(x23, h2);
-  const h2 l01 = __builtin_convertvector((x01 - __builtin_convertvector(h01, f2)) * 2048.0f, h2);
-  const h2 l23 = __builtin_convertvector((x23 - __builtin_convertvector(h23, f2)) * 2048.0f, h2);
+  const h2 l01 = conv_split_lo(x01, h01), l23 = conv_split_lo(x23, h23);
   unsigned char* d = (unsigned char*)(pixel + (c >> 5) * 32) + (c & 31) * 2;
   *(float2*)d = make_float2(__builtin_bit_cast(float, h01), __builtin_bit_cast(float, h23));
   *(float2*)(d + 64) = make_float2(__builtin_bit_cast(float, l01), __builtin_bit_cast(float, l23));
@@ -297,7 +312,7 @@ __device__ __forceinline__ void conv_store_split8(float* __restrict__ pixel, int
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const h2 h = __builtin_convertvector(x[q], h2);
-    const h2 l = __builtin_convertvector((x[q] - __builtin_convertvector(h, f2)) * 2048.0f, h2);
+    const h2 l = conv_split_lo(x[q], h);
     hi[q] = __builtin_bit_cast(float, h);
     lo[q] = __builtin_bit_cast(float, l);
   }

@@ -115,8 +115,7 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_heads3_kernel(ConvK p) {
       const h2 hi1 = __builtin_bit_cast(h2, sc_hi1 & keep), lo1 = __builtin_bit_cast(h2, sc_lo1 & keep);
       const f32x2 x01 = {v.x, v.y}, x23 = {v.z, v.w};
       const h2 h01 = __builtin_convertvector(x01, h2), h23 = __builtin_convertvector(x23, h2);
-      const h2 l01 = __builtin_convertvector((x01 - __builtin_convertvector(h01, f32x2)) * LO_SCALE, h2);
-      const h2 l23 = __builtin_convertvector((x23 - __builtin_convertvector(h23, f32x2)) * LO_SCALE, h2);
+      const h2 l01 = conv_split_lo(x01, h01), l23 = conv_split_lo(x23, h23);
       v = make_float4(__builtin_bit_cast(float, h01 * hi1), __builtin_bit_cast(float, h23 * hi1),
                       __builtin_bit_cast(float, l01 * lo1), __builtin_bit_cast(float, l23 * lo1));
     }

@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_k1_kernel(ConvK p) {
         const float4 v = (k >> 1) ? r1 : r0;
         const f32x2 x = (k & 1) ? f32x2{v.z, v.w} : f32x2{v.x, v.y};
         const h2 hh = __builtin_convertvector(x, h2);
-        const h2 ll = __builtin_convertvector((x - __builtin_convertvector(hh, f32x2)) * LO_SCALE, h2);
+        const h2 ll = conv_split_lo(x, hh);
         hw[k] = __builtin_bit_cast(float, hh * f_hi);
         lw[k] = __builtin_bit_cast(float, ll * f_lo);
       }

@@ -321,13 +321,19 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
         // C row (cout) = (r & 3) + 8 (r >> 2) + 4 kh, C column (halo pixel) = lane & 31: registers 4q .. 4q + 3 are the FOUR
         // CONSECUTIVE couts 8q + 4kh .. + 3 -- 8 bytes of hi and 8 bytes of lo in the pixel's LDS row, stored as they are (the
         // half-wave exchange that made 16-byte stores of them cost eight permlane swaps with their wait states)
+        // (packed: v_pk_fma_f32 + v_pk_add_f32 per register pair -- the same fma-then-add the scalar form compiled to -- then the
+        // ReLU per value)
         float v[16];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          v[4 * q] = fmaxf(cm[n][4 * q] + cc[n][4 * q] * LO_INV + bq[n][q].x, 0.f);
-          v[4 * q + 1] = fmaxf(cm[n][4 * q + 1] + cc[n][4 * q + 1] * LO_INV + bq[n][q].y, 0.f);
-          v[4 * q + 2] = fmaxf(cm[n][4 * q + 2] + cc[n][4 * q + 2] * LO_INV + bq[n][q].z, 0.f);
-          v[4 * q + 3] = fmaxf(cm[n][4 * q + 3] + cc[n][4 * q + 3] * LO_INV + bq[n][q].w, 0.f);
+          const f32x2 s01 = __builtin_elementwise_fma(f32x2{cc[n][4 * q], cc[n][4 * q + 1]}, f32x2{LO_INV, LO_INV}, f32x2{cm[n][4 * q], cm[n][4 * q + 1]}) +
+                            f32x2{bq[n][q].x, bq[n][q].y};
+          const f32x2 s23 = __builtin_elementwise_fma(f32x2{cc[n][4 * q + 2], cc[n][4 * q + 3]}, f32x2{LO_INV, LO_INV}, f32x2{cm[n][4 * q + 2], cm[n][4 * q + 3]}) +
+                            f32x2{bq[n][q].z, bq[n][q].w};
+          v[4 * q] = fmaxf(s01[0], 0.f);
+          v[4 * q + 1] = fmaxf(s01[1], 0.f);
+          v[4 * q + 2] = fmaxf(s23[0], 0.f);
+          v[4 * q + 3] = fmaxf(s23[1], 0.f);
         }
         if (need_ok) {
           const bool ok = okb != 0;
@@ -347,8 +353,8 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
           } else {
             h0 = __builtin_convertvector(x0, half2v);
             h1 = __builtin_convertvector(x1, half2v);
-            l0 = __builtin_convertvector((x0 - __builtin_convertvector(h0, f32x2)) * LO_SCALE, half2v);
-            l1 = __builtin_convertvector((x1 - __builtin_convertvector(h1, f32x2)) * LO_SCALE, half2v);
+            l0 = conv_split_lo(x0, h0);   // (conv_common.h: v_fma_mixlo / mixhi_f16)
+            l1 = conv_split_lo(x1, h1);
             // fp16 range guard of conv1_1's outputs, on the PACKED hi halves (values >= 0; an overflow is an inf there)
             amax1h = __builtin_elementwise_max(amax1h, __builtin_elementwise_max(h0, h1));
           }

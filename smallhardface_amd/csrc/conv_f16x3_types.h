@@ -68,15 +68,13 @@ __device__ __forceinline__ void bf16x4_of(const float4 v, _Float16 (&h)[4]) {
   h[0] = a[0]; h[1] = a[1]; h[2] = b[0]; h[3] = b[1];
 }
 
-// x -> (hi, lo) for four values, two per instruction: v_cvt_pk_f16_f32 for both halves, packed fp32
-// subtract / scale in between (3 VALU ops per value instead of 6; same results as the scalar form)
+// x -> (hi, lo) for four values: v_cvt_pk_f16_f32 for the hi pairs, conv_split_lo for the lo pairs (2 VALU ops per value;
+// same results as the scalar form)
 typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split4(const float4 v, half4& hi, half4& lo) {
   const f32x2 x01 = {v.x, v.y}, x23 = {v.z, v.w};
   const half2v h01 = __builtin_convertvector(x01, half2v), h23 = __builtin_convertvector(x23, half2v);
-  const f32x2 r01 = (x01 - __builtin_convertvector(h01, f32x2)) * f16x3::LO_SCALE;
-  const f32x2 r23 = (x23 - __builtin_convertvector(h23, f32x2)) * f16x3::LO_SCALE;
-  const half2v l01 = __builtin_convertvector(r01, half2v), l23 = __builtin_convertvector(r23, half2v);
+  const half2v l01 = conv_split_lo(x01, h01), l23 = conv_split_lo(x23, h23);   // (conv_common.h: v_fma_mixlo / mixhi_f16)
   hi = half4{h01[0], h01[1], h23[0], h23[1]};
   lo = half4{l01[0], l01[1], l23[0], l23[1]};
 }
