@@ -94,6 +94,26 @@ def test_conv_mfma(cin, cout, k, dil, h, w, relu):
         assert (go["c1"] < 0).any()
 
 
+def _fuzz_conv_cases(n=14, seed=2025):
+    """Seeded random layer shapes over everything the split-fp16 launcher distinguishes: Cin below / at / above the family's
+    64, Cout with 64- / 128- / 256-multiples, 1x1 and 3x3 at dilation 1 / 2 / 4, ragged maps down to smaller than a halo."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        k = int(rng.choice([1, 3, 3, 3]))
+        dil = int(rng.choice([1, 1, 2, 4])) if k == 3 else 1
+        cin = int(rng.choice([32, 64, 96, 128, 160, 256, 512]))
+        cout = int(rng.choice([64, 128, 192, 256, 384, 512]))
+        h, w = int(rng.integers(5, 60)), int(rng.integers(5, 70))
+        out.append((cin, cout, k, dil, h, w, bool(rng.integers(0, 2))))
+    return out
+
+
+@pytest.mark.parametrize("cin,cout,k,dil,h,w,relu", _fuzz_conv_cases())
+def test_conv_mfma_seeded_shapes(cin, cout, k, dil, h, w, relu):
+    test_conv_mfma(cin, cout, k, dil, h, w, relu)
+
+
 def shared_conv_layer(name, bottom, nout, dil):
     return ('layer { name: "%s" type: "Convolution" bottom: "%s" top: "%s" param { name: "hw" } param { name: "hb" } '
             'convolution_param { num_output: %d kernel_size: 3 pad: %d dilation: %d } }\n'
