@@ -33,7 +33,6 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_heads3_kernel(ConvK p) {
   constexpr int SLAB_B = BN * WROWB;
   constexpr int ALD = HP * 4 / NT;                    // 6 sixteen-byte halo pieces per thread and chunk
   static_assert(HP * 4 == ALD * NT, "no ragged piece");
-  constexpr float LO_SCALE = 2048.0f;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* As = smem;                           // [2 buffer sets][4 planes][HTH][24 px][16 B]
   unsigned char* Bs = smem + 2 * AS_B;                // [2 buffers][3 taps][BN][64 B]

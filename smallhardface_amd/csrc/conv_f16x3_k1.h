@@ -43,7 +43,6 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_k1_kernel(ConvK p) {
   constexpr int SLAB_B = BN * WROWB;                 // 16 KiB: one 16-channel slab of the block's couts
   constexpr int BUF_B = 2 * SLAB_B;                  // a 32-channel chunk of weights
   constexpr int ABUF_B = PXB * 128;                  // a 32-channel chunk of the block's pixels
-  constexpr float LO_SCALE = 2048.0f;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* As = smem;                          // [3 buffers][256 pixels][128 B]
   unsigned char* Bs = smem + 3 * ABUF_B;             // [2 buffers][2 slabs][BN][64 B]

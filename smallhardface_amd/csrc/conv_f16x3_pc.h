@@ -702,8 +702,15 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
   {
     auto rd = [&](int k) { return (unsigned)__builtin_amdgcn_readfirstlane((int)geoL[k]); };
     auto rd64 = [&](int k) { return (unsigned long long)rd(k) | ((unsigned long long)rd(k + 1) << 32); };
-    mem = TileGeo{(int)rd(0), (int)rd(1), (int)rd(2), (int)rd(3), (int)rd(4), (const float*)rd64(6), (float*)rd64(8), (float*)rd64(10),
-                  (unsigned*)rd64(12), (unsigned*)rd64(14)};
+    // (the pointers come back from LDS as integers: cast through the GLOBAL address space, or every access through them is a
+    // FLAT instruction -- counted in lgkmcnt as well as vmcnt, so that each LDS wait of the epilogue and of the row-tile
+    // claims behind a store waited for that store to reach memory; found in the ISA in round 5: the persistent form was the
+    // only conv kernel with flat_store)
+    typedef __attribute__((address_space(1))) float gfloat;
+    typedef __attribute__((address_space(1))) const float gcfloat;
+    typedef __attribute__((address_space(1))) unsigned gunsigned;
+    mem = TileGeo{(int)rd(0), (int)rd(1), (int)rd(2), (int)rd(3), (int)rd(4), (const float*)(gcfloat*)rd64(6), (float*)(gfloat*)rd64(8),
+                  (float*)(gfloat*)rd64(10), (unsigned*)(gunsigned*)rd64(12), (unsigned*)(gunsigned*)rd64(14)};
   }
   b = mem.b; ty0 = mem.ty0; tx0 = mem.tx0; H = mem.H; W = mem.W; gout = mem.out;
   amax1 = 0.f;

@@ -50,7 +50,6 @@ __global__ __launch_bounds__(256) void conv_mfma_f16x3_w4d_kernel(ConvK p) {
   constexpr int WROWB = 64;                           // weight rows: no padding, the 16-byte pieces rotated by row / 4
   constexpr int SLAB_B = BN * WROWB;                  // 8 192 B per tap slab
   constexpr int ALD = (HP * 4 + NT - 1) / NT;         // 16-byte halo pieces per thread and tile: 6 (16 rows) or 3
-  constexpr float LO_SCALE = 2048.0f;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* As = smem;                           // [2 buffer sets][NTILE][4 planes][HTH][24 px][16 B]
   unsigned char* Bs = smem + 2 * NB_B;                // [2 buffers][3 taps][BN][64 B]
