@@ -381,6 +381,7 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
   if (PERSIST && !consumer && tile + gstride < ntiles) nxt_pre = decode(tile + gstride);
 #ifdef SHF_CONV_TIMING
   unsigned long long ts_k = 0, ts_bar = 0, ts_role = 0, ts_tail = 0, t_role_end = 0, ts_st[6] = {0, 0, 0, 0, 0, 0}, ts_own[6] = {0, 0, 0, 0, 0, 0};
+  unsigned long long ts_epi = 0, n_claimed = 0;   // consumers: their epilogue alone; every wave: conv1_1 row tiles it claimed
   int n_walk = 0;
 #endif
   for (;;) {   // (PERSIST: the walk over this block's tiles; otherwise one turn)
@@ -656,6 +657,9 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
     }
     conv_amax_commit(mem.out_amax, seen, mem.pool ? mem.pool_amax : nullptr, seenp, amax);   // (producers hold no outputs)
   }
+#ifdef SHF_CONV_TIMING
+  ts_epi += __builtin_amdgcn_s_memtime() - t_barx;
+#endif
   if (PERSIST && has_next) {
     // the next tile's conv1_1: its 11 row tiles are CLAIMED one at a time (an LDS counter) by whichever wave is free -- the
     // producers from the barrier on, the consumers once their epilogue is out.  (Measured and dropped: row tiles split per
@@ -674,6 +678,9 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
       if (lane_p == 0) got = atomicAdd(ctrL, 1u);
       const int m = __builtin_amdgcn_readfirstlane((int)got);
       if (m >= NMT) break;
+#ifdef SHF_CONV_TIMING
+      ++n_claimed;
+#endif
       conv1_tile(m, 0, 2, halo_inside);
     }
     amax1 = conv_absmax_bits(amax1, fmaxf((float)amax1h[0], (float)amax1h[1]));
@@ -731,6 +738,11 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
     printf("[pc] blk%d wave%d tiles %d | per tile: K loop %llu, wait at the post-K barrier %llu, role work (wave 0: epilogue, wave 4: next tile's conv1_1) %llu, wait for stage 0 %llu | mean stages %llu %llu %llu %llu %llu %llu\n",
            bid, wave, n_walk, ts_k / n_walk, ts_bar / n_walk, ts_role / n_walk,
            n_walk > 1 ? ts_tail / (n_walk - 1) : 0ull, ts_st[0] / n_walk, ts_st[1] / n_walk, ts_st[2] / n_walk, ts_st[3] / n_walk, ts_st[4] / n_walk, ts_st[5] / n_walk);
+#endif
+#ifdef SHF_CONV_TIMING
+  if ((bid == 100) && lane == 0)
+    printf("[pc-role] blk%d wave%d per tile: epilogue alone (consumers; producers: 0) %llu, conv1_1 row tiles claimed %.2f\n", bid, wave,
+           ts_epi / (n_walk ? n_walk : 1), (double)n_claimed / (n_walk ? n_walk : 1));
 #endif
 #undef PC_T
 }
