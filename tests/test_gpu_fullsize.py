@@ -338,6 +338,21 @@ def test_c5_two_and_four_ranks_equal_one_rank(tmp_path):
 
 
 @pytest.mark.timeout(1800)
+def test_c5_eight_ranks_like_the_scaling_run(tmp_path):
+    """The command the driver's scaling run ends with -- `python bench.py --gpus 8` -- on the one GPU there is (gloo, all
+    ranks on it): the balanced window schedule (every rank one unit of each kind per window of 8 images) and the north
+    star's strict one-scale-per-GPU form (ranks 0-4 hold 2 flips x 8 images = 16 units = exactly one grouped pass, ranks
+    5-7 only take part in the exchange) both reproduce the 1-rank detections bit for bit."""
+    d1, _ = _run_bench(tmp_path, 1, [], "c5_n1_for8")
+    d8, j8 = _run_bench(tmp_path, 8, ["--shard", "window"], "c5_n8_window", bare=True)
+    np.testing.assert_array_equal(d1, d8)
+    assert j8["n_gpus"] == 8 and j8["collective_ranks"] == 8 and j8["config"]["images_per_step"] == 8
+    d8s, j8s = _run_bench(tmp_path, 8, ["--shard", "strict"], "c5_n8_strict", bare=True)
+    np.testing.assert_array_equal(d1, d8s)
+    assert j8s["config"]["shard"] == "strict"
+
+
+@pytest.mark.timeout(1800)
 def test_more_than_sixteen_units_per_share(tmp_path):
     """A share larger than one grouped pass (16 units: one kernel-argument member table): 9 scales x flip = 18 units per
     image on one rank (FusedDetector.submit splits the image into two passes into the same list), and strict level->rank
