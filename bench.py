@@ -229,6 +229,7 @@ def main():
         import datetime
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        store_dir = None
         pg = dict(rank=rank, world_size=world,
                   timeout=datetime.timedelta(seconds=float(os.environ.get("SHF_BENCH_DIST_TIMEOUT", "600"))))
         if world == 1 and "MASTER_PORT" not in os.environ:   # (--force-dist without a launcher: a file store, no port at all)
@@ -554,10 +555,13 @@ def main():
         # ---- the same stream from image FILES (the reference's hot loop starts at cv2.imread, lib/test.py:113,239-244):
         #      JPEGs of the same 8 shapes in a temp dir -> test.fused_image_loop (decode on reader threads, upload, device
         #      pyramid, grouped pass, two images in flight -- what test.inference_worker runs) -> the WIDER writer
-        if not args.no_files:
+        try:
+            from PIL import Image
+        except ImportError:       # (no decoder in this interpreter: the leg is skipped, the line says nothing about files)
+            Image = None
+        if not args.no_files and Image is not None:
             import shutil
             import tempfile
-            from PIL import Image
             from smallhardface_amd.datasets import write_detections_wider
             from smallhardface_amd.test import fused_image_loop
             tdir = tempfile.mkdtemp(prefix="shf_bench_files_")
@@ -795,6 +799,9 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+        if store_dir:
+            import shutil
+            shutil.rmtree(store_dir, ignore_errors=True)
 
 
 if __name__ == "__main__":

@@ -381,8 +381,9 @@ def fused_image_loop(net, paths, thresh=0.05, timers=None, progress=None, prefet
     flight on the GPU (FusedDetector.submit / collect).  The decodes of the next ``prefetch`` images (default 2; env
     SHF_DECODE_PREFETCH, 0 = decode synchronously like the reference) run on reader threads while image i is being
     submitted and image i - 1 collected: a JPEG decode is 5-15 ms, the GPU's share of an image 11-15 ms, so a
-    synchronous decode on the submitting thread would be exposed.  Returns the per-image (n, 5) detection arrays in order.  ``stats`` (a dict) receives per-image
-    mean milliseconds: decode (on the reader thread), decode_wait / submit / collect_wait (on this thread)."""
+    synchronous decode on the submitting thread would be exposed.  Returns the per-image (n, 5) detection arrays in
+    order.  ``stats`` (a dict) receives per-image mean milliseconds: decode (on the reader threads), decode_wait / submit /
+    collect_wait (on this thread)."""
     import time
     from concurrent.futures import ThreadPoolExecutor
     if timers is None:
