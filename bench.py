@@ -276,8 +276,6 @@ def main():
     n_flip = 2 if cfg.TEST.FLIP else 1
     n_units = len(cfg.TEST.SCALES) * n_flip
     mine = pyramid.my_units(rank, world, world, n_units, shard=args.shard, units_per_level=n_flip)
-    GROUP = 16     # units per grouped pass (one kernel-argument member table); a larger share runs as several passes
-    chunks = [(a, min(a + GROUP, len(mine))) for a in range(0, len(mine), GROUP)]
     units = {}
     cache = {}
     for (i, u) in mine:
@@ -287,17 +285,16 @@ def main():
         t = torch.from_numpy(data).to(dev)
         units[(i, u)] = (t, H, W, im_h, im_w, s, flip)
     del cache
-    export = [torch.empty((cfg.TEST.N_DETS_PER_MODULE, 5), dtype=torch.float32, device=dev)
-              for _ in range(len(mine))] if dist_path else None
     thresh = 0.05
     last = {}
 
-    from smallhardface_amd.test import FusedDetector
-    fd = FusedDetector(net, n_lanes=(n_units if args.mode == 'group' else args.lanes), mode=args.mode)
-    lanes = fd.lanes
+    fd = sd = None
     if world == 1:
         unit_list = [(units[(0, u)][0].data_ptr(),) + units[(0, u)][1:] for u in range(n_units)]
     if not dist_path:
+        from smallhardface_amd.test import FusedDetector
+        fd = FusedDetector(net, n_lanes=(n_units if args.mode == 'group' else args.lanes), mode=args.mode)
+        lanes = fd.lanes
         if args.host_input == "blobs":
             host_list = [(units[(0, u)][0].cpu().numpy(),) + units[(0, u)][1:] for u in range(n_units)]
         elif args.host_input == "image":
@@ -305,47 +302,14 @@ def main():
             dp = DevicePyramid(net, n_slots=2)
             host_im = np.random.default_rng(1000).integers(0, 256, (src_hw[0], src_hw[1], 3)).astype(np.uint8)
     else:
-        # two lane sets: window k+1's convolutions are enqueued (on the other set's head stream) before window
-        # k's detections are exported, gathered over RCCL and merged -- the exchange hides under compute
-        # (the root net keeps out of both sets: its image list is where the gathered rows are merged)
-        while len(lanes) < 1 + 2 * len(mine):
-            lanes.append(net.clone())
-        lane_sets = [lanes[1:1 + len(mine)], lanes[1 + len(mine):1 + 2 * len(mine)]]
-        # both windows' convolutions on ONE in-order stream, the tails / exports on the set heads' own high-priority
-        # streams, the merges on the root net's (shf_net_set_pipeline): no dependence on how the runtime maps streams
-        # to hardware queues
-        for h in [ls[a] for ls in lane_sets for (a, _) in chunks] + [net]:
-            h.set_pipeline(True)
-        export_sets = [export, [torch.empty_like(e) for e in export]]
+        # the N>1 schedule lives in the package (smallhardface_amd/pyramid.py ShardedDetector: two lane sets, grouped
+        # passes with per-member lists, export -> ONE all_to_all per window -> import -> merge on the owner, window k + 1's
+        # convolutions enqueued before window k's detections travel); this file only feeds it the resident window
+        sd = pyramid.ShardedDetector(net, rank, world, n_units, units_per_level=n_flip, shard=args.shard, thresh=thresh,
+                                     device=dev, force_collective=args.force_dist)
+        lanes = sd.nets
         mine_units = [(units[k][0].data_ptr(),) + units[k][1:] for k in mine]
-    state = {"k": 0, "pending": None, "collectives": 0}
     host_trace = [] if os.environ.get("SHF_BENCH_HOST_TRACE") == "1" else None   # diagnostics: where the host waits
-
-    dist_t = {"enqueue": 0.0, "export": 0.0, "gather": 0.0, "merge": 0.0}   # (SHF_BENCH_HOST_TRACE=1: where the host's time goes)
-
-    def finish_window(w):
-        ls, ex = lane_sets[w], export_sets[w]
-        t_a = time.perf_counter()
-        counts = []
-        for (a, b) in chunks:     # (each pass was enqueued on its own head lane ls[a])
-            counts += ls[a].detect_export_many(ls[a:b], [e.data_ptr() for e in ex[a:b]], cfg.TEST.N_DETS_PER_MODULE)
-        t_b = time.perf_counter()
-        local = {i: [] for i in range(world)}   # per image: the units' export buffers as they are (no concatenation)
-        for m, (i, u) in enumerate(mine):
-            if counts[m]:
-                local[i].append(ex[m][:min(counts[m], cfg.TEST.N_DETS_PER_MODULE)])
-        got = pyramid.gather_window(local, world, rank, world, device=dev, force_collective=args.force_dist)
-        state["collectives"] += 1
-        t_c = time.perf_counter()
-        for i, t in got.items():            # (gather_window has synchronised on the received header rows)
-            net.detect_begin()
-            t = t.contiguous()
-            net.detect_import(t.data_ptr(), int(t.shape[0]))
-            last[i] = net.detect_finish(cfg.TEST.NMS_METHOD, cfg.TEST.NMS_THRESH)
-        t_d = time.perf_counter()
-        dist_t["export"] += t_b - t_a
-        dist_t["gather"] += t_c - t_b
-        dist_t["merge"] += t_d - t_c
 
     def step():
         if not dist_path and args.mode == "streams":  # the older per-unit-streams schedule: one image at a time
@@ -368,26 +332,16 @@ def main():
                 if host_trace is not None:
                     host_trace.append(("collect<", time.perf_counter()))
             return
-        # this rank's units (from different images) as ONE grouped pass; every lane keeps the detections of its
-        # unit, which are then routed to the unit's image
-        w = state["k"] & 1
-        state["k"] += 1
-        ls = lane_sets[w]
-        t_e = time.perf_counter()
-        for (a, b) in chunks:
-            ls[a].detect_add_levels(ls[a:b], mine_units[a:b], thresh, on_device=True, per_member_lists=True)
-        dist_t["enqueue"] += time.perf_counter() - t_e
-        if state["pending"] is not None:
-            finish_window(state["pending"])
-        state["pending"] = w
+        # this rank's units (from different images) as grouped passes; the window submitted before this one is finished
+        # behind them (ShardedDetector.submit)
+        last.update(sd.submit(mine_units))
 
     def fence():
-        while not dist_path and fd.pending() > 0:
+        while fd is not None and fd.pending() > 0:
             last[0] = fd.collect()[0]
-        if dist_path and state["pending"] is not None:
-            finish_window(state["pending"])
-            state["pending"] = None
-        for ln in lanes + getattr(fd, "_heads", []):
+        if sd is not None:
+            last.update(sd.flush())
+        for ln in lanes + (getattr(fd, "_heads", []) if fd is not None else []):
             ln.sync()
         torch.cuda.synchronize()
         if dist is not None:
@@ -398,7 +352,7 @@ def main():
     for _ in range(2):
         step()
     fence()
-    prof_nets = lanes + getattr(fd, "_heads", [])
+    prof_nets = lanes + (getattr(fd, "_heads", []) if fd is not None else [])
 
     def read_prof():
         acc = {}
@@ -442,7 +396,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if host_trace is not None and dist_path:
-        print("host time per window (ms): " + ", ".join("%s %.2f" % (k, 1e3 * v / max(1, state["k"])) for k, v in dist_t.items()), file=sys.stderr)
+        print("host time per window (ms): " + ", ".join("%s %.2f" % (k, 1e3 * v / max(1, sd.collectives)) for k, v in sd.host_seconds.items()), file=sys.stderr)
     if host_trace:
         base = [t for k, t in host_trace if t >= t0][0]
         print(" ".join("%s%.2f" % (k, 1000 * (t - base)) for k, t in host_trace if t >= t0)[:4000], file=sys.stderr)
@@ -716,7 +670,7 @@ def main():
             out["rccl_ranks"] = int(ranks_seen) if args.backend == "nccl" else 0   # (sum of a 1-element all_reduce of ones)
             out["collective_ranks"] = int(ranks_seen)
             out["collective_backend"] = str(dist.get_backend())
-            out["collectives_issued_rank0"] = int(state["collectives"])
+            out["collectives_issued_rank0"] = int(sd.collectives)
             out["all_ranks_on_one_gpu"] = bool(one_gpu)
         if latency_ms is not None:
             out["latency_ms"] = latency_ms

@@ -277,14 +277,78 @@ void shf_net::forward() {
     }
     break;
   }
+  // (tail-fused blobs too: "newer" for them means the tail workspace holds this forward's logits -- read on demand)
   for (size_t i = 0; i < blobs.size(); ++i)
-    if (!std::count(inputs.begin(), inputs.end(), (int)i) && blobs[i].kind != BK_FUSED) blobs[i].dev_newer = true;
+    if (!std::count(inputs.begin(), inputs.end(), (int)i)) blobs[i].dev_newer = true;
+}
+
+// Blob.data of a blob whose producer was folded into the detection tail (the cls / bbox 1x1 convs, the score concat /
+// reshape, the softmax): pycaffe exposes every blob after forward() (pycaffe.py:24-32, _caffe.cpp:222-242), and someone
+// debugging through the shim reads them.  Nothing extra is computed in forward(): the logits kernel leaves
+// [K][A][cls0, cls1, dx, dy, dw, dh] in the tail workspace and the tail writes the softmax as the (1, 2A, h, w) blob the
+// proposal layer reads; the read-back re-orders those on the host into the blob's own NCHW shape.
+void shf_net::materialize_fused(int bi) {
+  Blob& b = blobs[bi];
+  const size_t n = b.count();
+  b.host.ensure(std::max<size_t>(n, 1) * 4);
+  if (!b.dev_newer || n == 0) return;          // (never forwarded: zeros, like a Caffe blob before its first forward)
+  const int A = tail_A;
+  const int h = blobs[tail_feat_blobs[0]].shape[2], w = blobs[tail_feat_blobs[0]].shape[3];
+  const size_t K = (size_t)h * w;
+  float* out = b.host.p;
+  if (b.fused_role == FR_PROB_PLANES) {
+    if (n != K * A * 2) throw std::runtime_error("blob '" + b.name + "': unexpected shape for the softmax output");
+    HIP_THROW(hipMemcpyAsync(out, blobs[tail_cls_blob].dev.p, n * 4, hipMemcpyDeviceToHost, stream));
+    HIP_THROW(hipStreamSynchronize(stream));
+    b.dev_newer = false;
+    return;
+  }
+  std::vector<float> lg(K * A * 6);
+  HIP_THROW(hipMemcpyAsync(lg.data(), tw.logits, lg.size() * 4, hipMemcpyDeviceToHost, stream));
+  HIP_THROW(hipStreamSynchronize(stream));
+  auto L = [&](size_t k, int a, int o) { return lg[(k * A + a) * 6 + o]; };
+  const bool per_head = tail_heads != 1;
+  switch (b.fused_role) {
+    case FR_CLS_CONV:
+      if (n != (per_head ? 2 : 2 * (size_t)A) * K) throw std::runtime_error("blob '" + b.name + "': unexpected shape");
+      if (per_head) {
+        for (int c = 0; c < 2; ++c)
+          for (size_t k = 0; k < K; ++k) out[c * K + k] = L(k, b.fused_head, c);
+      } else {
+        for (int c = 0; c < 2; ++c)
+          for (int a = 0; a < A; ++a)
+            for (size_t k = 0; k < K; ++k) out[((size_t)c * A + a) * K + k] = L(k, a, c);
+      }
+      break;
+    case FR_BOX_CONV:
+      if (n != (per_head ? 4 : 4 * (size_t)A) * K) throw std::runtime_error("blob '" + b.name + "': unexpected shape");
+      if (per_head) {
+        for (int j = 0; j < 4; ++j)
+          for (size_t k = 0; k < K; ++k) out[j * K + k] = L(k, b.fused_head, 2 + j);
+      } else {
+        for (int a = 0; a < A; ++a)
+          for (int j = 0; j < 4; ++j)
+            for (size_t k = 0; k < K; ++k) out[((size_t)a * 4 + j) * K + k] = L(k, a, 2 + j);
+      }
+      break;
+    case FR_CLS_PLANES:   // (1, 2, A*h, w): plane c, rows a*h .. a*h + h - 1 = head / anchor a
+      if (n != 2 * (size_t)A * K) throw std::runtime_error("blob '" + b.name + "': unexpected shape");
+      for (int c = 0; c < 2; ++c)
+        for (int a = 0; a < A; ++a)
+          for (size_t k = 0; k < K; ++k) out[((size_t)c * A + a) * K + k] = L(k, a, c);
+      break;
+    default:
+      throw std::runtime_error("blob '" + b.name + "' is fused into the detection tail and has no read-back rule");
+  }
+  b.dev_newer = false;
 }
 
 float* shf_net::host_data(int bi) {
   Blob& b = blobs[bi];
-  if (b.kind == BK_FUSED)
-    throw std::runtime_error("blob '" + b.name + "' is fused into the detection tail and not materialised");
+  if (b.kind == BK_FUSED) {
+    materialize_fused(bi);
+    return b.host.p;
+  }
   const size_t n = b.count();
   b.host.ensure(std::max<size_t>(n, 1) * 4);
   const bool is_input = std::count(inputs.begin(), inputs.end(), bi) > 0;

@@ -323,7 +323,19 @@ void shf_net::build(const std::string& text, const char* caffemodel) {
         throw std::runtime_error("tail: predictor channel counts do not match the anchors");
     for (int li2 : fused_layers) {
       layers[li2].op = OP_SKIP;
-      for (int t : layers[li2].tops) blobs[t].kind = BK_FUSED;
+      // what the top holds, for the on-demand read-back (shf_net::materialize_fused)
+      int role = FR_NONE, head = -1;
+      for (int i = 0; i < tail_heads; ++i) {
+        if (tail_cls_layers[i] == li2) role = FR_CLS_CONV, head = i;
+        if (tail_box_layers[i] == li2) role = FR_BOX_CONV, head = i;
+      }
+      if (role == FR_NONE && layers[li2].type == "Softmax") role = FR_PROB_PLANES;
+      if (role == FR_NONE && (layers[li2].type == "Concat" || layers[li2].type == "Reshape")) role = FR_CLS_PLANES;
+      for (int t : layers[li2].tops) {
+        blobs[t].kind = BK_FUSED;
+        blobs[t].fused_role = role;
+        blobs[t].fused_head = head;
+      }
     }
     blobs[tail_cls_blob].kind = BK_NCHW_MAT;
     blobs[tail_box_blob].kind = BK_NCHW_MAT;

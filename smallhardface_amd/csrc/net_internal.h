@@ -128,11 +128,24 @@ struct Blob {
   bool host_newer = false, dev_newer = false;
   const float* ext_dev = nullptr;  // externally bound device input (fused path)
   bool split_fused = false;        // fused split-fp16 path: stored pre-split ([chunk][hi|lo] fp16), see ConvArgs::in_split
+  // BK_FUSED blobs (tops of the layers folded into the detection tail) are materialised ON DEMAND when Blob.data is read
+  // after Net.forward() (shf_net::materialize_fused): what they hold, and for a predictor's top which head it belongs to
+  int fused_role = 0;              // FusedRole
+  int fused_head = -1;
   size_t count() const {
     size_t c = 1;
     for (int d : shape) c *= (size_t)d;
     return c;
   }
+};
+
+// what a tail-fused blob holds (pycaffe exposes every blob after forward(), pycaffe.py:24-32 / _caffe.cpp:222-242)
+enum FusedRole {
+  FR_NONE = 0,
+  FR_CLS_CONV,     // top of a class-score 1x1 conv: (1, 2, h, w) per head, or (1, 2A, h, w) channel = cls * A + a (plain template)
+  FR_BOX_CONV,     // top of a bbox 1x1 conv: (1, 4, h, w) per head, or (1, 4A, h, w) channel = 4a + j
+  FR_CLS_PLANES,   // the pre-softmax (1, 2, A*h, w) tensor: axis-2 Concat of the heads' scores, or the plain template's Reshape
+  FR_PROB_PLANES   // the Softmax's top, (1, 2, A*h, w): the memory of the materialised (1, 2A, h, w) cls_prob blob
 };
 
 enum OpType { OP_SKIP, OP_CONV, OP_POOL, OP_DECONV, OP_TAIL };
@@ -460,6 +473,7 @@ struct shf_net {
   void ensure_img_cap(int units_after);
   void forward();
   float* host_data(int bi);
+  void materialize_fused(int bi);   // Blob.data of a tail-fused blob, re-ordered on the host from the tail workspace
   void load_caffemodel(const std::string& path);
 };
 

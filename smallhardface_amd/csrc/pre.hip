@@ -6,7 +6,8 @@
 // The arithmetic is the host mirror's (smallhardface_amd/test_utils.py resize_bilinear), which restates OpenCV's
 // published INTER_LINEAR path for a CV_64F image (cv::resize / hal::resize / HResizeLinear / VResizeLinear in
 // modules/imgproc/src/resize.cpp): scale = 1 / f once in double; the source coordinate is narrowed to FLOAT before its
-// floor is subtracted (in float); the weights 1.f - fx and fx are floats widened to double; the mean-subtracted image
+// floor is subtracted (in float); the weights 1.f - fx and fx are floats widened to double (columns: weight zeroed at the
+// border; rows: the two row indices clipped, weights kept -- row_coef); the mean-subtracted image
 // is float64 (uint8 -> f32 minus f64 PIXEL_MEANS); products and sums are separate roundings (this file is built with
 // -ffp-contract=off), and only the finished level is narrowed to f32.  When both scale factors are exactly 2x down,
 // cv::resize replaces INTER_LINEAR by the INTER_AREA fast path (resizeAreaFast_Invoker<double, double, NoVec>): the four
@@ -44,6 +45,20 @@ __device__ inline AxisCoef axis_coef(int d, int n_src, double inv_f) {
   c.i1 = sx + 1 < n_src ? sx + 1 : n_src - 1;
   c.a0 = (double)(1.f - fx);
   c.a1 = (double)fx;
+  return c;
+}
+
+// the vertical table: no border rule on the weight -- resizeGeneric_Invoker clips the two source ROW INDICES
+// (clip(sy + k, 0, src_h), k = 0, 1) and keeps beta = {1.f - fy, fy} (test_utils.py _row_coeffs, oracle/resize.py y_table)
+__device__ inline AxisCoef row_coef(int d, int n_src, double inv_f) {
+  float fy = (float)(((double)d + 0.5) * inv_f - 0.5);
+  const int sy = (int)floorf(fy);
+  fy -= (float)sy;
+  AxisCoef c;
+  c.i0 = sy < 0 ? 0 : (sy < n_src ? sy : n_src - 1);
+  c.i1 = sy + 1 < 0 ? 0 : (sy + 1 < n_src ? sy + 1 : n_src - 1);
+  c.a0 = (double)(1.f - fy);
+  c.a1 = (double)fy;
   return c;
 }
 
@@ -92,7 +107,7 @@ __global__ void __launch_bounds__(256) pyramid_level_kernel(const uint8_t* __res
     return;
   }
   const double inv_f = 1.0 / scale;
-  const AxisCoef cy = axis_coef(y, im_h, inv_f);
+  const AxisCoef cy = row_coef(y, im_h, inv_f);
   const AxisCoef cx = axis_coef(flip ? lvl_w - 1 - x : x, im_w, inv_f);
   const uint8_t* r0 = im + (size_t)cy.i0 * im_w * 3;
   const uint8_t* r1 = im + (size_t)cy.i1 * im_w * 3;

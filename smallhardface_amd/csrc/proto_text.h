@@ -60,10 +60,14 @@ class TextParser {
     auto m = message(0);
     return m;
   }
+  // protobuf's own text / wire parsers stop at a recursion depth of 100 (io::CodedInputStream default_recursion_limit_);
+  // without a limit a file of 10^6 '{' overflows the stack of the process that only wanted to load a model
+  static constexpr int kMaxDepth = 100;
 
  private:
   const std::string& s_;
   size_t i_ = 0;
+  int depth_ = 0;
   void skip() {
     for (;;) {
       while (i_ < s_.size() && (isspace((unsigned char)s_[i_]) || s_[i_] == ',' || s_[i_] == ';')) ++i_;
@@ -122,7 +126,9 @@ class TextParser {
       if (s_[i_] == '{' || s_[i_] == '<') {
         const char c = s_[i_] == '{' ? '}' : '>';
         ++i_;
+        if (++depth_ > kMaxDepth) throw std::runtime_error("prototxt: messages nested deeper than " + std::to_string(kMaxDepth));
         f.msg = message(c);
+        --depth_;
         m->fields.push_back(f);
       } else if (s_[i_] == '[') {
         ++i_;
@@ -269,17 +275,23 @@ inline WireBlob read_blob(WireReader r) {
     }
   }
   if (b.shape.empty() && has_legacy) b.shape.assign(legacy, legacy + 4);
+  // Blob::Reshape (blob.cpp:23-51): every dim >= 0 and the running count <= INT_MAX; Blob::FromProto (blob.cpp:430-…):
+  // the float data, when present, has exactly count elements
+  if (b.shape.size() > 32) throw std::runtime_error("caffemodel: blob with more than 32 axes");
+  int64_t count = 1;
+  for (int64_t d : b.shape) {
+    if (d < 0) throw std::runtime_error("caffemodel: negative blob dimension");
+    if (d != 0 && count > (int64_t)INT32_MAX / d) throw std::runtime_error("caffemodel: blob size exceeds INT_MAX");
+    count *= d;
+  }
+  if (!b.shape.empty() && !b.data.empty() && (int64_t)b.data.size() != count)
+    throw std::runtime_error("caffemodel: blob data does not match its shape");
   return b;
 }
 
 // NetParameter.layer = 100 (LayerParameter: name=1, type=2, blobs=7); caffe.proto:64-96,306-…
-inline std::vector<WireLayer> read_caffemodel(const std::string& path) {
-  std::ifstream f(path, std::ios::binary);
-  if (!f) throw std::runtime_error("could not open " + path);
-  std::stringstream ss;
-  ss << f.rdbuf();
-  const std::string buf = ss.str();
-  WireReader r((const uint8_t*)buf.data(), buf.size());
+inline std::vector<WireLayer> parse_caffemodel(const uint8_t* data, size_t size) {
+  WireReader r(data, size);
   std::vector<WireLayer> out;
   while (!r.done()) {
     int wt;
@@ -315,6 +327,15 @@ inline std::vector<WireLayer> read_caffemodel(const std::string& path) {
     }
   }
   return out;
+}
+
+inline std::vector<WireLayer> read_caffemodel(const std::string& path) {
+  std::ifstream f(path, std::ios::binary);
+  if (!f) throw std::runtime_error("could not open " + path);
+  std::stringstream ss;
+  ss << f.rdbuf();
+  const std::string buf = ss.str();
+  return parse_caffemodel((const uint8_t*)buf.data(), buf.size());
 }
 
 }  // namespace shf

@@ -185,6 +185,126 @@ def gather_window(local, n_images, rank, world, device=None, group=None, force_c
     return out
 
 
+GROUP_UNITS = 16   # units per grouped pass (one kernel-argument member table: csrc/conv_common.h MAX_GROUP)
+
+
+class ShardedDetector(object):
+    """One rank's half of the pyramid-sharded schedule (north star / SURVEY.md §8e; the reference's analogue is the
+    image-range split with a Queue gather, lib/test.py:327-344).
+
+    A WINDOW is ``world`` images.  ``self.mine`` = the (image-in-window, unit) pairs this rank runs (``my_units``:
+    shard "window" or "strict").  ``submit(units)`` enqueues this rank's units of the next window as grouped passes of
+    at most GROUP_UNITS units -- every lane keeps the detections of ITS unit (per-member lists) -- on one of TWO lane
+    sets, and then finishes the window submitted before it: export of every unit's rows, ONE all_to_all to the images'
+    owner ranks (``gather_window``), import into the root net's image list and bbox_vote / NMS there.  So window k + 1's
+    convolutions are already queued while window k's detections travel and merge: the exchange hides under compute.
+    ``flush()`` finishes what is still pending.  Both return {image-in-window: (n, 5) float64 detections} for the
+    images this rank OWNS (``image_owner``).
+
+    Streams: both windows' convolutions share ONE in-order stream, tails and exports run on the set heads' own
+    high-priority streams, the merges on the root net's (shf_net_set_pipeline) -- independent of how the runtime maps
+    streams to hardware queues.  The root net is in neither lane set: its image list is where gathered rows merge.
+
+    Every rank must make the same sequence of submit / flush calls (each finished window is one collective), also a
+    rank whose share is empty (strict sharding with more ranks than levels)."""
+
+    def __init__(self, net, rank, world, n_units, units_per_level=2, shard="window", thresh=0.05, device=None,
+                 group=None, force_collective=False, cap_rows=None):
+        import torch
+        from .config import cfg
+        self.net, self.rank, self.world = net, int(rank), int(world)
+        self.shard, self.thresh, self.group = shard, float(thresh), group
+        self.force_collective = bool(force_collective)
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+        self.cap_rows = int(cap_rows or cfg.TEST.N_DETS_PER_MODULE)
+        self.mine = my_units(self.rank, self.world, self.world, n_units, shard=shard, units_per_level=units_per_level)
+        n = len(self.mine)
+        self.chunks = [(a, min(a + GROUP_UNITS, n)) for a in range(0, n, GROUP_UNITS)]
+        self.lane_sets = [[net.clone() for _ in range(n)] for _ in range(2)]
+        for h in [ls[a] for ls in self.lane_sets for (a, _) in self.chunks] + [net]:
+            h.set_pipeline(True)
+        self.export_sets = [[torch.empty((self.cap_rows, 5), dtype=torch.float32, device=self.device) for _ in range(n)]
+                            for _ in range(2)]
+        self._k = 0
+        self._pending = None      # (lane set, [(image, unit)] of that window, n_valid images)
+        self.collectives = 0
+        self.host_seconds = {"enqueue": 0.0, "export": 0.0, "gather": 0.0, "merge": 0.0}
+
+    @property
+    def nets(self):
+        """Every net / lane that launches kernels for this detector (profiling, synchronisation)."""
+        return [self.net] + self.lane_sets[0] + self.lane_sets[1]
+
+    def submit(self, units, picks=None, n_valid=None):
+        """Enqueue this rank's units of the next window; finish and return the previous one ({} for the first).
+
+        ``units``: (data, H, W, im_h, im_w, scale, flip) tuples with DEVICE pointers, aligned with ``picks`` (default
+        ``self.mine``; a last, partly filled window passes the pairs it has, in ``self.mine`` order).  ``n_valid``: images
+        the window really holds (default ``world``); owners of the others get nothing back."""
+        import time
+        picks = self.mine if picks is None else list(picks)
+        units = list(units)
+        if len(units) != len(picks) or len(picks) > len(self.mine):
+            raise ValueError("ShardedDetector.submit: %d units for %d picks (this rank's share is %d)"
+                             % (len(units), len(picks), len(self.mine)))
+        w = self._k & 1
+        self._k += 1
+        ls = self.lane_sets[w]
+        t0 = time.perf_counter()
+        for a in range(0, len(picks), GROUP_UNITS):
+            b = min(a + GROUP_UNITS, len(picks))
+            ls[a].detect_add_levels(ls[a:b], units[a:b], self.thresh, on_device=True, per_member_lists=True)
+        self.host_seconds["enqueue"] += time.perf_counter() - t0
+        done = self._finish() if self._pending is not None else {}
+        self._pending = (w, picks, self.world if n_valid is None else int(n_valid))
+        return done
+
+    def flush(self):
+        """Finish the pending window (one collective) and return its detections; {} when nothing is pending."""
+        if self._pending is None:
+            return {}
+        done = self._finish()
+        self._pending = None
+        return done
+
+    def _finish(self):
+        import time
+        from .config import cfg
+        w, picks, n_valid = self._pending
+        ls, ex = self.lane_sets[w], self.export_sets[w]
+        t_a = time.perf_counter()
+        counts = []
+        for a in range(0, len(picks), GROUP_UNITS):       # (each pass was enqueued on its own head lane ls[a])
+            b = min(a + GROUP_UNITS, len(picks))
+            counts += ls[a].detect_export_many(ls[a:b], [e.data_ptr() for e in ex[a:b]], self.cap_rows)
+        t_b = time.perf_counter()
+        local = {i: [] for i in range(self.world)}        # per image: the units' export buffers as they are
+        for m, (i, _) in enumerate(picks):
+            if counts[m]:
+                local[i].append(ex[m][:min(counts[m], self.cap_rows)])
+        got = gather_window(local, self.world, self.rank, self.world, device=self.device, group=self.group,
+                            force_collective=self.force_collective)
+        self.collectives += 1
+        t_c = time.perf_counter()
+        out = {}
+        for i, t in got.items():                          # (gather_window has synchronised on the received header rows)
+            if i >= n_valid:
+                continue
+            self.net.detect_begin()
+            t = t.contiguous()
+            self.net.detect_import(t.data_ptr(), int(t.shape[0]))
+            out[i] = self.net.detect_finish(cfg.TEST.NMS_METHOD, cfg.TEST.NMS_THRESH)
+        t_d = time.perf_counter()
+        self.host_seconds["export"] += t_b - t_a
+        self.host_seconds["gather"] += t_c - t_b
+        self.host_seconds["merge"] += t_d - t_c
+        return out
+
+    def sync(self):
+        for ln in self.nets:
+            ln.sync()
+
+
 def level_flops(H, W):
     """Algorithmic conv FLOPs of one unit: 2 * 361460 MAC per input pixel."""
     return 2.0 * 361460.0 * H * W

@@ -176,29 +176,45 @@ class DevicePyramid(object):
         self._k = 0
 
     def units(self, im, scales=None, im_dev=None, net=None):
+        return self.window_units([im], None, scales=[scales], im_devs=[im_dev], net=net)
+
+    def window_units(self, ims, picks=None, scales=None, im_devs=None, net=None):
+        """The units ``picks`` = [(image index in ``ims``, unit index)] (default: every unit of every image, image-major)
+        of several images in ONE slot: what a rank of the pyramid-sharded schedule runs of a window
+        (pyramid.ShardedDetector) -- an image none of whose units is picked is not uploaded."""
         import torch
         net = net or self.net
-        if scales is None:
-            scales = pyramid_scales(im.shape)
-        im_h, im_w = im.shape[:2]
-        if im_dev is None:
-            im_dev = torch.from_numpy(np.ascontiguousarray(im, dtype=np.uint8)).to("cuda", non_blocking=False)
-        geo = []
-        for s in scales:
-            lh, lw, H, W = caffe.pyramid_level_shape(im_h, im_w, s, cfg.MAX_RESOLUTION)
-            for flip in ([False, True] if cfg.TEST.FLIP else [False]):
-                geo.append((lh, lw, H, W, s, flip))
-        total = sum(3 * g[2] * g[3] for g in geo)
+        geos = []
+        for k, im in enumerate(ims):
+            sc = scales[k] if scales is not None and scales[k] is not None else pyramid_scales(im.shape)
+            im_h, im_w = im.shape[:2]
+            geo = []
+            for s in sc:
+                lh, lw, H, W = caffe.pyramid_level_shape(im_h, im_w, s, cfg.MAX_RESOLUTION)
+                for flip in ([False, True] if cfg.TEST.FLIP else [False]):
+                    geo.append((lh, lw, H, W, s, flip))
+            geos.append(geo)
+        if picks is None:
+            picks = [(k, u) for k in range(len(ims)) for u in range(len(geos[k]))]
+        devs = {}
+        for k in sorted(set(k for k, _ in picks)):
+            d = im_devs[k] if im_devs is not None else None
+            if d is None:
+                d = torch.from_numpy(np.ascontiguousarray(ims[k], dtype=np.uint8)).to("cuda", non_blocking=False)
+            devs[k] = d
+        total = sum(3 * geos[k][u][2] * geos[k][u][3] for k, u in picks)
         slot = self._slots[self._k]
         if slot is None or slot[0].numel() < total:
-            slot = [torch.empty(total, dtype=torch.float32, device="cuda"), None]
-        slot[1] = im_dev  # keep the image alive while the kernels are in flight
+            slot = [torch.empty(max(total, 1), dtype=torch.float32, device="cuda"), None]
+        slot[1] = devs  # keep the images alive while the kernels are in flight
         self._slots[self._k] = slot
         self._k = (self._k + 1) % len(self._slots)
         out, off = [], 0
-        for lh, lw, H, W, s, flip in geo:
+        for k, u in picks:
+            lh, lw, H, W, s, flip = geos[k][u]
+            im_h, im_w = ims[k].shape[:2]
             ptr = slot[0].data_ptr() + 4 * off
-            net.make_pyramid_level(im_dev.data_ptr(), im_h, im_w, s, flip, cfg.PIXEL_MEANS, ptr, H, W, lh, lw)
+            net.make_pyramid_level(devs[k].data_ptr(), im_h, im_w, s, flip, cfg.PIXEL_MEANS, ptr, H, W, lh, lw)
             out.append((ptr, H, W, lh, lw, s, flip))
             off += 3 * H * W
         return out
@@ -533,6 +549,122 @@ def _gather_results(result_queue, procs, poll_seconds=0.5, grace_polls=20):
     return [got[r] for r in sorted(got)]
 
 
+def dist_env():
+    """(rank, world, local_rank) of a process started by torch.distributed.run / torchrun; (0, 1, 0) otherwise."""
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")),
+            int(os.environ.get("LOCAL_RANK", os.environ.get("RANK", "0"))))
+
+
+def pyramid_sharded_inference(imdb, target_test, thresh=0.05, strict=False, progress_every=0):
+    """``TEST.SHARD = "pyramid"`` (or "pyramid_strict"): the north star's split of the work -- the PYRAMID of every image is
+    sharded over the ranks of a torch.distributed job (one process per GPU, started by ``torch.distributed.run``), not the
+    image list (lib/test.py:327-344, which ``TEST.SHARD = "images"`` keeps).  Windows of ``world`` images go through
+    pyramid.ShardedDetector: every rank decodes the window's images, builds ITS units on the device (DevicePyramid),
+    runs them as grouped passes, and the > thresh rows travel to the image's owner rank in ONE all_to_all per window
+    (RCCL; ``SHF_DIST_BACKEND=gloo`` for validation with several ranks on one GPU), which merges them.  At the end the
+    owners' results are all-gathered so that every rank returns the full ``dets[class][image]`` lists.
+
+    Device of rank r: ``TEST.GPU_ID[r]`` when the list has one entry per rank (``[0,0]``: two ranks on one GPU, gloo),
+    LOCAL_RANK otherwise."""
+    import torch
+    from concurrent.futures import ThreadPoolExecutor
+    from .pyramid import ShardedDetector
+    rank, world, local = dist_env()
+    ids = cfg.TEST.GPU_ID if not isinstance(cfg.TEST.GPU_ID, int) else [cfg.TEST.GPU_ID]
+    dev_id = int(ids[rank]) if len(ids) == world else local
+    if len(cfg.TEST.SCALES) <= 1 or len(cfg.TEST.LEVEL) > 0:
+        raise ValueError("TEST.SHARD pyramid needs the pyramid path (several TEST.SCALES, no TEST.LEVEL subset)")
+    if not str(cfg.TEST.MODEL):
+        raise IOError("TEST.MODEL is empty: pass --amend TEST.MODEL <file>.caffemodel")
+    torch.cuda.set_device(dev_id)
+    dist, own_group = None, False
+    if world > 1:
+        import datetime
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            backend = os.environ.get("SHF_DIST_BACKEND", "nccl")
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            kw = dict(rank=rank, world_size=world,
+                      timeout=datetime.timedelta(seconds=float(os.environ.get("SHF_DIST_TIMEOUT", "600"))))
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", dev_id), **kw)
+            else:
+                dist.init_process_group(backend, **kw)
+            own_group = True
+    try:
+        cfg.GPU_ID = dev_id
+        caffe.set_mode_gpu()
+        caffe.set_device(dev_id)
+        net = caffe.Net(str(target_test), str(cfg.TEST.MODEL), caffe.TEST)
+        if "SHF_CONV_MODE" not in os.environ:
+            net.set_conv_mode("f16x3")
+        n_flip = 2 if cfg.TEST.FLIP else 1
+        n_units = len(cfg.TEST.SCALES) * n_flip
+        sd = ShardedDetector(net, rank, world, n_units, units_per_level=n_flip, shard="strict" if strict else "window",
+                             thresh=thresh, device=torch.device("cuda", dev_id))
+        dp = DevicePyramid(net, n_slots=2)   # window k + 1 is built while window k is in flight; k - 1 is finished
+        n = len(imdb)
+        n_windows = (n + world - 1) // world
+        owned = {}
+
+        def window_plan(w):
+            base = w * world
+            n_valid = min(world, n - base)
+            picks = [(i, u) for (i, u) in sd.mine if i < n_valid]
+            need = sorted(set(i for i, _ in picks))
+            return base, n_valid, picks, need
+
+        def read(i):
+            im = _imread(imdb.image_path_at(i))
+            if im is None:
+                raise IOError("cannot read image %s" % imdb.image_path_at(i))
+            return im
+
+        pool = ThreadPoolExecutor(max_workers=max(1, min(4, world)))
+        try:
+            ahead = None
+            prev_base = None
+            for w in range(n_windows):
+                base, n_valid, picks, need = window_plan(w)
+                futs = ahead if ahead is not None else {i: pool.submit(read, base + i) for i in need}
+                if w + 1 < n_windows:                       # the next window's decodes run under this window's GPU work
+                    nb, _, _, nneed = window_plan(w + 1)
+                    ahead = {i: pool.submit(read, nb + i) for i in nneed}
+                else:
+                    ahead = None
+                ims = [futs[i].result() for i in need]
+                remap = {i: k for k, i in enumerate(need)}
+                ls = sd.lane_sets[sd._k & 1]                # the pass's head: its pre-processing runs in front of its convolutions
+                head = ls[0] if ls else net                 # (a rank without a share -- strict sharding, more ranks than levels)
+                units = dp.window_units(ims, [(remap[i], u) for (i, u) in picks], net=head)
+                done = sd.submit(units, picks=picks, n_valid=n_valid)
+                for i, d in done.items():
+                    owned[prev_base + i] = d
+                prev_base = base
+                if progress_every and rank == 0 and (w + 1) % progress_every == 0:
+                    print('\r{:02d}% of {} windows'.format(int(100 * (w + 1) / n_windows), n_windows), end='')
+            for i, d in sd.flush().items():
+                owned[prev_base + i] = d
+        finally:
+            pool.shutdown(wait=True)
+        sd.sync()
+        if dist is not None:
+            parts = [None] * world
+            dist.all_gather_object(parts, owned)
+            owned = {}
+            for p_ in parts:
+                owned.update(p_)
+        assert sorted(owned) == list(range(n)), "Detection result compromised"
+        dets = [[[] for _ in range(n)] for _ in range(imdb.num_classes)]
+        for i in range(n):
+            dets[1][i] = owned[i]
+        return dets
+    finally:
+        if own_group:
+            dist.barrier()
+            dist.destroy_process_group()
+
+
 def test_net(imdb, output_dir, target_test, thresh=0.05, no_cache=False, step=0):
     logger.info('Evaluating {} on {}'.format(cfg.NAME, imdb.name))
     run_inference = True
@@ -548,7 +680,17 @@ def test_net(imdb, output_dir, target_test, thresh=0.05, no_cache=False, step=0)
             except Exception:
                 logger.warning('Could not load the cached detections file, detecting from scratch!')
 
-    if run_inference:
+    shard = str(cfg.TEST.get("SHARD", "images"))
+    if shard not in ("images", "pyramid", "pyramid_strict"):
+        raise ValueError("TEST.SHARD must be 'images' (the reference's image ranges), 'pyramid' or 'pyramid_strict'")
+    if run_inference and shard != "images":
+        # the north star's split: every image's pyramid sharded over the ranks of a torch.distributed job
+        dets = pyramid_sharded_inference(imdb, target_test, thresh, strict=(shard == "pyramid_strict"))
+        assert len(dets[0]) == len(imdb), "Detection result compromised"
+        if not no_cache and dist_env()[0] == 0:
+            with open(os.path.join(output_dir, 'detections.pkl'), 'wb') as f:
+                pickle.dump(dets, f, pickle.HIGHEST_PROTOCOL)
+    elif run_inference:
         if isinstance(cfg.TEST.GPU_ID, int):
             cfg.TEST.GPU_ID = [cfg.TEST.GPU_ID]
         assert len(cfg.TEST.GPU_ID) >= 1, "You must specify at least one GPU"
@@ -579,6 +721,8 @@ def test_net(imdb, output_dir, target_test, thresh=0.05, no_cache=False, step=0)
             with open(det_file, 'wb') as f:
                 pickle.dump(dets, f, pickle.HIGHEST_PROTOCOL)
 
+    if shard != "images" and dist_env()[0] != 0:
+        return dets                           # every rank holds the full lists; rank 0 writes and evaluates
     logger.info('Evaluating detections')
     result = imdb.evaluate_detections(all_boxes=dets, output_dir=output_dir, method_name=cfg.NAME, step=step)
     logger.info(result)

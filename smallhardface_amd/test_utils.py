@@ -15,6 +15,8 @@ offline, the functions are named instead):
   ``fx = (float)((dx + 0.5) * scale - 0.5); sx = cvFloor(fx); fx -= sx;`` -- the source coordinate is narrowed to
   FLOAT before the floor is subtracted, in float; ``sx < 0 -> (fx, sx) = (0, 0)``; ``sx >= src_w - 1 -> (fx, sx) =
   (0, src_w - 1)``; ``cbuf[0] = 1.f - fx; cbuf[1] = fx`` (a float subtraction);
+* the VERTICAL table has no such border rule (``_row_coeffs``, round 6 -- found by restating the call a second time,
+  independently, as oracle/resize.py): the invoker clips the two source row indices and keeps ``beta = {1.f - fy, fy}``;
 * ``HResizeLinear<double, double, float, 1>`` / ``VResizeLinear<double, double, float>`` (the CV_64F instantiation):
   ``S[sx] * a0 + S[sx + cn] * a1`` with the float coefficients widened to double, rows first, then
   ``S0[x] * b0 + S1[x] * b1``; products and sums are separate roundings.
@@ -78,6 +80,22 @@ def _axis_coeffs(n_src, n_dst, f):
     return i0, i1, a0, fx.astype(np.float32)
 
 
+def _row_coeffs(n_src, n_dst, f):
+    """The VERTICAL table of the same call (round 6): hal::resize forms ``fy = (float)((dy + 0.5) * scale_y - 0.5); sy =
+    cvFloor(fy); fy -= sy; beta = {1.f - fy, fy}`` WITHOUT the horizontal table's border rule -- instead
+    resizeGeneric_Invoker clips the two source ROW INDICES, ``clip(sy + k, 0, src_h)`` for k = 0, 1, so a destination row
+    above the first / below the last source row blends that row with itself under weights that need not add up to
+    exactly 1 in float: ``S * b0 + S * b1`` is not always ``S`` in the last double bit.  -> (i0, i1, b0, b1)."""
+    scale = 1.0 / float(f)
+    d = np.arange(n_dst, dtype=np.float64)
+    fy = ((d + 0.5) * scale - 0.5).astype(np.float32)
+    sy = np.floor(fy).astype(np.int64)
+    fy = (fy - sy.astype(np.float32)).astype(np.float32)
+    i0 = np.clip(sy, 0, n_src - 1)
+    i1 = np.clip(sy + 1, 0, n_src - 1)
+    return i0, i1, (np.float32(1.0) - fy).astype(np.float32), fy
+
+
 def is_area_fast_2x(fx, fy):
     """cv::resize's switch from INTER_LINEAR to the INTER_AREA fast path (module docstring): both scales exactly 2x down."""
     eps = np.finfo(np.float64).eps
@@ -130,7 +148,7 @@ def resize_bilinear(im, fx, fy):
     nw = int(np.round(w * fx))
     if is_area_fast_2x(fx, fy):
         return _resize_area_fast_2x(im, nh, nw)
-    y0, y1, b0, b1 = _axis_coeffs(h, nh, fy)
+    y0, y1, b0, b1 = _row_coeffs(h, nh, fy)
     x0, x1, a0, a1 = _axis_coeffs(w, nw, fx)
     a0 = a0[None, :, None].astype(im.dtype)
     a1 = a1[None, :, None].astype(im.dtype)

@@ -222,8 +222,9 @@ def main():
     tmp = tempfile.mkdtemp(prefix="shf_ref_py3_")
     convert_reference(tmp)
 
-    # --- fake cv2: registry-backed imread, resize delegated to OUR bilinear so
-    # the detect() fixture pins orchestration only (cv2 parity is unpinned).
+    # --- fake cv2: registry-backed imread, resize delegated to the ORACLE's independent restatement of
+    # cv2.resize (oracle/resize.py -- not the product's host mirror), so the detect() fixture pins orchestration
+    # only (cv2 parity itself is unpinned: OpenCV is not installable here).
     fake_cv2 = types.ModuleType("cv2")
     fake_cv2.INTER_LINEAR = 1
     fake_cv2._images = {}
@@ -231,8 +232,8 @@ def main():
     sys.path.insert(0, os.path.join(OUT, "..", ".."))
 
     def _resize(im, a, b, fx=None, fy=None, interpolation=None):
-        from smallhardface_amd.test_utils import resize_bilinear
-        return resize_bilinear(im, fx, fy)
+        from oracle.resize import cv_resize_linear_f64
+        return cv_resize_linear_f64(im, fx, fy)
 
     fake_cv2.resize = _resize
     install_stubs(fake_cv2)

@@ -124,6 +124,62 @@ def test_cli_one_process_per_gpu_id(tmp_path, n_images, gpu_id):
         assert int(one[f].splitlines()[1]) >= 1
 
 
+@pytest.mark.gpu
+@pytest.mark.timeout(1500)
+@pytest.mark.parametrize("shard,world,n_images", [("pyramid", 2, 3), ("pyramid_strict", 3, 4), ("pyramid", 1, 2)])
+def test_cli_pyramid_sharded_over_torchrun_ranks(tmp_path, shard, world, n_images):
+    """TEST.SHARD pyramid (not in the reference, whose multi-GPU mode is the image-range split above): ``train_test.py
+    --train false`` under ``torch.distributed.run`` shards every image's PYRAMID over the ranks (pyramid.ShardedDetector:
+    windows of `world` images, this rank's units as grouped passes, ONE all_to_all of detections per window to the owner
+    ranks, merge there) -- here 2 ranks (window schedule; 3 images = a full and a partly filled window) and 3 ranks (the
+    north star's strict one-scale-per-rank form on 2 scales: rank 2 only takes part in the exchange), all on the one test
+    GPU over gloo.  Rank 0 writes the detection files: byte-identical to the single-process run."""
+    import socket
+    from PIL import Image
+    from smallhardface_amd import caffemodel, weights
+    from tests import helpers as H
+    data = tmp_path / "data"
+    (data / "images" / "0--Parade").mkdir(parents=True)
+    rng = np.random.default_rng(5)
+    names = []
+    for i in range(n_images):
+        h, w = 84 + 10 * i, 146 - 7 * i
+        Image.fromarray(rng.integers(0, 256, (h, w, 3)).astype(np.uint8)).save(
+            data / "images" / "0--Parade" / ("img%d.jpg" % i))
+        names.append("images/0--Parade/img%d.jpg" % i)
+    (data / "wider_val.txt").write_text("\n".join(names) + "\n")
+    model = str(tmp_path / "synthetic.caffemodel")
+    caffemodel.write_caffemodel(model, weights.synth_params(H.detector_msg(True), cls_bias=1.0))
+    one, _ = _run_cli(tmp_path, data, model, "[0]", "exp_one")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, PYTHONPATH=ROOT, SHF_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", SHF_DIST_TIMEOUT="120")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    exp = tmp_path / "exp_sharded"
+    launcher = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+                "--master-addr", "127.0.0.1", "--master-port", str(port)] if world > 1 else [sys.executable]   # (1: no launcher, no group)
+    r = subprocess.run(launcher + [os.path.join(ROOT, "train_test.py"), "--train", "false", "--conf",
+                        os.path.join(ROOT, "configs", "smallhardface.toml"), "--amend", "TEST.MODEL", model,
+                        "DATA_DIR", str(data), "TEST.GPU_ID", "[" + ",".join(["0"] * world) + "]", "TEST.SCALES", "[100, 300]",
+                        "TEST.SHARD", shard, "EXP_DIR", str(exp)],
+                       cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, _stderr_of(r, exp)
+    many = {}
+    for root, _, files in os.walk(str(exp)):
+        for f in files:
+            if f.endswith(".txt") and "img" in f:
+                assert f not in many, "only rank 0 writes detection files"
+                many[f] = open(os.path.join(root, f)).read()
+    assert len(one) == n_images and sorted(one) == sorted(many), (sorted(one), sorted(many), _stderr_of(r, exp))
+    for f in one:
+        assert one[f] == many[f], f
+    logs, cfgs = _run_outputs(exp)
+    assert len(logs) == world and len(cfgs) == world          # every rank keeps its own stderr.log / cfgs.txt
+
+
 def test_cli_refuses_training():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "train_test.py"), "--train", "true"],
                        env=dict(os.environ, PYTHONPATH=ROOT), capture_output=True, text=True, timeout=120)

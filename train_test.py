@@ -4,6 +4,10 @@
     python train_test.py --train false --conf configs/smallhardface.toml \\
         --amend TEST.MODEL final.caffemodel DATA_DIR /data/WIDER TEST.GPU_ID "[0,1,2,3]"
 
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 train_test.py --train false \\
+        --conf configs/smallhardface.toml --amend TEST.MODEL final.caffemodel TEST.SHARD pyramid
+        (not in the reference: every image's PYRAMID sharded over the ranks, smallhardface_amd/pyramid.py ShardedDetector)
+
 Same flags and control flow (cfg_from_file -> NO_CACHE -> --amend -> seed -> manipulate_test ->
 test_net).  ``--train true`` is refused: training is outside this build's scope.  The image
 database is a plain list: ``<DATA_DIR>/<TEST.DB>.txt`` (one image path per line, relative to
@@ -22,7 +26,7 @@ import numpy as np
 from smallhardface_amd.config import cfg, cfg_dump, cfg_from_file, cfg_from_list, get_output_dir
 from smallhardface_amd.datasets import ImageList
 from smallhardface_amd.prototxt import manipulate_test
-from smallhardface_amd.test import test_net
+from smallhardface_amd.test import dist_env, test_net
 
 logging.basicConfig(format='%(asctime)s,%(msecs)d %(levelname)-8s [%(filename)s:%(lineno)d] %(message)s',
                     datefmt='%m-%d-%Y:%H:%M:%S',
@@ -64,6 +68,11 @@ if __name__ == '__main__':
     if args.test.lower() == 'true':
         cfg.NAME_TIME = datetime.datetime.now().strftime('%Y%m%d_%H%M%S')
         imdb = get_imdb(cfg.TEST.DB)
+        rank, world, _ = dist_env()
+        if world > 1 and rank != 0:
+            # TEST.SHARD pyramid under torch.distributed.run: rank 0 owns the results directory, the other ranks keep their
+            # stderr.log / test.prototxt in a sibling of their own (the ranks' clocks need not agree on NAME_TIME)
+            cfg.NAME_TIME += '_rank%d' % rank
         output_dir = get_output_dir(cfg.TEST.DB, cfg.NAME_TIME)
         # train_test.py:122-124: from here on the run's stderr goes to <output_dir>/stderr.log (warnings, tracebacks)
         f = open(osp.join(output_dir, 'stderr.log'), 'w', 1)
