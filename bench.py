@@ -130,17 +130,45 @@ def cpu_baseline(msg, params, seconds_budget=45.0):
             "sample_seconds": tot_dt + vote_dt, "sample_gflops_per_s": tot_fl / tot_dt / 1e9}
 
 
+def visible_gpu_count():
+    """GPUs this process could use, WITHOUT touching the HIP runtime (the launcher parent only starts children): the KFD
+    topology's nodes with SIMDs (CPU nodes have simd_count 0), narrowed by HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES /
+    CUDA_VISIBLE_DEVICES when one is set to a plain index list.  None when the topology cannot be read (the ranks then
+    report a shortage themselves: "needs N visible MI355X, found M")."""
+    import glob
+    n = 0
+    if not os.path.isdir("/sys/class/kfd"):
+        return 0                       # no amdgpu / KFD driver on this host at all
+    nodes = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
+    if not nodes:
+        return None
+    for p in nodes:
+        try:
+            for line in open(p):
+                k, _, v = line.partition(" ")
+                if k == "simd_count" and int(v) > 0:
+                    n += 1
+        except (OSError, ValueError):
+            return None
+    for var in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            ids = [t for t in v.split(",") if t.strip() != ""]
+            if all(t.strip().lstrip("-").isdigit() for t in ids):
+                n = min(n, len([t for t in ids if int(t) >= 0]))
+    return n
+
+
 def self_launch(n):
     """`python bench.py --gpus N` (N > 1) without a launcher: start the N ranks as children of ONE fresh
     `python -m torch.distributed.run` (the reference starts its N workers from one command as well,
-    lib/test.py:327-344) and return its exit code.  The parent counts the devices (which does not initialise the
-    GPU on this image) and otherwise never touches it; no exec.  `--standalone` keeps the rendezvous on a TCPStore
+    lib/test.py:327-344) and return its exit code.  The parent counts the devices from the KFD topology in sysfs
+    (visible_gpu_count: no HIP call, no KFD handle held for the run) and never touches the GPU; no exec.  `--standalone` keeps the rendezvous on a TCPStore
     the agent binds itself (port 0) and hands to the workers: no bind-close-reuse of a port."""
     import subprocess
     if os.environ.get("SHF_BENCH_ONE_GPU") != "1":
-        import torch
-        n_dev = torch.cuda.device_count()
-        if n_dev < n:
+        n_dev = visible_gpu_count()
+        if n_dev is not None and n_dev < n:
             raise SystemExit("bench.py --gpus %d needs %d visible MI355X, found %d (SHF_BENCH_ONE_GPU=1 --backend gloo runs "
                              "all ranks on one GPU for validation)" % (n, n, n_dev))
     env = dict(os.environ)
@@ -200,6 +228,8 @@ def main():
                     help="N=1: after the timed region, back-to-back steps for this long in the headline mode -> 'sustained' "
                          "(0 to skip); --steps still defines 'value'")
     ap.add_argument("--no-mixed", action="store_true", help="skip the mixed-shape image stream leg ('mixed_shapes', N=1)")
+    ap.add_argument("--no-forward-path", action="store_true", help="skip the literal Net.forward() drop-in leg ('net_forward_path', N=1: "
+                    "lib/test.py's detect() on the bench image -- host pre-processing, ten Net.forward() with host blobs, C-ABI bbox_vote)")
     ap.add_argument("--no-files", action="store_true", help="skip the file-to-detections leg ('from_files', N=1; part of the "
                     "mixed-shape leg: the same shapes as JPEG files through test.fused_image_loop into the WIDER writer)")
     args = ap.parse_args()
@@ -395,6 +425,7 @@ def main():
         step()
     fence()
     elapsed = time.perf_counter() - t0
+    headline_dets = np.array(last[0], copy=True) if (world == 1 and 0 in last) else None   # (later legs overwrite `last`)
     if host_trace is not None and dist_path:
         print("host time per window (ms): " + ", ".join("%s %.2f" % (k, 1e3 * v / max(1, sd.collectives)) for k, v in sd.host_seconds.items()), file=sys.stderr)
     if host_trace:
@@ -415,22 +446,35 @@ def main():
     #      the timed region itself is a quarter of a second on a chip that is power-limited and drifts; `value` stays
     #      what --steps defines.  HIP events are off here (they bracket every launch of the timed region).
     sustained = None
+    hwmon = None
+    if world == 1 and rank == 0:
+        # the card's hwmon files (sclk, socket power), found through the runtime's PCI bus id: sampled from the host side
+        # under `sustained` and under the matrix-pipe calibration (smallhardface_amd/telemetry.py); no GPU call
+        from smallhardface_amd import _lib, telemetry
+        import ctypes as C_
+        buf = C_.create_string_buffer(64)
+        if _lib.load().shf_device_pci_bus_id(buf, 64) == 0:
+            hwmon = telemetry.find_card(buf.value.decode())
     if not dist_path and args.mode == "group" and args.sustain_seconds > 0 and not args.host_input:
+        from smallhardface_amd import telemetry
         marks = []
-        t1 = time.perf_counter()
-        while True:
-            step()
-            marks.append(time.perf_counter())
-            if marks[-1] - t1 >= args.sustain_seconds:
-                break
-        fence()
-        t2 = time.perf_counter()
+        with telemetry.Sampler(hwmon) as tel:
+            t1 = time.perf_counter()
+            while True:
+                step()
+                marks.append(time.perf_counter())
+                if marks[-1] - t1 >= args.sustain_seconds:
+                    break
+            fence()
+            t2 = time.perf_counter()
+        sustained_tel = tel.summary()
         marks = np.asarray(marks) - t1
         sustained = {"seconds": t2 - t1, "steps": len(marks), "value": len(marks) / (t2 - t1), "unit": "images/s",
                      "first_second": float(np.sum(marks <= 1.0)),
                      "last_second": float(np.sum(marks > marks[-1] - 1.0)),
                      "note": "same resident pyramid, same pipeline as the timed region, per-launch HIP events off; "
-                             "first / last second = steps completed in that second"}
+                             "first / last second = steps completed in that second",
+                     "telemetry": sustained_tel}
 
     # ---- single-image latency: ONE image, nothing else in flight, submit -> merged detections on the host
     latency_ms = None
@@ -453,12 +497,22 @@ def main():
         L = _lib.load()
         bf = 1 if args.conv_mode == "bf16" else 0
 
-        def pipe_rate(zero8, const):
+        from smallhardface_amd import telemetry
+        pipe_tel = {}
+
+        def pipe_rate(zero8, const, key):
+            # the figure: the first call, as before; then the same stream for ~0.6 s more under the clock / power sampler
             v = C.c_double(0.0)
             _lib.check(L.shf_calib_matrix_pipe(bf, zero8, const, 20000, 6, C.byref(v)))
-            return v.value
-        pipe = {"operands_constant": pipe_rate(0, 1), "operands_random": pipe_rate(0, 0),
-                "operands_random_half_of_activations_zero": pipe_rate(4, 0)}
+            first = v.value
+            with telemetry.Sampler(hwmon, period_s=0.01) as tel:
+                t_end = time.perf_counter() + 0.6
+                while time.perf_counter() < t_end:
+                    _lib.check(L.shf_calib_matrix_pipe(bf, zero8, const, 20000, 6, C.byref(v)))
+            pipe_tel[key] = tel.summary()
+            return first
+        pipe = {"operands_constant": pipe_rate(0, 1, "operands_constant"), "operands_random": pipe_rate(0, 0, "operands_random"),
+                "operands_random_half_of_activations_zero": pipe_rate(4, 0, "operands_random_half_of_activations_zero")}
     # ---- mixed-shape image stream (BASELINE config 4 "WIDER-val-shaped" as a RATE; the reference's hot loop runs images
     #      of different sizes, lib/test.py:239-244): uint8 images of 8 WIDER-like shapes, consecutive images never of the
     #      same shape, through DevicePyramid + FusedDetector.submit / collect exactly as test.inference_worker does --
@@ -628,6 +682,61 @@ def main():
         reduced["also"] = legs["f16"]
         reduced["note"] = "drift-labelled throughput modes, NOT parity modes: the headline value is the f16x3 run above"
 
+    # ---- the LITERAL drop-in path (N=1): what a maintainer gets who only swaps `import caffe` -- lib/test.py:109-178 detect()
+    #      on the bench image: host pre-processing (_get_image_blob), ten forward_net() = ten Net.forward() with HOST blobs
+    #      in and out (lib/test.py:21-106), the > 0.05 cut on the host, bbox_vote through the C ABI.  After and outside the
+    #      timed region; every other leg times the device-resident loop (test.fused_image_loop / FusedDetector).
+    nf_path = None
+    if not dist_path and args.mode == "group" and not args.no_forward_path and not args.host_input and rank == 0:
+        from smallhardface_amd import test as T
+        from smallhardface_amd.test_utils import _get_image_blob, pyramid_scales
+        im0 = np.random.default_rng(1000).integers(0, 256, (src_hw[0], src_hw[1], 3)).astype(np.uint8)   # = build_units(0)
+        fence()
+        T.detect(net, None, thresh, pyramid=True, im=im0)                  # untimed: buffers of the root net at these shapes
+        t1 = time.perf_counter()
+        _get_image_blob(im0, pyramid_scales(im0.shape))
+        pre_s = time.perf_counter() - t1
+        n_nf = 3
+        net.timing = {}
+        net.prof_enable(True)
+        net.prof_reset()
+        walls, det_t, misc_t = [], 0.0, 0.0
+        for _ in range(n_nf):
+            t1 = time.perf_counter()
+            dets_nf, tm_nf = T.detect(net, None, thresh, pyramid=True, im=im0)
+            walls.append(time.perf_counter() - t1)
+            det_t += tm_nf['detect'].total_time
+            misc_t += tm_nf['misc'].total_time
+        pr = net.prof_read()
+        net.prof_enable(False)
+        tm = net.timing
+        net.timing = None
+        per = lambda v: 1000.0 * v / n_nf
+        wall = float(np.median(walls))
+        dev_ms = {k: v["ms"] / n_nf for k, v in pr.items() if v["launches"] > 0}
+        fused_ref = np.asarray(headline_dets) if headline_dets is not None else None
+        got = np.asarray(dets_nf[0], dtype=np.float64)
+        nf_path = {
+            "value": 1.0 / wall, "unit": "images/s", "ms_per_image": 1000.0 * wall, "images": n_nf,
+            "vs_fused_rate": (1.0 / wall) / (args.steps / elapsed),
+            "host_preprocess_ms": 1000.0 * pre_s,
+            "forward_calls_per_image": tm.get("calls", 0) / n_nf,
+            "input_copy_ms": per(tm.get("input_copy_s", 0.0)), "forward_call_ms": per(tm.get("forward_call_s", 0.0)),
+            "output_read_ms": per(tm.get("output_read_s", 0.0)),
+            "h2d_ms": dev_ms.get("h2d_copy", 0.0), "d2h_ms": dev_ms.get("d2h_copy", 0.0),
+            "forward_ms": sum(v for k, v in dev_ms.items() if k not in ("h2d_copy", "d2h_copy", "box_merge")),
+            "merge_ms": 1000.0 * misc_t / n_nf, "detect_timer_ms": 1000.0 * det_t / n_nf,
+            "boxes": int(len(got)),
+            "identical_to_fused_path": bool(fused_ref is not None and fused_ref.shape == got.shape and np.array_equal(fused_ref, got)),
+            "kernel_ms_per_image": {k: round(v, 3) for k, v in dev_ms.items()},
+            "path": "test.detect(net, im=...) as lib/test.py:109-178: _get_image_blob on the host (numpy restatement of cv2.resize, "
+                    "float64: host_preprocess_ms of ms_per_image), ten forward_net() -> Net.forward() with host blobs "
+                    "(input_copy_ms: np.pad + the copy into the blob's pinned mirror; forward_call_ms: shf_net_forward = H2D + "
+                    "kernels + count read-back, on the device h2d_ms / forward_ms / d2h_ms by HIP events; output_read_ms: "
+                    "Blob.data of boxes / cls_prob), > 0.05 cut on the host, bbox_vote through the C ABI (merge_ms); f16x3: "
+                    "Net.forward() runs the fused path's kernels (fused first pair, pools in the epilogues)",
+        }
+
     if rank == 0 and args.dump_dets and 0 in last:
         np.save(args.dump_dets, np.asarray(last[0]))
     if rank == 0:
@@ -733,6 +842,8 @@ def main():
                         "v_mfma_f32_32x32x16_%s with the conv kernels' register diet (1 wave/SIMD, 8 accumulator tiles, 3 products "
                         "per fragment pair), no memory traffic; the clock drops with the operands' bit toggling (power limit), so "
                         "the nominal peak is only reached with constant operands" % ("bf16" if args.conv_mode == "bf16" else "f16"),
+                "telemetry": {k: ({kk: v[kk] for kk in ("sclk_mhz_mean", "sclk_mhz_min", "power_w_mean", "power_w_max", "power_cap_w", "samples")}
+                                  if v else None) for k, v in pipe_tel.items()},
                 "frac_issued_of_sustained": round(r["issued_mfma_achieved"] / ceil_, 4),
                 "frac_issued_of_sustained_note": "issued MFMA rate of the dominant kernel / the half-zero-activation row (the "
                                                  "activations this workload's convolutions read are 41-54 % zeros from conv3_2 on: "
@@ -747,6 +858,8 @@ def main():
                 out["from_files"] = from_files
         if reduced is not None:
             out["reduced_precision"] = reduced
+        if nf_path is not None:
+            out["net_forward_path"] = nf_path
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(msg, params)
         print(json.dumps(out), flush=True)

@@ -108,6 +108,17 @@ long long shf_net_range_fallbacks(shf_net* net);
  * semantics, caffe/src/caffe/blob.cpp:22-50: capacity only ever grows; syncedmem.cpp:15-50 is where Caffe allocates).  A
  * stream of images whose shapes were all seen before must leave both counts unchanged.  Measurement only. */
 void shf_alloc_counts(long long* device_allocs, long long* pinned_host_allocs);
+/* _get_image_blob (lib/utils/test_utils.py:29-46) + im_list_to_blob (lib/utils/blob.py:16-32) for a whole scale list, for
+ * callers that keep HOST blobs (lib/test.py:109-178 detect() -> forward_net): `im_bgr_host` uint8 HxWx3 is uploaded once,
+ * level i = mean subtraction + cv2.resize(fx = fy = scales[i], INTER_LINEAR) restated (csrc/pre.hip: the host mirror's
+ * arithmetic bit for bit; scale 1.0 = no resize) lands in out_host[i] as an UNPADDED, unflipped (1,3,lvl_h[i],lvl_w[i])
+ * fp32 blob; lvl_h / lvl_w from shf_pyramid_level_shape.  The reference calls a native library (OpenCV) at this point too. */
+int shf_image_blobs(const uint8_t* im_bgr_host, int im_h, int im_w, int n, const double* scales, const double* pixel_means,
+                    float* const* out_host, const int* lvl_h, const int* lvl_w);
+/* PCI bus id ("0000:c5:00.0") of the device the runtime is set to (shf_set_device; caffe.set_device,
+ * caffe/python/caffe/_caffe.cpp:394-396), so that a host-side sampler can find the card's sysfs hwmon files (clock, socket
+ * power) without a GPU call of its own.  Measurement only (bench.py `telemetry`). */
+int shf_device_pci_bus_id(char* out, int cap);
 
 /* ---- fused per-image path (device-resident pyramid; lib/test.py:109-178) ---- */
 /* detect(): begin an image */

@@ -89,6 +89,8 @@ def _declare(lib):
         "shf_net_get_conv_mode": (ci, [vp]),
         "shf_net_range_fallbacks": (C.c_longlong, [vp]),
         "shf_alloc_counts": (None, [C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
+        "shf_device_pci_bus_id": (ci, [C.c_char_p, ci]),
+        "shf_image_blobs": (ci, [vp, ci, ci, ci, dp, dp, C.POINTER(vp), ip, ip]),
         "shf_net_set_layer_products": (ci, [vp, C.c_char_p, ci]),
         "shf_net_record_event": (ci, [vp]),
         "shf_net_wait_event": (ci, [vp, vp]),

@@ -13,6 +13,7 @@ reference's inference driver touches:
 Solvers, backward, forward_all, io, Classifier, NCCL are not part of the hot path.
 """
 import ctypes as C
+import time
 from collections import OrderedDict
 
 import numpy as np
@@ -245,6 +246,8 @@ class Net(object):
         if blobs is None:
             blobs = []
         outputs = set(self.outputs + blobs)
+        tm = getattr(self, "timing", None)     # measurement only (bench.py net_forward_path): a dict collects host seconds
+        t0 = time.perf_counter() if tm is not None else 0.0
         if kwargs:
             if set(kwargs.keys()) != set(self.inputs):
                 raise Exception('Input blob arguments do not match net inputs.')
@@ -252,8 +255,17 @@ class Net(object):
                 if blob.shape[0] != self.blobs[in_].shape[0]:
                     raise Exception('Input is not batch sized')
                 self.blobs[in_].data[...] = blob
+        t1 = time.perf_counter() if tm is not None else 0.0
         self._forward()
-        return {out: self.blobs[out].data for out in outputs}
+        t2 = time.perf_counter() if tm is not None else 0.0
+        out = {out: self.blobs[out].data for out in outputs}
+        if tm is not None:
+            t3 = time.perf_counter()
+            tm["calls"] = tm.get("calls", 0) + 1
+            tm["input_copy_s"] = tm.get("input_copy_s", 0.0) + (t1 - t0)     # host blob -> the pinned mirror (Blob.data[...] = x)
+            tm["forward_call_s"] = tm.get("forward_call_s", 0.0) + (t2 - t1)  # shf_net_forward: H2D + kernels + the count read-back
+            tm["output_read_s"] = tm.get("output_read_s", 0.0) + (t3 - t2)   # Blob.data of the outputs: D2H
+        return out
 
     # -- measurement helpers ------------------------------------------------------
     def sync(self):

@@ -224,6 +224,52 @@ void shf_alloc_counts(long long* device_allocs, long long* pinned_host_allocs) {
   if (pinned_host_allocs) *pinned_host_allocs = g_host_allocs.load();
 }
 
+static void box_ctx_init();
+
+// _get_image_blob of a whole scale list for callers that work with HOST blobs (lib/test.py's detect(): the reference calls
+// cv2.resize here -- a native library as well): the uint8 image goes up once, every level is formed by pre.hip's kernel
+// (the arithmetic of the host mirror, bit for bit) on the box context's stream and comes back as an UNPADDED (1,3,h,w) blob.
+int shf_image_blobs(const uint8_t* im_bgr_host, int im_h, int im_w, int n, const double* scales, const double* pixel_means,
+                    float* const* out_host, const int* lvl_h, const int* lvl_w) {
+  API_BEGIN
+  if (!im_bgr_host || !scales || !pixel_means || !out_host || !lvl_h || !lvl_w || n < 1 || im_h < 1 || im_w < 1)
+    throw std::runtime_error("image_blobs: bad argument");
+  std::lock_guard<std::mutex> lk(g_box_mu);
+  box_ctx_init();
+  static DevBuf* im_dev = new DevBuf();
+  static DevBuf* lv_dev = new DevBuf();
+  const size_t im_bytes = (size_t)im_h * im_w * 3;
+  size_t total = 0;
+  for (int i = 0; i < n; ++i) {
+    if (lvl_h[i] < 1 || lvl_w[i] < 1 || !(scales[i] > 0)) throw std::runtime_error("image_blobs: bad level geometry");
+    total += (size_t)3 * lvl_h[i] * lvl_w[i];
+  }
+  im_dev->ensure(im_bytes);
+  lv_dev->ensure(total * 4);
+  HIP_THROW(hipMemcpyAsync(im_dev->p, im_bgr_host, im_bytes, hipMemcpyHostToDevice, g_box_stream));
+  size_t off = 0;
+  for (int i = 0; i < n; ++i) {
+    float* o = (float*)lv_dev->p + off;
+    CHECK_RC(launch_pyramid_level((const uint8_t*)im_dev->p, im_h, im_w, scales[i], 0, pixel_means, o, lvl_h[i], lvl_w[i],
+                                  lvl_h[i], lvl_w[i], g_box_stream));
+    HIP_THROW(hipMemcpyAsync(out_host[i], o, (size_t)3 * lvl_h[i] * lvl_w[i] * 4, hipMemcpyDeviceToHost, g_box_stream));
+    off += (size_t)3 * lvl_h[i] * lvl_w[i];
+  }
+  HIP_THROW(hipStreamSynchronize(g_box_stream));
+  return 0;
+  API_END(-1)
+}
+
+int shf_device_pci_bus_id(char* out, int cap) {
+  API_BEGIN
+  if (!out || cap < 16) throw std::runtime_error("device_pci_bus_id: buffer too small");
+  int dev = 0;
+  HIP_THROW(hipGetDevice(&dev));
+  HIP_THROW(hipDeviceGetPCIBusId(out, cap, dev));
+  return 0;
+  API_END(-1)
+}
+
 int shf_net_record_event(shf_net* net) {
   API_BEGIN
   if (!net->ev_mark) HIP_THROW(hipEventCreateWithFlags(&net->ev_mark, hipEventDisableTiming));

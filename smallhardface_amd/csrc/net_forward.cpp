@@ -26,7 +26,7 @@ const char* const kProfNames[PC_COUNT] = {"conv_mfma_f32_kernel<3, 1, 128, 8, 16
                                            "conv_mfma_f16x3_w4d_kernel<true, 4, 1, 3, false, 2>", "conv_mfma_f16x3_w4d_kernel<true, 4, 1, 3, false, 4>",
                                            "conv_mfma_f16x3_heads3_kernel<true, 3>",
                                            "conv_first_kernel", "conv_direct_kernel", "maxpool_kernel",
-                                           "deconv_depthwise", "detect_tail", "box_merge", "layout"};
+                                           "deconv_depthwise", "detect_tail", "box_merge", "layout", "h2d_copy", "d2h_copy"};
 
 // which split-fp16 kernel launch_conv_f16x3_group picks for these arguments -- decided by the launcher's OWN predicates on the
 // actual arguments, so that the 8-wave fallbacks (unaligned views, Cout % 256, bf16 1x1s ...) are not booked under the name of
@@ -71,7 +71,7 @@ TailArgs shf_net::tail_args(float im_h, float im_w, float im_scale, bool fused_p
   t.feat_stride = feat_stride;
   t.im_h = im_h; t.im_w = im_w; t.im_scale = im_scale;
   t.min_size = min_size; t.score_thresh = score_thresh; t.pre_nms_topN = pre_nms_topN;
-  if (materialize_tail && !fused_path) {
+  if (materialize_tail && (!fused_path || in_net_forward)) {
     t.cls_prob_reshape_nchw = (float*)blobs[tail_cls_blob].dev.p;
     t.bbox_pred_nchw = (float*)blobs[tail_box_blob].dev.p;
   }
@@ -214,6 +214,7 @@ void shf_net::forward_ops(bool fused_path, float im_h, float im_w, float im_scal
         break;
       }
       case OP_TAIL: {
+        if (plain_skip_tail) break;   // (ensure_plain: the intermediates only -- the tail's outputs stay the forward's own)
         TailArgs t = tail_args(im_h, im_w, im_scale, fused_path);
         const double K = (double)t.h * t.w;
         ProfScope ps(pf, st, PC_TAIL, 2.0 * K * tail_A * 6 * tail_Cf,
@@ -229,6 +230,16 @@ void shf_net::forward_ops(bool fused_path, float im_h, float im_w, float im_scal
   }
 }
 
+// the fused path's kernels behind Net.forward(): a split-fp16 mode, a detector graph whose outputs are the proposal
+// layer's (nothing else is an output: a conv top that is a net output must hold plain fp32 after forward())
+bool shf_net::forward_fast_eligible() const {
+  static const bool knob = !(getenv("SHF_FORWARD_FAST") && atoi(getenv("SHF_FORWARD_FAST")) == 0);
+  if (!knob || conv_mode < 1 || tail_layer < 0 || data_blob < 0) return false;
+  for (int o : outputs)
+    if (o != boxes_blob && o != prob_blob) return false;
+  return true;
+}
+
 void shf_net::forward() {
   if (data_blob >= 0 && blobs[data_blob].shape != last_data_shape) {
     infer_shapes();
@@ -239,6 +250,7 @@ void shf_net::forward() {
     b.ext_dev = nullptr;
     if (b.host_newer && b.host.p) {
       b.dev.ensure(b.count() * 4);
+      ProfScope ps(prof, stream, PC_H2D, 0, 4.0 * b.count());
       HIP_THROW(hipMemcpyAsync(b.dev.p, b.host.p, b.count() * 4, hipMemcpyHostToDevice, stream));
       b.host_newer = false;
     }
@@ -246,22 +258,39 @@ void shf_net::forward() {
   float ii[3] = {0, 0, 1};
   if (im_info_blob >= 0 && blobs[im_info_blob].host.p && blobs[im_info_blob].count() >= 3)
     memcpy(ii, blobs[im_info_blob].host.p, 12);
+  memcpy(last_im_info, ii, 12);
+  const bool fast = forward_fast_eligible();
+  struct Scope {   // (forward_ops may throw)
+    bool& f;
+    explicit Scope(bool& f_) : f(f_) { f = true; }
+    ~Scope() { f = false; }
+  };
   for (int attempt = 0; attempt < 2; ++attempt) {
     if (conv_mode >= 1) HIP_THROW(hipMemsetAsync(range_flag.p, 0, 4, stream));
     reset_amax(stream);
-    forward_ops(false, ii[0], ii[1], ii[2]);
+    {
+      Scope sc(in_net_forward);
+      forward_ops(fast, ii[0], ii[1], ii[2]);
+    }
+    plain_stale = fast;
     int cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, flag = 0;
-    if (tail_layer >= 0) HIP_THROW(hipMemcpyAsync(cnt, tw.counters, sizeof(cnt), hipMemcpyDeviceToHost, stream));
-    if (conv_mode >= 1) HIP_THROW(hipMemcpyAsync(&flag, range_flag.p, 4, hipMemcpyDeviceToHost, stream));
+    {
+      ProfScope ps(prof, stream, PC_D2H, 0, sizeof(cnt) + 4);
+      if (tail_layer >= 0) HIP_THROW(hipMemcpyAsync(cnt, tw.counters, sizeof(cnt), hipMemcpyDeviceToHost, stream));
+      if (conv_mode >= 1) HIP_THROW(hipMemcpyAsync(&flag, range_flag.p, 4, hipMemcpyDeviceToHost, stream));
+    }
     HIP_THROW(hipStreamSynchronize(stream));
     if (flag && conv_mode >= 1) {
       const int mode_was = conv_mode;
       // a convolution produced |x| > 65504: fp16(hi) of the split overflowed somewhere downstream.  The reference
-      // computes in fp32 (_caffe.cpp:46-48): redo THIS forward on the exact fp32 matrix-core kernels.
+      // computes in fp32 (_caffe.cpp:46-48): redo THIS forward on the exact fp32 matrix-core kernels (per-layer path:
+      // every blob materialised).
       ++sh->range_fallbacks;
       conv_mode = 0;
       try {
+        reset_amax(stream);
         forward_ops(false, ii[0], ii[1], ii[2]);
+        plain_stale = false;
         if (tail_layer >= 0) HIP_THROW(hipMemcpyAsync(cnt, tw.counters, sizeof(cnt), hipMemcpyDeviceToHost, stream));
         HIP_THROW(hipStreamSynchronize(stream));
       } catch (...) {
@@ -280,6 +309,23 @@ void shf_net::forward() {
   // (tail-fused blobs too: "newer" for them means the tail workspace holds this forward's logits -- read on demand)
   for (size_t i = 0; i < blobs.size(); ++i)
     if (!std::count(inputs.begin(), inputs.end(), (int)i)) blobs[i].dev_newer = true;
+}
+
+// the intermediate blobs after a fast forward (see net_internal.h `plain_stale`): run the per-layer kernels once, in the
+// forward's own arithmetic mode, on the inputs still resident on the device -- everything except the proposal tail
+void shf_net::ensure_plain() {
+  if (!plain_stale) return;
+  if (data_blob >= 0 && blobs[data_blob].shape != last_data_shape)
+    throw std::runtime_error("an input was reshaped after the last forward(): call forward() before reading intermediate blobs");
+  struct Scope {
+    bool& f;
+    explicit Scope(bool& f_) : f(f_) { f = true; }
+    ~Scope() { f = false; }
+  } sc(plain_skip_tail);
+  reset_amax(stream);
+  forward_ops(false, last_im_info[0], last_im_info[1], last_im_info[2]);
+  HIP_THROW(hipStreamSynchronize(stream));
+  plain_stale = false;
 }
 
 // Blob.data of a blob whose producer was folded into the detection tail (the cls / bbox 1x1 convs, the score concat /
@@ -354,13 +400,16 @@ float* shf_net::host_data(int bi) {
   const bool is_input = std::count(inputs.begin(), inputs.end(), bi) > 0;
   if (b.dev_newer && n > 0) {
     if (b.kind == BK_NHWC) {
+      if (!is_input) ensure_plain();   // (after a fast forward: the activations are not plain fp32 tensors yet)
       b.stage.ensure(n * 4);
       {
         ProfScope ps(prof, stream, PC_LAYOUT, 0, 8.0 * n);
         CHECK_RC(launch_nhwc_to_nchw(view_of(bi), (float*)b.stage.p, stream));
       }
+      ProfScope ps(prof, stream, PC_D2H, 0, 4.0 * n);
       HIP_THROW(hipMemcpyAsync(b.host.p, b.stage.p, n * 4, hipMemcpyDeviceToHost, stream));
     } else {
+      ProfScope ps(prof, stream, PC_D2H, 0, 4.0 * n);
       HIP_THROW(hipMemcpyAsync(b.host.p, b.dev.p, n * 4, hipMemcpyDeviceToHost, stream));
     }
     HIP_THROW(hipStreamSynchronize(stream));

@@ -453,6 +453,23 @@ void shf_net::build(const std::string& text, const char* caffemodel) {
       if (Q.dil == 4 && d4 < 0) d4 = (int)lj;
     }
     if (d2 < 0 || d4 < 0) continue;
+    if (layers[d2].heads3_lead >= 0 || layers[d4].heads3_lead >= 0 || layers[d2].heads3_d2 >= 0 || layers[d4].heads3_d2 >= 0)
+      continue;   // a sibling already claimed by another dilation-1 layer
+    // the fused launch writes the siblings' tops at THIS layer's place in the schedule: legal only when nothing in between
+    // reads or writes those tops, and nothing in between (or the siblings' own in-place ReLUs aside) rewrites the shared bottom
+    bool safe = true;
+    const int t2 = layers[d2].tops[0], t4 = layers[d4].tops[0], shared_bottom = A.bottoms[0];
+    for (int lj = (int)li + 1; lj < std::max(d2, d4) && safe; ++lj) {
+      if (lj == d2 || lj == d4) continue;
+      const Layer& Q = layers[lj];
+      // (the three convs' own in-place ReLUs are folded into them: Layer::relu)
+      if (Q.op == OP_SKIP && Q.type == "ReLU" && Q.bottoms.size() == 1 && Q.tops.size() == 1 && Q.bottoms[0] == Q.tops[0] &&
+          (Q.tops[0] == A.tops[0] || Q.tops[0] == t2 || Q.tops[0] == t4))
+        continue;
+      for (int bb : Q.bottoms) safe = safe && bb != t2 && bb != t4;
+      for (int tt : Q.tops) safe = safe && tt != t2 && tt != t4 && tt != shared_bottom;
+    }
+    if (!safe) continue;
     A.heads3_d2 = d2;
     A.heads3_d4 = d4;
     layers[d2].heads3_lead = layers[d4].heads3_lead = (int)li;

@@ -171,7 +171,7 @@ struct Layer {
 };
 
 // the first 8 classes are the instantiations of conv_mfma_f32_kernel, named like rocprofv3 prints them
-enum ProfClass { PC_CONV_MFMA, PC_CONV_MFMA_1 = 1, PC_CONV_MFMA_7 = 7, PC_CONV_F16X3_128, PC_CONV_F16X3_W4, PC_CONV_F16X3_W4_SPLIT, PC_CONV_F16X3_W4_MT2, PC_CONV_F16X3_W4_SPLIT_MT2, PC_CONV_F16X3_64, PC_CONV_F16X3_64_FUSE1, PC_CONV_F16X3_64_D2, PC_CONV_F16X3_64_D4, PC_CONV_F16X3_128_K1, PC_CONV_F16X3_64_K1, PC_CONV_F16X3_PC, PC_CONV_F16X3_W4D_0, PC_CONV_F16X3_W4D_7 = PC_CONV_F16X3_W4D_0 + 7, PC_CONV_F16X3_PCP, PC_CONV_F16X3_K1G, PC_CONV_F16X3_W4D_D2, PC_CONV_F16X3_W4D_D4, PC_CONV_F16X3_H3, PC_CONV_FIRST, PC_CONV_DIRECT, PC_POOL, PC_DECONV, PC_TAIL, PC_MERGE, PC_LAYOUT, PC_COUNT };
+enum ProfClass { PC_CONV_MFMA, PC_CONV_MFMA_1 = 1, PC_CONV_MFMA_7 = 7, PC_CONV_F16X3_128, PC_CONV_F16X3_W4, PC_CONV_F16X3_W4_SPLIT, PC_CONV_F16X3_W4_MT2, PC_CONV_F16X3_W4_SPLIT_MT2, PC_CONV_F16X3_64, PC_CONV_F16X3_64_FUSE1, PC_CONV_F16X3_64_D2, PC_CONV_F16X3_64_D4, PC_CONV_F16X3_128_K1, PC_CONV_F16X3_64_K1, PC_CONV_F16X3_PC, PC_CONV_F16X3_W4D_0, PC_CONV_F16X3_W4D_7 = PC_CONV_F16X3_W4D_0 + 7, PC_CONV_F16X3_PCP, PC_CONV_F16X3_K1G, PC_CONV_F16X3_W4D_D2, PC_CONV_F16X3_W4D_D4, PC_CONV_F16X3_H3, PC_CONV_FIRST, PC_CONV_DIRECT, PC_POOL, PC_DECONV, PC_TAIL, PC_MERGE, PC_LAYOUT, PC_H2D, PC_D2H, PC_COUNT };
 extern const char* const kProfNames[PC_COUNT];   // net_forward.cpp
 
 struct Prof {
@@ -417,6 +417,15 @@ struct shf_net {
   TailWork tw;
   DevBuf tw_logits, tw_rec, tw_keys, tw_counters;
   bool materialize_tail = true;
+  // Net.forward() in a split-fp16 mode on a detector graph runs the FUSED path's kernels (fused first pair, pools in the
+  // convolutions' epilogues, split activation format: forward_ops(true) -- the very pass shf_detect_add_level runs, so
+  // lib/test.py's ten net.forward() calls give the detections of the device-resident path bit for bit) and leaves the
+  // intermediate blobs unmaterialised: `plain_stale`.  Reading one of them (Blob.data) then runs the per-layer kernels
+  // once, everything but the proposal tail (ensure_plain), so every name in net.blobs stays readable (pycaffe.py:24-32).
+  bool in_net_forward = false, plain_stale = false, plain_skip_tail = false;
+  float last_im_info[3] = {0.f, 0.f, 1.f};
+  bool forward_fast_eligible() const;
+  void ensure_plain();
   std::vector<int> last_data_shape;
   // fused per-image path
   DevBuf img_dets, img_keys, img_count;

@@ -26,7 +26,7 @@ import numpy as np
 from . import _lib, caffe
 from .config import cfg
 from .nms import bbox_vote, nms
-from .test_utils import _compute_scaling_factor, _get_image_blob, pyramid_scales
+from .test_utils import _compute_scaling_factor, _get_image_blob, _get_image_blob_device, pyramid_scales
 from .timer import Timer
 
 logger = logging.getLogger(__name__)
@@ -123,7 +123,10 @@ def detect(net, im_path, thresh=0.05, timers=None, pyramid=False, im=None):
         base_scale = _compute_scaling_factor(im.shape, cfg.TEST.PYRAMID_BASE_SIZE[0],
                                              cfg.TEST.PYRAMID_BASE_SIZE[1])
         pyramid_scales = [float(scale) / cfg.TEST.PYRAMID_BASE_SIZE[0] * base_scale for scale in cfg.TEST.SCALES]
-        im_blobs = _get_image_blob(im, pyramid_scales)
+        # (the reference: cv2.resize per level, a native library; here the same step on the GPU with host blobs out -- bit-equal
+        # to the numpy mirror _get_image_blob, which SHF_HOST_PREPROCESS=1 selects)
+        im_blobs = (_get_image_blob if os.environ.get("SHF_HOST_PREPROCESS") == "1" or im.dtype != np.uint8 else
+                    _get_image_blob_device)(im, pyramid_scales)
         for i in range(len(pyramid_scales)):
             probs, boxes = forward_net(net, im_blobs[i], pyramid_scales[i], pyramid=True)
             for j in range(len(probs)):
@@ -347,13 +350,15 @@ class FusedDetector(object):
         """``units``: list of (data, H, W, im_h, im_w, scale, flip); data = host array or device pointer."""
         units = list(units)
         if self.mode == "group":
-            while len(self.lanes) < min(len(units), GROUP_UNITS):
+            # every pass of a longer unit list on lanes of ITS OWN, like submit(): a pass's tail phase 2 may run (pipelined
+            # head) beside the next pass's convolutions and logits, and the two must not share tail workspaces
+            while len(self.lanes) < len(units):
                 self.lanes.append(self.net.clone())
             head = self.lanes[0]
             head.detect_begin()
             for a in range(0, len(units), GROUP_UNITS):
-                chunk = units[a:a + GROUP_UNITS]
-                head.detect_add_levels(self.lanes[:len(chunk)], chunk, thresh, on_device=on_device)
+                b = min(a + GROUP_UNITS, len(units))
+                head.detect_add_levels(self.lanes[a:b], units[a:b], thresh, on_device=on_device)
             try:
                 return [head.detect_finish(cfg.TEST.NMS_METHOD, cfg.TEST.NMS_THRESH)]
             except _lib.ShfError as e:
@@ -460,6 +465,17 @@ def fused_image_loop(net, paths, thresh=0.05, timers=None, progress=None, prefet
             out[j] = fd.collect()[0]
             if progress:
                 progress(j)
+    except BaseException:
+        # a reader or a submit failed with images still in flight: drain the detector (a caller-provided ``fd`` would
+        # otherwise hand the NEXT user detections of these images) and drop the decodes that have not started
+        for f in ahead:
+            f.cancel()
+        while fd.pending():
+            try:
+                fd.collect()
+            except Exception:
+                pass
+        raise
     finally:
         if pool:
             pool.shutdown(wait=True)

@@ -44,10 +44,10 @@ def test_gather_results_orders_by_rank():
 
 
 @pytest.mark.parametrize("mode,code", [("die", "7"), ("silent", "0")])
-def test_dead_worker_raises_instead_of_hanging(mode, code):
+def test_dead_worker_raises_instead_of_hanging(mode, code, monkeypatch):
     from smallhardface_amd.config import cfg
     from smallhardface_amd.test import _gather_results
-    cfg.TEST.GPU_ID = [0, 0, 0]
+    monkeypatch.setattr(cfg.TEST, "GPU_ID", [0, 0, 0])
     q, procs = _start(["ok", mode, "slow"])
     t0 = time.time()
     with pytest.raises(RuntimeError) as e:
