@@ -619,7 +619,9 @@ def main():
                          "mean_jpeg_kb": nbytes / len(paths) / 1024.0,
                          "decode_ms": st_["decode_ms"], "decode_wait_ms": st_["decode_wait_ms"], "submit_ms": st_["submit_ms"],
                          "collect_wait_ms": st_["collect_wait_ms"], "write_ms": 1000.0 * (t3 - t2) / len(paths),
-                         "decode_threads": st_["decode_threads"], "voted_boxes": int(sum(len(d) for d in dets_f)),
+                         "decode_threads": st_["decode_threads"], "decode_prefetch": st_["decode_prefetch"],
+                         "decode_prefetch_adaptive": st_["decode_prefetch_adaptive"], "decode_over_step": st_["decode_over_step"],
+                         "voted_boxes": int(sum(len(d) for d in dets_f)),
                          "path": "JPEG files (the mixed_shapes stream's 8 shapes, photo-like content, quality 90) -> PIL decode on "
                                  "reader threads -> test.fused_image_loop (what test.inference_worker runs) -> "
                                  "datasets.write_detections_wider; per-image means in ms: decode on the reader threads, and on "
@@ -689,13 +691,16 @@ def main():
     nf_path = None
     if not dist_path and args.mode == "group" and not args.no_forward_path and not args.host_input and rank == 0:
         from smallhardface_amd import test as T
-        from smallhardface_amd.test_utils import _get_image_blob, pyramid_scales
+        from smallhardface_amd.test_utils import _get_image_blob, _get_image_blob_device, pyramid_scales
         im0 = np.random.default_rng(1000).integers(0, 256, (src_hw[0], src_hw[1], 3)).astype(np.uint8)   # = build_units(0)
         fence()
         T.detect(net, None, thresh, pyramid=True, im=im0)                  # untimed: buffers of the root net at these shapes
         t1 = time.perf_counter()
-        _get_image_blob(im0, pyramid_scales(im0.shape))
+        _get_image_blob_device(im0, pyramid_scales(im0.shape))       # what detect() calls (C ABI shf_image_blobs)
         pre_s = time.perf_counter() - t1
+        t1 = time.perf_counter()
+        _get_image_blob(im0, pyramid_scales(im0.shape))              # the numpy mirror of the same step (SHF_HOST_PREPROCESS=1)
+        pre_host_s = time.perf_counter() - t1
         n_nf = 3
         net.timing = {}
         net.prof_enable(True)
@@ -719,7 +724,7 @@ def main():
         nf_path = {
             "value": 1.0 / wall, "unit": "images/s", "ms_per_image": 1000.0 * wall, "images": n_nf,
             "vs_fused_rate": (1.0 / wall) / (args.steps / elapsed),
-            "host_preprocess_ms": 1000.0 * pre_s,
+            "preprocess_ms": 1000.0 * pre_s, "preprocess_numpy_mirror_ms": 1000.0 * pre_host_s,
             "forward_calls_per_image": tm.get("calls", 0) / n_nf,
             "input_copy_ms": per(tm.get("input_copy_s", 0.0)), "forward_call_ms": per(tm.get("forward_call_s", 0.0)),
             "output_read_ms": per(tm.get("output_read_s", 0.0)),
@@ -729,8 +734,9 @@ def main():
             "boxes": int(len(got)),
             "identical_to_fused_path": bool(fused_ref is not None and fused_ref.shape == got.shape and np.array_equal(fused_ref, got)),
             "kernel_ms_per_image": {k: round(v, 3) for k, v in dev_ms.items()},
-            "path": "test.detect(net, im=...) as lib/test.py:109-178: _get_image_blob on the host (numpy restatement of cv2.resize, "
-                    "float64: host_preprocess_ms of ms_per_image), ten forward_net() -> Net.forward() with host blobs "
+            "path": "test.detect(net, im=...) as lib/test.py:109-178: _get_image_blob with host blobs out (preprocess_ms: the five "
+                    "levels through shf_image_blobs, where the reference calls cv2.resize; the bit-equal numpy mirror would take "
+                    "preprocess_numpy_mirror_ms), ten forward_net() -> Net.forward() with host blobs "
                     "(input_copy_ms: np.pad + the copy into the blob's pinned mirror; forward_call_ms: shf_net_forward = H2D + "
                     "kernels + count read-back, on the device h2d_ms / forward_ms / d2h_ms by HIP events; output_read_ms: "
                     "Blob.data of boxes / cls_prob), > 0.05 cut on the host, bbox_vote through the C ABI (merge_ms); f16x3: "

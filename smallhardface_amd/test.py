@@ -409,13 +409,21 @@ def fused_image_loop(net, paths, thresh=0.05, timers=None, progress=None, prefet
     from concurrent.futures import ThreadPoolExecutor
     if timers is None:
         timers = {'detect': Timer(), 'misc': Timer()}
+    # decode-ahead depth: SHF_DECODE_PREFETCH / ``prefetch`` fix it; otherwise it starts at 2 and is re-sized every few images
+    # from what the loop itself measures -- decodes in flight needed = decode time / time per image of the loop, + 1 of
+    # slack, within [2, 8] (a slow decoder -- large JPEGs, a busy host -- then gets more reader threads instead of
+    # starving the GPU; stats["decode_prefetch"] reports where it ended)
+    adaptive = prefetch is None and "SHF_DECODE_PREFETCH" not in os.environ
     if prefetch is None:
         prefetch = int(os.environ.get("SHF_DECODE_PREFETCH", "2"))
     prefetch = max(0, int(prefetch))
+    max_prefetch = 8 if adaptive else prefetch
     n_units = len(cfg.TEST.SCALES) * (2 if cfg.TEST.FLIP else 1)
     fd = fd or FusedDetector(net, n_lanes=n_units, mode="group")
     dp = dp or DevicePyramid(net, n_slots=2)
     acc = {"decode": 0.0, "decode_wait": 0.0, "submit": 0.0, "collect_wait": 0.0}
+    n_decoded = [0]
+    t_loop0 = time.perf_counter()
 
     import threading
     acc_lock = threading.Lock()
@@ -425,13 +433,14 @@ def fused_image_loop(net, paths, thresh=0.05, timers=None, progress=None, prefet
         im = _imread(path)
         with acc_lock:
             acc["decode"] += time.perf_counter() - t0
+            n_decoded[0] += 1
         if im is None:
             raise IOError("cannot read image %s" % path)
         return im
 
     out = [None] * len(paths)
     queued = []
-    pool = ThreadPoolExecutor(max_workers=prefetch) if prefetch and len(paths) > 1 else None
+    pool = ThreadPoolExecutor(max_workers=max_prefetch) if prefetch and len(paths) > 1 else None
     ahead, nxt_i = [], 0     # futures of the images after the current one, in order
     try:
         for i in list(range(len(paths))) + [None]:
@@ -439,6 +448,11 @@ def fused_image_loop(net, paths, thresh=0.05, timers=None, progress=None, prefet
                 timers['misc'].tic()
                 t0 = time.perf_counter()
                 if pool:
+                    if adaptive and i >= 4 and i % 4 == 0 and n_decoded[0] > 0:
+                        with acc_lock:
+                            dec = acc["decode"] / n_decoded[0]
+                        per_image = (time.perf_counter() - t_loop0) / i
+                        prefetch = int(min(max_prefetch, max(2, np.ceil(dec / max(per_image, 1e-6)) + 1)))
                     while nxt_i < len(paths) and nxt_i <= i + prefetch:
                         ahead.append(pool.submit(read, paths[nxt_i]))
                         nxt_i += 1
@@ -481,7 +495,10 @@ def fused_image_loop(net, paths, thresh=0.05, timers=None, progress=None, prefet
             pool.shutdown(wait=True)
     if stats is not None and paths:
         stats.update({k + "_ms": 1000.0 * v / len(paths) for k, v in acc.items()})
-        stats["decode_threads"] = prefetch if pool else 0
+        stats["decode_threads"] = max_prefetch if pool else 0
+        stats["decode_prefetch"] = prefetch if pool else 0
+        stats["decode_prefetch_adaptive"] = bool(adaptive and pool)
+        stats["decode_over_step"] = (acc["decode"] / max(1, n_decoded[0])) / max((time.perf_counter() - t_loop0) / max(1, len(paths)), 1e-9)
     return out
 
 
