@@ -53,7 +53,17 @@ def build_units(image_index, src_hw=(SRC_H, SRC_W)):
     return list(pyramid_units(im))
 
 
-PMC_FILE = "profiles/r05_pmc.json"   # written by tools/make_profiles.sh (separate rocprofv3 --pmc passes of this command)
+PMC_FILE = "profiles/r06_pmc.json"   # written by tools/make_profiles.sh (separate rocprofv3 --pmc passes of this command)
+LADDER_FILE = "profiles/r06_precision_ladder.json"   # tools/precision_ladder.py: measured drift of the reduced modes
+
+
+def ladder_drift(mode):
+    """'max |dscore| X vs the oracle at C1' for a reduced mode, read from the committed ladder (never a remembered figure)."""
+    try:
+        v = json.load(open(os.path.join(ROOT, LADDER_FILE)))["modes"][mode]["c1_max_abs_dscore_vs_oracle"]
+        return "max |dscore| %.1e vs the oracle at C1 (%s)" % (v, LADDER_FILE)
+    except Exception:
+        return "drift: see tools/precision_ladder.py"
 
 
 def committed_pmc(kernel_name):
@@ -198,8 +208,8 @@ def main():
                     help="f16x3 (headline): split-fp16 MFMA, 3 fp16 products per fp32 product, fp32 accumulate: fp32-class "
                          "accuracy, passes every 1e-4 parity test; fp32: exact v_mfma_f32_32x32x2_f32 everywhere; f16x2 / "
                          "f16 / bf16: the reduced ladder (2 / 1 fp16 products, 1 bf16 product, in EVERY conv kernel) -- NOT "
-                         "parity modes, their measured score drift is in profiles/r03_precision_ladder.json (1.8e-3 / 2.6e-3 / "
-                         "1.9e-2 at C1)")
+                         "parity modes, their measured score drift is in " + LADDER_FILE + " (f16x2: %s; f16: %s; bf16: %s)"
+                         % (ladder_drift("f16x2"), ladder_drift("f16"), ladder_drift("bf16")))
     ap.add_argument("--no-reduced", action="store_true", help="skip the reduced-precision leg (N=1, headline mode f16x3 only): a "
                     "short second run in bf16 and f16 AFTER and OUTSIDE the timed region, reported as 'reduced_precision'")
     ap.add_argument("--host-input", nargs="?", const="blobs", default=None, choices=["blobs", "image"],
@@ -757,10 +767,9 @@ def main():
             "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
             "dtype": {"f16x3": "f32 via split-f16 MFMA (3x fp16 products, f32 accumulate)", "fp32": "f32",
-                      "f16x2": "f16 activations x split-f16 weights (2 fp16 products, f32 accumulate): drift-labelled, "
-                               "max |dscore| 1.5e-3 vs the oracle at C1",
-                      "f16": "f16 operands (1 product, f32 accumulate): drift-labelled, max |dscore| 2.6e-3 at C1",
-                      "bf16": "bf16 operands (1 product, f32 accumulate): drift-labelled, max |dscore| 1.9e-2 at C1"}[args.conv_mode],
+                      "f16x2": "f16 activations x split-f16 weights (2 fp16 products, f32 accumulate): drift-labelled, " + ladder_drift("f16x2"),
+                      "f16": "f16 operands (1 product, f32 accumulate): drift-labelled, " + ladder_drift("f16"),
+                      "bf16": "bf16 operands (1 product, f32 accumulate): drift-labelled, " + ladder_drift("bf16")}[args.conv_mode],
             "data": "synthetic",
             "config": {
                 "workload": ("C5: full smallhardface.toml test pyramid" if default_wl else "test pyramid") +

@@ -1,4 +1,4 @@
-"""The committed bench line (profiles/r05_bench.json, written by bench.py on an MI355X) carries every field
+"""The committed bench line (profiles/r06_bench.json, written by bench.py on an MI355X) carries every field
 the bench contract names, and the committed rocprofv3 summary names the same dominant kernel."""
 import csv
 import json
@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_bench_json_contract():
-    d = json.load(open(os.path.join(ROOT, "profiles", "r05_bench.json")))
+    d = json.load(open(os.path.join(ROOT, "profiles", "r06_bench.json")))
     base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
@@ -42,10 +42,35 @@ def test_bench_json_contract():
     assert 1e-4 < rp["max_abs_dscore_vs_fp32"] < 0.1 and 1e-5 < rp["also"]["max_abs_dscore_vs_fp32"] < 0.02
 
 
+def test_bench_json_round6_legs():
+    """Round 6: sampled clock / socket power of the sustained leg and of the matrix-pipe calibration rows (host-side hwmon
+    sampler), and the literal drop-in path -- lib/test.py's detect() with ten Net.forward() calls and host
+    blobs -- as a rate of its own with its h2d / forward / d2h split, detections identical to the fused path (#3)."""
+    d = json.load(open(os.path.join(ROOT, "profiles", "r06_bench.json")))
+    t = d["sustained"]["telemetry"]
+    for k in ("sclk_mhz_mean", "sclk_mhz_min", "power_w_mean", "power_cap_w", "samples"):
+        assert k in t, k
+    assert t["samples"] > 50 and 500 < t["sclk_mhz_mean"] <= 2500 and 100 < t["power_w_mean"] <= t["power_cap_w"] * 1.05
+    ct = d["roofline"]["matrix_pipe_sustained"]["telemetry"]
+    assert set(ct) == {"operands_constant", "operands_random", "operands_random_half_of_activations_zero"}
+    # toggling operands cost clock: the constant-operand stream runs faster than the random one, and draws less
+    assert ct["operands_constant"]["sclk_mhz_mean"] > ct["operands_random"]["sclk_mhz_mean"]
+    assert ct["operands_constant"]["power_w_mean"] < ct["operands_random"]["power_w_mean"]
+    n = d["net_forward_path"]
+    for k in ("value", "ms_per_image", "h2d_ms", "forward_ms", "d2h_ms", "preprocess_ms", "forward_calls_per_image",
+              "identical_to_fused_path", "vs_fused_rate"):
+        assert k in n, k
+    assert n["forward_calls_per_image"] == 10 and n["identical_to_fused_path"] is True
+    assert 0 < n["value"] < d["value"] and abs(n["vs_fused_rate"] - n["value"] / d["value"]) < 1e-6
+    assert n["h2d_ms"] > 0 and n["forward_ms"] > n["h2d_ms"]
+    f = d["from_files"]
+    assert "decode_prefetch" in f and f["decode_prefetch"] >= 2
+
+
 def test_rocprof_summary_names_the_dominant_kernel():
-    d = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_under_rocprof.json")))
+    d = json.load(open(os.path.join(ROOT, "profiles", "r06_bench_under_rocprof.json")))
     name = d["roofline"]["kernel"]
-    rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "r05_bench_kernel_stats.csv"))))
+    rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "r06_bench_kernel_stats.csv"))))
     hit = [r for r in rows if name in r["Name"]]
     assert hit, name
     avg_ms = float(hit[0]["AverageNs"]) / 1e6
@@ -54,28 +79,28 @@ def test_rocprof_summary_names_the_dominant_kernel():
 
 
 def test_committed_pmc_summary_and_layer_table():
-    """profiles/r05_pmc.json (counter passes) and r05_layers.csv (one row per conv launch of an image) are what the
+    """profiles/r06_pmc.json (counter passes) and r06_layers.csv (one row per conv launch of an image) are what the
     roofline numbers can be recomputed from; the layer table covers the whole image's algorithmic work."""
-    d = json.load(open(os.path.join(ROOT, "profiles", "r05_pmc.json")))
-    dom = json.load(open(os.path.join(ROOT, "profiles", "r05_bench.json")))["roofline"]["kernel"]
+    d = json.load(open(os.path.join(ROOT, "profiles", "r06_pmc.json")))
+    dom = json.load(open(os.path.join(ROOT, "profiles", "r06_bench.json")))["roofline"]["kernel"]
     assert dom.startswith("conv_mfma_f16x3_w4d")    # the dual-tile 4-wave family
     k = d["kernels"][dom]
     for key in ("hbm_bytes_per_launch", "mfma_busy", "effective_clock_ghz", "lds_bank_conflict_frac", "avg_us"):
         assert key in k, key
     assert 0.0 < k["mfma_busy"] <= 1.0
-    rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "r05_layers.csv"))))
+    rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "r06_layers.csv"))))
     assert len(rows) == 17 and rows[0]["layer"] == "conv1_1+conv1_2"     # (the three dilated heads are one launch: one row)
     gf = sum(float(r["algorithmic_gflop"]) for r in rows)
     assert abs(gf - 5021.6) < 2.0          # SURVEY.md 8d: 5021.62 GFLOP per image (the deconv's 0.1 GFLOP aside)
 
 
 def test_committed_counters_belong_to_the_committed_kernels():
-    """profiles/r05_pmc.json carries the hash of the kernel sources it was measured on (tools/kernel_hash.py: comments and
+    """profiles/r06_pmc.json carries the hash of the kernel sources it was measured on (tools/kernel_hash.py: comments and
     white space do not count); bench.py only quotes traffic / MFMA-busy from it while that matches -- so must the tree."""
     import sys
     sys.path.insert(0, ROOT)
     from tools.kernel_hash import kernel_source_hash
-    d = json.load(open(os.path.join(ROOT, "profiles", "r05_pmc.json")))
+    d = json.load(open(os.path.join(ROOT, "profiles", "r06_pmc.json")))
     assert d["kernel_source_hash"] == kernel_source_hash()
-    b = json.load(open(os.path.join(ROOT, "profiles", "r05_bench.json")))
+    b = json.load(open(os.path.join(ROOT, "profiles", "r06_bench.json")))
     assert b["roofline"]["traffic"] is not None and b["roofline"]["mfma_busy"] is not None

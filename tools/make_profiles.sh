@@ -1,6 +1,6 @@
 #!/bin/bash
 # Regenerates the evidence under profiles/ on a GPU box (run from the repo root, e.g. via gpurun):
-#   tools/make_profiles.sh r05
+#   tools/make_profiles.sh r06
 # 1. rocprofv3 --kernel-trace --stats of the default bench command  -> <tag>_bench_kernel_stats.csv
 #    + the JSON line bench.py printed in that run                    -> <tag>_bench_under_rocprof.json
 # 2. counter passes, each its own run with --kernel-trace only (never with --stats / --sys-trace):
@@ -12,13 +12,13 @@
 # Everything is written under gpurun_out/prof_<tag>/ and the summaries copied to gpurun_out/profiles_<tag>/
 # (gpurun merges gpurun_out/ back; copy from there into profiles/ and commit).
 set -u
-tag=${1:-r05}
+tag=${1:-r06}
 root=$(pwd)
 out=$root/gpurun_out/prof_$tag
 dst=$root/gpurun_out/profiles_$tag
 mkdir -p $out $dst
 cd /tmp && export TMPDIR=/tmp && cd $root
-BENCH_PMC="bench.py --steps 2 --warmup 1 --no-events --no-cpu-baseline --no-latency --no-reduced --no-calib --no-mixed --sustain-seconds 0"
+BENCH_PMC="bench.py --steps 2 --warmup 1 --no-events --no-cpu-baseline --no-latency --no-reduced --no-calib --no-mixed --no-forward-path --sustain-seconds 0"
 rocprofv3 --kernel-trace --output-format csv -d $out/trace -- python3 $BENCH_PMC > $out/trace.log 2>&1
 i=0
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES"; do
@@ -27,7 +27,7 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GR
 done
 python3 tools/layer_table.py $out $dst $tag > $out/layer_table.log 2>&1
 tail -40 $out/layer_table.log
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --steps 10 --warmup 2 --no-reduced --no-calib --no-mixed --sustain-seconds 0 --no-cpu-baseline > $out/bench_under_rocprof.out 2> $out/bench_under_rocprof.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --steps 10 --warmup 2 --no-reduced --no-calib --no-mixed --no-forward-path --sustain-seconds 0 --no-cpu-baseline > $out/bench_under_rocprof.out 2> $out/bench_under_rocprof.log
 grep '^{"metric"' $out/bench_under_rocprof.out | tail -1 > $dst/${tag}_bench_under_rocprof.json
 cp $(ls $out/stats/*/*kernel_stats.csv | head -1) $dst/${tag}_bench_kernel_stats.csv
 # the bench line quotes traffic / MFMA-busy from the committed counter file: make this run's the committed one
