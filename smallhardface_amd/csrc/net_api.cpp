@@ -134,6 +134,7 @@ int shf_blob_reshape(shf_net* net, int blob, const int* dims, int ndim) {
       b.dev.ensure(std::max<size_t>(b.count(), 1) * 4);
       b.host.ensure(std::max<size_t>(b.count(), 1) * 4);
       b.host_newer = true;
+      net->inputs_reshaped = true;   // (the device copy of the last forward's input may have been re-allocated: ensure_plain)
     }
   }
   return 0;

@@ -259,6 +259,7 @@ void shf_net::forward() {
   if (im_info_blob >= 0 && blobs[im_info_blob].host.p && blobs[im_info_blob].count() >= 3)
     memcpy(ii, blobs[im_info_blob].host.p, 12);
   memcpy(last_im_info, ii, 12);
+  inputs_reshaped = false;
   const bool fast = forward_fast_eligible();
   struct Scope {   // (forward_ops may throw)
     bool& f;
@@ -315,7 +316,7 @@ void shf_net::forward() {
 // forward's own arithmetic mode, on the inputs still resident on the device -- everything except the proposal tail
 void shf_net::ensure_plain() {
   if (!plain_stale) return;
-  if (data_blob >= 0 && blobs[data_blob].shape != last_data_shape)
+  if (inputs_reshaped || (data_blob >= 0 && blobs[data_blob].shape != last_data_shape))
     throw std::runtime_error("an input was reshaped after the last forward(): call forward() before reading intermediate blobs");
   struct Scope {
     bool& f;

@@ -422,7 +422,7 @@ struct shf_net {
   // lib/test.py's ten net.forward() calls give the detections of the device-resident path bit for bit) and leaves the
   // intermediate blobs unmaterialised: `plain_stale`.  Reading one of them (Blob.data) then runs the per-layer kernels
   // once, everything but the proposal tail (ensure_plain), so every name in net.blobs stays readable (pycaffe.py:24-32).
-  bool in_net_forward = false, plain_stale = false, plain_skip_tail = false;
+  bool in_net_forward = false, plain_stale = false, plain_skip_tail = false, inputs_reshaped = false;
   float last_im_info[3] = {0.f, 0.f, 1.f};
   bool forward_fast_eligible() const;
   void ensure_plain();

@@ -353,6 +353,18 @@ def test_every_blob_is_readable_after_forward(dd, conv_mode):
     name = fused[0]
     a, b = gnet.blobs[name].data, onet.blobs[name].data
     assert a.shape == b.shape and np.abs(a - b).max() < 1e-4 * max(1.0, float(np.abs(b).max()))
+    if conv_mode == "f16x3":
+        # a split-fp16 forward runs the fused path's kernels and leaves the intermediates to be materialised on demand from
+        # the inputs still on the device: reshaping an input in between is refused with a message, not answered with garbage
+        H.run_both(gnet, onet, data2, np.array([[48, 64, 1.0]], np.float32))
+        gnet.blobs['data'].reshape(1, 3, 32, 32)
+        with pytest.raises(Exception, match="reshaped after the last forward"):
+            gnet.blobs["conv3_3"].data
+        gnet.blobs['data'].reshape(*data2.shape)
+        with pytest.raises(Exception, match="reshaped after the last forward"):     # (its device copy may be gone)
+            gnet.blobs["conv3_3"].data
+        H.run_both(gnet, onet, data2, np.array([[48, 64, 1.0]], np.float32))
+        assert H.rel_err(gnet.blobs["conv3_3"].data, onet.blobs["conv3_3"].data) < ACT_TOL
 
 
 def test_proposal_edge_cases():
