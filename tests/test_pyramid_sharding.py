@@ -138,3 +138,155 @@ def test_pyramid_level_shape_matches_host_rounding():
         assert caffe.pyramid_level_shape(h, w, s, m) == want, (h, w, s)
     with pytest.raises(ValueError):
         caffe.pyramid_level_shape(0, 5, 1.0, 16)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# pyramid.ShardedDetector's schedule on CPU: a FAKE net (host tensors, rows that encode which unit produced them) under
+# the real class, the real gather_window and a real gloo group -- lane sets, chunking into passes of 16, export ->
+# all_to_all -> import -> merge on the owner, window k + 1 enqueued before window k is finished, a partly filled last window,
+# a rank without a share.  (The same class runs the GPU net in bench.py and in test.pyramid_sharded_inference.)
+# ------------------------------------------------------------------------------------------------------------
+class _FakeNet(object):
+    """The slice of caffe.Net that ShardedDetector touches.  A unit's `data` field carries its id (window, image, unit);
+    the rows a unit "detects" are a function of that id alone, so the checker can regenerate them."""
+
+    def __init__(self, log=None):
+        self.log = log if log is not None else []
+        self.rows = None
+        self.imported = []
+
+    def clone(self):
+        return _FakeNet(self.log)
+
+    def set_pipeline(self, on=True):
+        pass
+
+    def sync(self):
+        pass
+
+    @staticmethod
+    def rows_of(uid):
+        rng = np.random.default_rng(uid)
+        n = int(rng.integers(0, 6))
+        r = rng.uniform(1, 100, (n, 5)).astype(np.float32)
+        r[:, 4] = uid + np.arange(n) / 16.0            # scores: unique, exact in fp32, identify the unit
+        return r
+
+    def detect_add_levels(self, members, units, thresh, on_device=False, per_member_lists=False):
+        assert on_device and per_member_lists and 1 <= len(units) <= 16 and len(members) == len(units)
+        assert len(set(id(m) for m in members)) == len(members) and members[0] is self
+        self.log.append(("pass", len(units)))
+        for m, u in zip(members, units):
+            m.rows = self.rows_of(int(u[0]))
+
+    def detect_export_many(self, members, dst_ptrs, cap_rows):
+        import ctypes
+        counts = []
+        for m, p in zip(members, dst_ptrs):
+            r = np.ascontiguousarray(m.rows[:cap_rows])
+            if len(r):
+                ctypes.memmove(int(p), r.ctypes.data, r.nbytes)
+            counts.append(len(m.rows))
+        self.log.append(("export", len(members)))
+        return counts
+
+    def detect_begin(self):
+        self.imported = []
+
+    def detect_import(self, src_ptr, n_rows):
+        import ctypes
+        a = np.empty((n_rows, 5), np.float32)
+        if n_rows:
+            ctypes.memmove(a.ctypes.data, int(src_ptr), a.nbytes)
+        self.imported.append(a)
+
+    def detect_finish(self, method="BBOX_VOTE", nms_thresh=0.4, cap=None):
+        a = np.concatenate(self.imported, 0) if self.imported else np.zeros((0, 5), np.float32)
+        return a[np.argsort(-a[:, 4], kind="stable")].astype(np.float64)      # a stand-in "merge": score order
+
+
+def _uid(window, image, unit):
+    return 1000 * window + 20 * image + unit + 1
+
+
+def _sharded_worker(rank, world, port, q, shard, n_units, n_windows, last_valid):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        net = _FakeNet()
+        sd = pyramid.ShardedDetector(net, rank, world, n_units, units_per_level=2, shard=shard, thresh=0.05,
+                                     device=torch.device("cpu"), cap_rows=64)
+        assert len(sd.lane_sets) == 2 and all(len(ls) == len(sd.mine) for ls in sd.lane_sets)
+        out = {}
+        prev = None
+        for w in range(n_windows):
+            n_valid = last_valid if w == n_windows - 1 else world
+            picks = [(i, u) for (i, u) in sd.mine if i < n_valid]
+            units = [(_uid(w, i, u), 16, 16, 16, 16, 1.0, False) for (i, u) in picks]
+            done = sd.submit(units, picks=picks, n_valid=n_valid)
+            if w == 0:
+                assert done == {}                              # nothing to finish behind the first window
+            for i, d in done.items():
+                out[(prev, i)] = d
+            prev = w
+        for i, d in sd.flush().items():
+            out[(prev, i)] = d
+        assert sd.flush() == {}
+        q.put((rank, {k: v for k, v in out.items()}, sd.collectives, [e for e in net.log if e[0] == "pass"]))
+    finally:
+        if world > 1:
+            dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world,shard,n_units,n_windows,last_valid", [
+    (2, "window", 10, 3, 1),        # the bench's shape on two ranks; the last window holds ONE image
+    (2, "strict", 18, 2, 2),        # rank 0: 5 levels x 2 flips x 2 images = 20 units = two passes (16 + 4) on two head lanes
+    (3, "strict", 4, 2, 3),         # 2 levels on 3 ranks: rank 2 runs nothing and only takes part in the exchange
+    (1, "window", 10, 2, 1),        # one rank, no process group: the same class without a collective
+])
+def test_sharded_detector_schedule_with_a_fake_net(world, shard, n_units, n_windows, last_valid):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, world, port, q, shard, n_units, n_windows, last_valid))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in procs:
+        r, out, collectives, passes = q.get(timeout=240)
+        res[r] = (out, collectives, passes)
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    for r in range(world):
+        out, collectives, passes = res[r]
+        assert collectives == n_windows                     # ONE exchange per window, on every rank alike
+        mine = pyramid.my_units(r, world, world, n_units, shard=shard, units_per_level=2)
+        if len(mine) > 16:                                  # a share above one member table runs as several passes
+            assert ("pass", 16) in passes and ("pass", len(mine) - 16) in passes
+        # this rank holds exactly the images it owns, of exactly the windows' valid images
+        want_keys = {(w, i) for w in range(n_windows) for i in range(last_valid if w == n_windows - 1 else world)
+                     if pyramid.image_owner(i, world) == r}
+        assert set(out) == want_keys, (r, sorted(out), sorted(want_keys))
+        for (w, i), got in out.items():
+            rows = [_FakeNet.rows_of(_uid(w, i, u)) for u in range(n_units)]
+            exp = np.concatenate(rows, 0)
+            exp = exp[np.argsort(-exp[:, 4], kind="stable")].astype(np.float64)
+            assert got.dtype == np.float64 and got.shape == exp.shape, (w, i, got.shape, exp.shape)
+            np.testing.assert_array_equal(got, exp)
+
+
+def test_sharded_detector_refuses_a_mismatched_share():
+    import torch
+    sd = pyramid.ShardedDetector(_FakeNet(), 0, 1, 4, units_per_level=2, device=torch.device("cpu"), cap_rows=8)
+    with pytest.raises(ValueError):
+        sd.submit([(1, 16, 16, 16, 16, 1.0, False)] * 3, picks=[(0, 0), (0, 1)])
+    with pytest.raises(ValueError):
+        sd.submit([(1, 16, 16, 16, 16, 1.0, False)] * 5, picks=[(0, u) for u in range(5)])
