@@ -246,6 +246,24 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
     constexpr int NMT = (HP + 31) / 32;  // 11 row tiles
     // work items: tiles 0..7 whole (one per wave), tiles 8..10 split by N tile over waves 0..5: the longest
     // wave does 1.5 tiles instead of 2
+    // conv1_1's operands -- weight fragments [n][kk][hi / lo] and the bias quads of couts 8q + 4kh .. + 3 -- are the SAME for
+    // every row tile: a wave reads them from LDS ONCE per phase (before its first row tile of a tile's conv1_1) and keeps them
+    // in registers over the 2-3 row tiles it gets through (round 6; until then every row tile re-read its 16 KiB: 16 of the 33
+    // LDS instructions of a row tile and a full LDS round trip at its start).  They are not held across the K loop.
+    half8 bwn[2][2][2];   // [n][kk][hi / lo]
+    float4 bq[2][4];      // [n][register quad]
+    auto conv1_operands = [&]() {
+#pragma unroll
+      for (int n = 0; n < 2; ++n) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+          for (int hl = 0; hl < 2; ++hl)
+            bwn[n][kk][hl] = *(const half8*)(w1L + ((size_t)((n * 2 + kk) * 2 + hl) * 64 + (i1 + 32 * kh1)) * 16);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bq[n][q] = *(const float4*)(b1L + n * 32 + 8 * q + 4 * kh1);
+      }
+    };
     auto conv1_tile = [&](int m, int n_lo, int n_hi, bool halo_inside) {
       const int hp = m * 32 + i1 < HP ? m * 32 + i1 : HP - 1;
       const int hy = (hp * 58255) >> 20, hx = hp - hy * HTW;
@@ -283,19 +301,6 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
       // all the MFMAs (two independent chains), then the two epilogues.  Written chunk by chunk -- operands, MFMAs, epilogue,
       // stores, next chunk -- the compiler waited for each bias quad on its own (eight serial LDS round trips) and could not
       // start chunk 1's reads before chunk 0's LDS stores: a row tile was one ~2.8 k-cycle dependent chain.
-      half8 bwn[2][2][2];   // [n][kk][hi / lo]
-      float4 bq[2][4];      // [n][register quad]: biases of couts 8q + 4kh .. + 3
-#pragma unroll
-      for (int n = 0; n < 2; ++n) {
-        if (n < n_lo || n >= n_hi) continue;  // wave-uniform
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-          for (int hl = 0; hl < 2; ++hl)
-            bwn[n][kk][hl] = *(const half8*)(w1L + ((size_t)((n * 2 + kk) * 2 + hl) * 64 + (i1 + 32 * kh1)) * 16);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) bq[n][q] = *(const float4*)(b1L + n * 32 + 8 * q + 4 * kh1);
-      }
       unsigned char okb = 1;
       const bool need_ok = !(halo_inside && m + 1 < NMT);   // (wave-uniform: most row tiles have every halo pixel inside the image)
       if (need_ok) okb = valid[m * 32 + i1];               // 0 outside the image (conv1_2's zero padding, not conv1_1 evaluated out there)
@@ -372,6 +377,7 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
     };
     {
       const bool halo_inside = ty0 >= 1 && tx0 >= 1 && ty0 + TH < H && tx0 + TW < W;   // (wave-uniform)
+      conv1_operands();
       conv1_tile(wave_u, 0, 2, halo_inside);
       if (wave_u < 2 * (NMT - 8)) conv1_tile(8 + wave_u % (NMT - 8), wave_u / (NMT - 8), wave_u / (NMT - 8) + 1, halo_inside);
       amax1 = conv_absmax_bits(amax1, fmaxf((float)amax1h[0], (float)amax1h[1]));
@@ -672,6 +678,7 @@ __global__ __launch_bounds__(512) void conv_mfma_f16x3_pc_kernel(ConvK p) {
     i1 = lane_p & 31;
     kh1 = lane_p >> 5;
     const bool halo_inside = __builtin_amdgcn_readfirstlane((int)ctrL[1]) != 0;
+    conv1_operands();
 #pragma unroll 1
     for (;;) {
       unsigned got = 0u;
