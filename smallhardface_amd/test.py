@@ -625,7 +625,7 @@ def pyramid_sharded_inference(imdb, target_test, thresh=0.05, strict=False, prog
     if not str(cfg.TEST.MODEL):
         raise IOError("TEST.MODEL is empty: pass --amend TEST.MODEL <file>.caffemodel")
     torch.cuda.set_device(dev_id)
-    dist, own_group = None, False
+    dist, own_group, finished = None, False, False
     if world > 1:
         import datetime
         import torch.distributed as dist
@@ -706,10 +706,12 @@ def pyramid_sharded_inference(imdb, target_test, thresh=0.05, strict=False, prog
         dets = [[[] for _ in range(n)] for _ in range(imdb.num_classes)]
         for i in range(n):
             dets[1][i] = owned[i]
+        finished = True
         return dets
     finally:
         if own_group:
-            dist.barrier()
+            if finished:                  # (after a failure the other ranks are not at this barrier: let the group's timeout end them)
+                dist.barrier()
             dist.destroy_process_group()
 
 
