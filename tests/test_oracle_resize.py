@@ -119,3 +119,28 @@ def test_device_pyramid_level_equals_the_oracle(shape, scales, flip):
             off = (ptr - base.data_ptr()) // 4
             dev = base[off:off + 3 * Hh * Ww].cpu().numpy().reshape(1, 3, Hh, Ww)
             np.testing.assert_array_equal(dev.view(np.uint32), want.view(np.uint32))
+
+
+@pytest.mark.parametrize("h,w,f", [(64, 96, 0.5), (64, 96, 0.25), (64, 96, 0.75), (64, 96, 1.5), (64, 96, 2.5), (40, 56, 1.375),
+                                   (48, 80, 0.625)])
+def test_oracle_against_a_third_implementation_of_half_pixel_bilinear(h, w, f):
+    """Not a pin (cv2 is the only thing that could pin a4 / f3), a sanity bound: torch's ``interpolate(mode="bilinear",
+    align_corners=False, recompute_scale_factor=False)`` is the same half-pixel two-tap filter with ``scale = 1 / f`` computed
+    in float64 throughout, so it must agree with the OpenCV restatement up to what OpenCV's FLOAT narrowing of the source
+    coordinate and of the weights does: a coordinate near 100 keeps 2^-17, i.e. the fraction is off by up to ~4e-6 and a
+    blend of pixels up to 255 apart by up to ~1e-3; where the coordinates are exact in float (scale 2 and 4: also OpenCV's
+    2x INTER_AREA shortcut) the two agree to the last double bits.  (Shapes chosen so that floor(n f) == cvRound(n f).)"""
+    import torch
+    import torch.nn.functional as F
+    rng = np.random.default_rng(int(h * 1000 + w + 100 * f))
+    im = rng.integers(0, 256, (h, w, 3)).astype(np.float64) - 115.0
+    a = R.cv_resize_linear_f64(im, f, f)
+    t = torch.from_numpy(im.transpose(2, 0, 1)[None].copy())
+    b = F.interpolate(t, scale_factor=f, mode="bilinear", align_corners=False, recompute_scale_factor=False)
+    b = b.numpy()[0].transpose(1, 2, 0)
+    assert a.shape == b.shape == (R.dsize_of(h, f), R.dsize_of(w, f), 3)
+    err = float(np.abs(a - b).max())
+    if f in (0.5, 0.25):
+        assert err < 1e-10, err
+    else:
+        assert 0.0 < err < 2e-3, err       # not zero: the float narrowing is really there; small: the same filter
