@@ -237,6 +237,9 @@ def main():
     ap.add_argument("--sustain-seconds", type=float, default=6.0,
                     help="N=1: after the timed region, back-to-back steps for this long in the headline mode -> 'sustained' "
                          "(0 to skip); --steps still defines 'value'")
+    ap.add_argument("--overlap-seconds", type=float, default=3.0,
+                    help="N=1: a measurement leg after `sustained` -- the same kernels with consecutive images' convolutions "
+                         "overlapped on two lane sets / two streams -> 'overlapped_pipeline' (0 to skip; never `value`)")
     ap.add_argument("--no-mixed", action="store_true", help="skip the mixed-shape image stream leg ('mixed_shapes', N=1)")
     ap.add_argument("--no-forward-path", action="store_true", help="skip the literal Net.forward() drop-in leg ('net_forward_path', N=1: "
                     "lib/test.py's detect() on the bench image -- host pre-processing, ten Net.forward() with host blobs, C-ABI bbox_vote)")
@@ -485,6 +488,44 @@ def main():
                      "note": "same resident pyramid, same pipeline as the timed region, per-launch HIP events off; "
                              "first / last second = steps completed in that second",
                      "telemetry": sustained_tel}
+
+    # ---- what overlapping consecutive images' convolutions would add (N=1; a MEASUREMENT leg, never `value`): the same
+    #      kernels on two lane sets and two streams (FusedDetector lane_sets=2) fill each other's partial last rounds; every
+    #      kernel's duration then contains its neighbour's blocks, which is why the shipped pipeline does not do it
+    overlapped = None
+    if (not dist_path and args.mode == "group" and args.overlap_seconds > 0 and not args.host_input and
+            args.conv_mode == "f16x3"):
+        from smallhardface_amd.test import FusedDetector as _FD
+        fdo = _FD(net, n_lanes=n_units, mode="group", lane_sets=2)
+        last_o = {}
+        for _ in range(4):
+            fdo.submit(unit_list, thresh, on_device=True)
+            if fdo.pending() > 1:
+                last_o[0] = fdo.collect()[0]
+        while fdo.pending():
+            last_o[0] = fdo.collect()[0]
+        fence()
+        n_o = 0
+        t1 = time.perf_counter()
+        while time.perf_counter() - t1 < args.overlap_seconds:
+            fdo.submit(unit_list, thresh, on_device=True)
+            n_o += 1
+            if fdo.pending() > 1:
+                last_o[0] = fdo.collect()[0]
+        while fdo.pending():
+            last_o[0] = fdo.collect()[0]
+        for ln in fdo.lanes + (fdo._lanes_b or []) + fdo._heads:
+            ln.sync()
+        torch.cuda.synchronize()
+        dt_o = time.perf_counter() - t1
+        overlapped = {"value": n_o / dt_o, "unit": "images/s", "seconds": dt_o, "steps": n_o,
+                      "vs_value": (n_o / dt_o) / (args.steps / elapsed),
+                      "identical_to_headline": bool(headline_dets is not None and 0 in last_o and
+                                                    np.array_equal(np.asarray(last_o[0]), headline_dets)),
+                      "note": "NOT the shipped pipeline and never `value`: two lane sets, two streams, consecutive images' "
+                              "convolutions overlap on the GPU (same kernels, same bits) and fill each other's partial last "
+                              "rounds; per-kernel durations then contain the neighbour's blocks, so no roofline is read from it"}
+        del fdo
 
     # ---- single-image latency: ONE image, nothing else in flight, submit -> merged detections on the host
     latency_ms = None
@@ -866,6 +907,8 @@ def main():
             }
         if sustained is not None:
             out["sustained"] = sustained
+        if overlapped is not None:
+            out["overlapped_pipeline"] = overlapped
         if mixed is not None:
             from_files = mixed.pop("from_files", None)
             out["mixed_shapes"] = mixed

@@ -257,13 +257,20 @@ class FusedDetector(object):
     image spread over execution lanes (own HIP stream + activations, shared weights) so the
     latency-bound small pyramid levels overlap with the large ones."""
 
-    def __init__(self, net, n_lanes=4, mode="streams"):
+    def __init__(self, net, n_lanes=4, mode="streams", lane_sets=1):
         """mode "streams": units spread over lanes running on their own HIP streams;
         mode "group": the lanes only lend activation buffers and every MFMA conv layer runs as
-        ONE grid over all units of the image (shf_detect_add_levels)."""
+        ONE grid over all units of the image (shf_detect_add_levels).
+        ``lane_sets`` (group mode, submit / collect): 1 = the shipped pipeline -- consecutive images share one lane set and one
+        in-order convolution stream, so a kernel's duration is its own; 2 = a MEASUREMENT mode (bench.py `overlapped_pipeline`):
+        the two head lanes get a lane set and a stream each, consecutive images' convolutions overlap on the GPU and fill each
+        other's partial last rounds -- the same kernels, the same bits, more images/s, but every kernel's duration then contains
+        its neighbour's blocks, so no per-kernel roofline can be read off such a run."""
         self.net = net
         self.mode = mode
+        self.lane_sets = 2 if int(lane_sets) >= 2 else 1
         self.lanes = [net] + [net.clone() for _ in range(max(1, n_lanes) - 1)]
+        self._lanes_b = None
         self._xbuf = None
 
     # -- software pipeline over images (group mode): the box merging + read-back of image k overlaps
@@ -274,15 +281,20 @@ class FusedDetector(object):
         same stream: DevicePyramid.units(im, net=fd.next_head()))."""
         if not hasattr(self, "_heads"):
             self._heads = [self.net.clone(), self.net.clone()]
-            # one lane set: image k + 1's convolutions queue behind image k's (both images' convolutions overlapped on two
-            # lane sets measured +3 % images/s in round 2, but then no kernel's duration is its own: removed in round 4)
-            self._heads[0].set_predecessor(self._heads[1])
-            self._heads[1].set_predecessor(self._heads[0])
-            if os.environ.get("SHF_PIPE_SHARED_CONV_STREAM", "1") != "0":
-                # convolutions of consecutive images on one in-order stream, tails + merge on the heads' own
-                # high-priority streams: does not depend on how the runtime maps streams to hardware queues
-                for h in self._heads:
-                    h.set_pipeline(True)
+            if self.lane_sets == 2:
+                # measurement mode: no predecessor, no shared convolution stream -- each head's whole pass on its own stream
+                # over its own lane set (a lane is only ever re-used by the same head, two images later)
+                self._lanes_b = [self.net.clone() for _ in self.lanes]
+            else:
+                # one lane set: image k + 1's convolutions queue behind image k's (both images' convolutions overlapped on two
+                # lane sets measure +3 % images/s, but then no kernel's duration is its own: not the shipped pipeline)
+                self._heads[0].set_predecessor(self._heads[1])
+                self._heads[1].set_predecessor(self._heads[0])
+                if os.environ.get("SHF_PIPE_SHARED_CONV_STREAM", "1") != "0":
+                    # convolutions of consecutive images on one in-order stream, tails + merge on the heads' own
+                    # high-priority streams: does not depend on how the runtime maps streams to hardware queues
+                    for h in self._heads:
+                        h.set_pipeline(True)
             self._turn = 0
             self._inflight = []
         return self._heads[self._turn]
@@ -310,7 +322,7 @@ class FusedDetector(object):
         units = list(units)
         assert self.mode == "group"
         head = self.next_head()
-        lanes = self.lanes
+        lanes = self._lanes_b if (self.lane_sets == 2 and self._turn == 1) else self.lanes
         while len(lanes) < len(units):
             lanes.append(self.net.clone())
         head.detect_begin()

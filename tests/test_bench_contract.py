@@ -65,6 +65,8 @@ def test_bench_json_round6_legs():
     assert n["h2d_ms"] > 0 and n["forward_ms"] > n["h2d_ms"]
     f = d["from_files"]
     assert "decode_prefetch" in f and f["decode_prefetch"] >= 2
+    o = d["overlapped_pipeline"]       # a measurement leg: what overlapping consecutive images' convolutions would add (nothing)
+    assert o["identical_to_headline"] is True and 0.9 < o["vs_value"] < 1.1 and "never `value`" in o["note"]
 
 
 def test_rocprof_summary_names_the_dominant_kernel():

@@ -285,7 +285,8 @@ def _run_bench(tmp_path, world, extra, tag, more_env=None, bare=False):
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
         env.pop(k, None)
     base = [os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "0", "--no-cpu-baseline",
-            "--no-latency", "--no-calib", "--no-reduced", "--no-mixed", "--sustain-seconds", "0", "--dump-dets", out] + extra
+            "--no-latency", "--no-calib", "--no-reduced", "--no-mixed", "--no-forward-path", "--overlap-seconds", "0",
+            "--sustain-seconds", "0", "--dump-dets", out] + extra
     if world == 1:
         cmd = [sys.executable] + base
     elif bare:

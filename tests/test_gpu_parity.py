@@ -658,6 +658,33 @@ def test_get_image_blob_on_the_device_equals_the_host_mirror(shape, scales, conv
         np.testing.assert_array_equal(g['data'].view(np.uint32), w['data'].view(np.uint32))
 
 
+def test_two_lane_sets_overlap_mode_gives_the_same_detections(conv_mode):
+    """FusedDetector(lane_sets=2) -- bench.py's `overlapped_pipeline` measurement leg: each head lane with a lane set and a
+    stream of its own, consecutive images' convolutions overlapping on the GPU -- runs the same kernels on the same data:
+    a stream of alternating images comes back bit for bit as from the shipped one-lane-set pipeline."""
+    from smallhardface_amd import test as T
+    cfg.MODEL.DIFFERENT_DILATION.ENABLE = True
+    cfg.TEST.SCALES = [100, 300, 500]
+    gnet, _ = H.make_pair(H.detector_msg(True), cls_bias=1.0)
+    gnet.set_conv_mode(conv_mode)
+    ims = [np.random.default_rng(70 + i).integers(0, 256, (110 + 9 * i, 150 - 6 * i, 3)).astype(np.uint8) for i in range(3)]
+    units = [list(T.pyramid_units(im)) for im in ims]
+    outs = {}
+    for sets in (1, 2):
+        fd = T.FusedDetector(gnet, n_lanes=6, mode="group", lane_sets=sets)
+        got = []
+        for k in range(7):
+            fd.submit(units[k % 3], 0.05)
+            if fd.pending() > 1:
+                got.append(fd.collect()[0])
+        while fd.pending():
+            got.append(fd.collect()[0])
+        outs[sets] = got
+    assert len(outs[1]) == len(outs[2]) == 7 and len(outs[1][0]) > 0
+    for a, b in zip(outs[1], outs[2]):
+        np.testing.assert_array_equal(a, b)
+
+
 def test_device_preprocessing_feeds_the_detector():
     """uint8 image -> device pyramid -> grouped detector == host pyramid -> grouped detector."""
     from smallhardface_amd import test as T

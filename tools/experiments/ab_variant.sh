@@ -2,8 +2,8 @@ set -u
 cd $GRAFT_REPO_ROOT
 [ "${2:-}" = "test" ] && python -m pytest tests/test_gpu_parity.py tests/test_gpu_magnitudes.py -x -q -m gpu 2>&1 | tail -3
 for i in 1 2; do
-python bench.py --steps 30 --warmup 3 --no-cpu-baseline --no-reduced --no-latency --no-calib --no-mixed --no-forward-path --sustain-seconds 0 2>/dev/null | tail -1 > gpurun_out/ab_new$i.json
-SHF_LIB=$GRAFT_REPO_ROOT/variants/${1:-pre_dbuf}.so python bench.py --steps 30 --warmup 3 --no-cpu-baseline --no-reduced --no-latency --no-calib --no-mixed --no-forward-path --sustain-seconds 0 2>/dev/null | tail -1 > gpurun_out/ab_old$i.json
+python bench.py --steps 30 --warmup 3 --no-cpu-baseline --no-reduced --no-latency --no-calib --no-mixed --no-forward-path --overlap-seconds 0 --sustain-seconds 0 2>/dev/null | tail -1 > gpurun_out/ab_new$i.json
+SHF_LIB=$GRAFT_REPO_ROOT/variants/${1:-pre_dbuf}.so python bench.py --steps 30 --warmup 3 --no-cpu-baseline --no-reduced --no-latency --no-calib --no-mixed --no-forward-path --overlap-seconds 0 --sustain-seconds 0 2>/dev/null | tail -1 > gpurun_out/ab_old$i.json
 done
 python - <<'PY'
 import json
