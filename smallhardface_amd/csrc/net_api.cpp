@@ -125,9 +125,9 @@ int shf_blob_reshape(shf_net* net, int blob, const int* dims, int ndim) {
   API_BEGIN
   if (blob < 0 || blob >= (int)net->blobs.size()) throw std::runtime_error("bad blob index");
   Blob& b = net->blobs[blob];
+  if (ndim < 0 || ndim > 32) throw std::runtime_error("Blob.reshape: 0 .. 32 axes");
   std::vector<int> s(dims, dims + ndim);
-  for (int d : s)
-    if (d < 0) throw std::runtime_error("negative blob dimension");
+  check_blob_dims(s, b.name);
   if (s != b.shape) {
     b.shape = s;
     if (std::count(net->inputs.begin(), net->inputs.end(), blob)) {

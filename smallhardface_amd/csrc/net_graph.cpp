@@ -100,7 +100,22 @@ int conv_out(int n, int k, int pad, int stride, int dil) {
 
 }  // namespace shf
 
-static int geti(const PMsg* m, const char* n, int d) { return m ? (int)m->num(n, d) : d; }
+static int geti(const PMsg* m, const char* n, int d) {
+  if (!m) return d;
+  const long v = m->num(n, d);          // (a value outside int would wrap: clamp, the range checks below refuse it by name)
+  return v > 2147483647L ? 2147483647 : (v < -2147483647L ? -2147483647 : (int)v);
+}
+
+// Blob::Reshape (blob.cpp:23-51): at most 32 axes, every dim >= 0, count <= INT_MAX
+void shf::check_blob_dims(const std::vector<int>& shp, const std::string& name) {
+  if (shp.size() > 32) throw std::runtime_error("blob '" + name + "': more than 32 axes");
+  long long count = 1;
+  for (int d : shp) {
+    if (d < 0) throw std::runtime_error("blob '" + name + "': negative dimension");
+    if (d != 0 && count > 2147483647LL / d) throw std::runtime_error("blob '" + name + "': size exceeds INT_MAX");
+    count *= d;
+  }
+}
 
 void shf_net::build(const std::string& text, const char* caffemodel) {
   proto_text = text;
@@ -126,6 +141,7 @@ void shf_net::build(const std::string& text, const char* caffemodel) {
     else
       for (size_t j = 4 * i; j < 4 * i + 4 && j < in_dims.size(); ++j) shp.push_back(atoi(in_dims[j]->scalar.c_str()));
     if (shp.empty()) shp = {1};
+    check_blob_dims(shp, in_names[i]->scalar);
     blobs[bi].shape = shp;
   }
   for (auto lf : root->all("layer")) {
@@ -146,6 +162,7 @@ void shf_net::build(const std::string& text, const char* caffemodel) {
         if (i < shapes.size() && shapes[i]->msg)
           for (auto d : shapes[i]->msg->all("dim")) shp.push_back(atoi(d->scalar.c_str()));
         if (shp.empty()) shp = {1};
+        check_blob_dims(shp, tops[i]->scalar);
         blobs[bi].shape = shp;
         L.tops.push_back(bi);
       }
@@ -199,6 +216,14 @@ void shf_net::build(const std::string& text, const char* caffemodel) {
       L.dil = geti(cp, "dilation", 1);
       L.group = geti(cp, "group", 1);
       L.bias_term = cp->str("bias_term", "true") != "false";
+      // BaseConvolutionLayer::LayerSetUp's CHECKs (base_conv_layer.cpp:21-120): Caffe aborts on these, here the graph is refused
+      // with the layer's name -- a hostile prototxt must not reach a division by a zero stride or a 2^31-channel allocation
+      if (L.nout < 1 || L.nout > (1 << 20)) throw std::runtime_error("layer '" + L.name + "': num_output must be in 1 .. 2^20");
+      if (L.k < 1 || L.k > 64) throw std::runtime_error("layer '" + L.name + "': kernel_size must be in 1 .. 64");
+      if (L.stride < 1 || L.stride > 64) throw std::runtime_error("layer '" + L.name + "': stride must be in 1 .. 64");
+      if (L.dil < 1 || L.dil > 64) throw std::runtime_error("layer '" + L.name + "': dilation must be in 1 .. 64");
+      if (L.pad < 0 || L.pad > 4096) throw std::runtime_error("layer '" + L.name + "': pad must be in 0 .. 4096");
+      if (L.group < 1 || L.nout % L.group) throw std::runtime_error("layer '" + L.name + "': group must divide num_output");
       L.op = (L.type == "Convolution") ? OP_CONV : OP_DECONV;
     } else if (L.type == "ReLU") {
       if (L.bottoms.size() != 1 || L.tops.size() != 1 || L.bottoms[0] != L.tops[0])
@@ -220,6 +245,9 @@ void shf_net::build(const std::string& text, const char* caffemodel) {
       L.k = geti(pp, "kernel_size", 2);
       L.stride = geti(pp, "stride", 1);
       L.pad = geti(pp, "pad", 0);
+      // PoolingLayer::LayerSetUp (pooling_layer.cpp:20-77): kernel > 0, stride > 0, pad < kernel
+      if (L.k < 1 || L.k > 64 || L.stride < 1 || L.stride > 64 || L.pad < 0 || L.pad >= L.k)
+        throw std::runtime_error("layer '" + L.name + "': pooling needs kernel_size 1 .. 64, stride 1 .. 64 and 0 <= pad < kernel_size");
       L.op = OP_POOL;
     } else if (L.type == "Python") {
       const PMsg* py = L.msg->sub("python_param");

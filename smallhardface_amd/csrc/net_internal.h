@@ -148,6 +148,8 @@ enum FusedRole {
   FR_PROB_PLANES   // the Softmax's top, (1, 2, A*h, w): the memory of the materialised (1, 2A, h, w) cls_prob blob
 };
 
+void check_blob_dims(const std::vector<int>& shp, const std::string& name);   // net_graph.cpp: Blob::Reshape's limits
+
 enum OpType { OP_SKIP, OP_CONV, OP_POOL, OP_DECONV, OP_TAIL };
 
 struct Layer {

@@ -367,6 +367,36 @@ def test_every_blob_is_readable_after_forward(dd, conv_mode):
         assert H.rel_err(gnet.blobs["conv3_3"].data, onet.blobs["conv3_3"].data) < ACT_TOL
 
 
+@pytest.mark.parametrize("bad,msg", [
+    ("stride: 0", "stride must be"), ("kernel_size: 0", "kernel_size must be"), ("num_output: 0", "num_output must be"),
+    ("num_output: 99999999999", "num_output must be"), ("dilation: 0", "dilation must be"), ("pad: -3", "pad must be"),
+    ("group: 3", "group must divide"), ("kernel_size: 4000000000", "kernel_size must be"),
+])
+def test_hostile_layer_parameters_are_refused_by_name(bad, msg, conv_mode):
+    """BaseConvolutionLayer::LayerSetUp's CHECKs (base_conv_layer.cpp:21-120) abort Caffe; here a prototxt with a zero stride,
+    a zero / absurd kernel, no or 10^11 outputs ... is refused at caffe.Net() with the layer's name -- no division by zero, no
+    2^31-channel allocation, the process lives on (tests/test_parser_robustness.py covers the SYNTAX of hostile files)."""
+    if conv_mode != "fp32":
+        pytest.skip("graph construction only")
+    from smallhardface_amd import caffe
+    key = bad.split(":")[0]
+    base = {"num_output": "num_output: 8", "kernel_size": "kernel_size: 3", "pad": "pad: 1", "stride": "", "dilation": "", "group": ""}
+    base[key] = bad
+    txt = ('input: "data" input_shape { dim: 1 dim: 3 dim: 16 dim: 16 }\n'
+           'layer { name: "evil" type: "Convolution" bottom: "data" top: "c" convolution_param { %s } }\n' % " ".join(v for v in base.values() if v))
+    with pytest.raises(RuntimeError, match=msg):
+        caffe.Net(None, prototxt_text=txt)
+    for shape, m2 in (("dim: 1 dim: 3 dim: -4 dim: 16", "negative dimension"), ("dim: 65536 dim: 65536 dim: 4", "exceeds INT_MAX")):
+        with pytest.raises(RuntimeError, match=m2):
+            caffe.Net(None, prototxt_text='input: "data" input_shape { %s }\n' % shape)
+    ok = caffe.Net(None, prototxt_text='input: "data" input_shape { dim: 1 dim: 3 dim: 16 dim: 16 }\n'
+                   'layer { name: "fine" type: "Convolution" bottom: "data" top: "c" convolution_param { num_output: 8 kernel_size: 3 pad: 1 } }\n')
+    with pytest.raises(Exception, match="INT_MAX|negative"):
+        ok.blobs["data"].reshape(70000, 70000)
+    with pytest.raises(Exception, match="INT_MAX|negative"):
+        ok.blobs["data"].reshape(1, 3, -1, 16)
+
+
 def test_proposal_edge_cases():
     """all-below-threshold keeps the single best anchor; >10000 candidates are cut at N_DETS_PER_MODULE."""
     msg = H.detector_msg(True)
